@@ -1,0 +1,522 @@
+/*
+  gts_component.hpp -- cycle removal and scaffold construction for ONE weakly
+  connected component of the filtered scaffold graph, executed by ONE
+  wavefront.
+
+  ref src/gt_scaffolder_algorithms.c:346-868 (isterminal, calc_cc_and_terminals,
+  detect_cycle_recursive, removecycles, create_walk, makescaffold).
+
+  Why components: every traversal of those functions follows unmarked edges
+  between unmarked vertices, and every mark they set lands on edges incident
+  to the vertex being marked.  Edge states are NOT symmetric after the filter
+  (algorithms.c:249-258 marks edges whose twins stay unmarked), so the unit of
+  independence is the WEAKLY connected component (an unmarked edge in either
+  direction joins its end vertices).  Inside a component the reference's
+  order-dependent semantics are kept exactly: its "connected components" are
+  directed BFS reachability sets taken in vertex-index order, terminals are in
+  BFS order, the DFS visits adjacency lists in insertion order, walks use the
+  FIFO label-correcting search with float distance maps, strict-greater
+  tie-breaks and LIFO evaluation of reached terminals.
+
+  Execution model: the wavefront runs the component's sequential program with
+  wave-uniform control flow; the 64 lanes share each adjacency-list scan
+  (one coalesced 64-entry chunk per step, __ballot to pick / order the
+  qualifying edges, popcount prefix sums to append to the BFS / walk queues in
+  list order) and the back-tracking of the reached terminals.  W is the wave
+  policy: 64 lanes on gfx950; the test harness instantiates it with 1 lane on
+  the host.
+
+  Component-local ("compact") graph: vertices of all non-trivial components
+  are renumbered into slots (sorted by component, then vertex index) and their
+  live edges (unmarked when the component phase starts) are copied into a
+  compact CSR in list order.  Marks set here (CYCLIC, SCAFFOLD) go to the
+  global graph AND to the compact copy.
+*/
+#ifndef GTS_COMPONENT_HPP
+#define GTS_COMPONENT_HPP
+
+#include "gts_defs.h"
+
+enum { GTS_MODE_REMOVECYCLES = 0, GTS_MODE_MAKESCAFFOLD = 1 };
+enum { GTS_CERR_NONE = 0, GTS_CERR_WALKQ_OVERFLOW = 1, GTS_CERR_WALK_LOOP = 2 };
+
+struct GtsCompView {
+  GtsGraphView G;            /* global graph (marks are mirrored there) */
+  const uint32_t *cmap;      /* m: global position -> compact edge or NONE */
+  uint32_t ncomp;
+  const uint32_t *comp_off;  /* ncomp+1: slot range of a component */
+  const uint32_t *slot_v;    /* slot -> global vertex */
+  const int64_t *cseq;       /* slot -> seq_len */
+  const uint32_t *coff;      /* nslots+1: compact edge range of a slot */
+  const uint32_t *cstart;    /* compact edge -> start slot */
+  const uint32_t *cend;      /* compact edge -> end slot */
+  const int64_t *cdist;
+  const uint8_t *cflags;
+  const uint32_t *cgpos;     /* compact edge -> global position */
+  uint8_t *cstate;           /* compact copy of the edge state */
+  uint8_t *vst;              /* slot -> vertex state */
+  /* per-slot scratch (a component uses its own slot range) */
+  uint32_t *queue, *term, *visited, *st_v, *st_par, *st_cur, *edgemap,
+      *lastpop, *wterm, *touched, *cc_best;
+  uint8_t *st_dir;
+  float *distmap;            /* all GTS_DIST_UNSET between walks */
+  uint32_t *ccoff;           /* nslots + ncomp entries; comp c at comp_off[c]+c */
+  /* walk FIFO: ring per component, wq_off[c]..wq_off[c+1] */
+  const uint64_t *wq_off;    /* ncomp+1 */
+  uint32_t *wq_edge;
+  int64_t *wq_dist;
+  uint32_t *cerr;            /* ncomp: error code per component */
+  uint64_t max_pops;         /* bound on queue pops of one walk */
+};
+
+/* (float)GT_WORD_MAX, ref algorithms.c:650 */
+#define GTS_DIST_UNSET 9223372036854775808.0f
+
+template <class W>
+struct GtsComponent {
+  const GtsCompView &C;
+  uint32_t c, s0, s1;   /* component, slot range */
+  uint32_t nterm, ncc;  /* filled by calc_cc */
+  uint32_t err;
+  /* walk-queue state of the walk in flight */
+  uint64_t qbase, qcap, qh, qn;
+  uint32_t ntouch;
+
+  GTS_HD GtsComponent(const GtsCompView &cv, uint32_t comp)
+      : C(cv), c(comp), s0(cv.comp_off[comp]), s1(cv.comp_off[comp + 1]),
+        nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0), ntouch(0) {}
+
+  GTS_HD uint32_t *ccoffs() const { return C.ccoff + s0 + c; }
+
+  /* ---- ref algorithms.c:379-436 (with isterminal, :346-373, fused) ---- */
+  GTS_HD void calc_cc()
+  {
+    const uint32_t lane = W::lane();
+    for (uint32_t s = s0 + lane; s < s1; s += W::WIDTH)
+      if (!gts_vertex_is_marked(C.vst[s])) C.vst[s] = GIS_UNVISITED;
+    W::fence();
+    uint32_t *ccoff = ccoffs();
+    nterm = 0; ncc = 0;
+    for (uint32_t s = s0; s < s1; ++s) {
+      const uint8_t st = (uint8_t)W::uni(C.vst[s]);
+      if (gts_vertex_is_marked(st) || st == GIS_VISITED) continue;
+      C.vst[s] = GIS_PROCESSED;
+      C.queue[s0] = s;
+      ccoff[ncc++] = nterm;
+      W::fence();
+      uint32_t bh = 0, bn = 1;
+      while (bh < bn) {
+        const uint32_t cur = W::uni(C.queue[s0 + bh]);
+        ++bh;
+        const uint32_t eb = W::uni(C.coff[cur]), ee = W::uni(C.coff[cur + 1]);
+        bool has_s = false, has_a = false;
+        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+          const uint32_t ce = base + lane;
+          bool live = false, sense = false, unv = false;
+          uint32_t nb = 0;
+          if (ce < ee) {
+            live = !gts_edge_is_marked(C.cstate[ce]);
+            sense = (C.cflags[ce] & GTS_F_SENSE) != 0;
+            nb = C.cend[ce];
+            unv = live && C.vst[nb] == GIS_UNVISITED;
+          }
+          has_s |= W::ballot(live && sense) != 0;
+          has_a |= W::ballot(live && !sense) != 0;
+          const uint64_t mask = W::ballot(unv);
+          if (unv) {
+            C.queue[s0 + bn + W::popc_below(mask, lane)] = nb;
+            C.vst[nb] = GIS_PROCESSED;
+          }
+          bn += W::popc(mask);
+          W::fence();
+        }
+        if (!(has_s && has_a)) C.term[s0 + nterm++] = cur;
+        C.vst[cur] = GIS_VISITED;
+        W::fence();
+      }
+    }
+    ccoff[ncc] = nterm;
+    W::fence();
+  }
+
+  /* ---- ref algorithms.c:448-492, explicit stack.  Returns the compact edge
+     that closes a cycle or GTS_NONE. ---- */
+  GTS_HD uint32_t detect_cycle(uint32_t start, bool dir0, uint32_t &nvis)
+  {
+    const uint32_t lane = W::lane();
+    uint32_t sp = 1;
+    nvis = 0;
+    C.st_v[s0] = start; C.st_par[s0] = GTS_NONE; C.st_cur[s0] = C.coff[start];
+    C.st_dir[s0] = dir0 ? 1 : 0;
+    C.visited[s0 + nvis++] = start;
+    C.vst[start] = GIS_VISITED;
+    W::fence();
+    while (sp > 0) {
+      const uint32_t f = s0 + sp - 1;
+      const uint32_t v = W::uni(C.st_v[f]), par = W::uni(C.st_par[f]);
+      const bool dir = W::uni((uint32_t)C.st_dir[f]) != 0;
+      uint32_t cur = W::uni(C.st_cur[f]);
+      const uint32_t ee = W::uni(C.coff[v + 1]);
+      bool descended = false;
+      while (cur < ee) {
+        const uint32_t ce = cur + lane;
+        bool cand = false;
+        uint32_t nb = 0, vs = 0, fl = 0;
+        if (ce < ee) {
+          fl = C.cflags[ce];
+          nb = C.cend[ce];
+          if (((fl & GTS_F_SENSE) != 0) == dir &&
+              !gts_edge_is_marked(C.cstate[ce]) && nb != par) {
+            vs = C.vst[nb];
+            cand = !gts_vertex_is_marked((uint8_t)vs) && vs != GIS_PROCESSED;
+          }
+        }
+        const uint64_t mask = W::ballot(cand);
+        if (mask) {
+          const uint32_t l = W::ctz(mask);
+          const uint32_t nb_l = W::shfl(nb, l), vs_l = W::shfl(vs, l);
+          const uint32_t fl_l = W::shfl(fl, l);
+          if (vs_l == GIS_VISITED) return cur + l;      /* back edge */
+          /* GIS_UNVISITED: descend */
+          C.st_cur[f] = cur + l + 1;
+          const uint32_t g = s0 + sp;
+          C.st_v[g] = nb_l; C.st_par[g] = v; C.st_cur[g] = C.coff[nb_l];
+          C.st_dir[g] = gts_next_dir((uint8_t)fl_l) ? 1 : 0;
+          ++sp;
+          C.visited[s0 + nvis++] = nb_l;
+          C.vst[nb_l] = GIS_VISITED;
+          W::fence();
+          descended = true;
+          break;
+        }
+        cur += W::WIDTH;
+      }
+      if (!descended) {
+        C.vst[v] = GIS_PROCESSED;
+        --sp;
+        W::fence();
+      }
+    }
+    return GTS_NONE;
+  }
+
+  /* ---- ref algorithms.c:61-87 mark_vertex(v, GIS_CYCLIC) ---- */
+  GTS_HD void mark_vertex_cyclic(uint32_t s)
+  {
+    const uint32_t lane = W::lane();
+    const uint32_t v = C.slot_v[s];
+    C.vst[s] = GIS_CYCLIC;
+    C.G.vstate[v] = GIS_CYCLIC;
+    const uint32_t b = C.G.row[v], e = C.G.row[v + 1];
+    for (uint32_t p = b + lane; p < e; p += W::WIDTH) {
+      const uint32_t t = C.G.twin[p];
+      C.G.state[p] = GIS_CYCLIC;
+      C.G.state[t] = GIS_CYCLIC;
+      const uint32_t cp = C.cmap[p], ct = C.cmap[t];
+      if (cp != GTS_NONE) C.cstate[cp] = GIS_CYCLIC;
+      if (ct != GTS_NONE) C.cstate[ct] = GIS_CYCLIC;
+    }
+    W::fence();
+  }
+
+  /* ---- ref algorithms.c:495-578 ---- */
+  GTS_HD void removecycles()
+  {
+    const uint32_t lane = W::lane();
+    bool found = true;
+    while (found) {
+      found = false;
+      calc_cc();
+      for (uint32_t s = s0 + lane; s < s1; s += W::WIDTH)
+        if (!gts_vertex_is_marked(C.vst[s])) C.vst[s] = GIS_UNVISITED;
+      W::fence();
+      /* the ccs are visited in order; their boundaries do not matter here */
+      for (uint32_t j = 0; j < nterm; ++j) {
+        const uint32_t start = W::uni(C.term[s0 + j]);
+        /* direction of the LAST unmarked edge, algorithms.c:533-538 */
+        const uint32_t eb = W::uni(C.coff[start]), ee = W::uni(C.coff[start + 1]);
+        bool set_dir = false, dir = true;
+        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+          const uint32_t ce = base + lane;
+          bool live = false;
+          uint32_t fl = 0;
+          if (ce < ee) {
+            live = !gts_edge_is_marked(C.cstate[ce]);
+            fl = C.cflags[ce];
+          }
+          const uint64_t mask = W::ballot(live);
+          if (mask) {
+            dir = (W::shfl(fl, W::msb(mask)) & GTS_F_SENSE) != 0;
+            set_dir = true;
+          }
+        }
+        if (!set_dir) continue;
+        if (gts_vertex_is_marked((uint8_t)W::uni(C.vst[start]))) continue;
+        uint32_t nvis = 0;
+        const uint32_t back = detect_cycle(start, dir, nvis);
+        for (uint32_t k = lane; k < nvis; k += W::WIDTH)
+          C.vst[C.visited[s0 + k]] = GIS_UNVISITED;
+        W::fence();
+        if (back != GTS_NONE) {
+          found = true;
+          const uint32_t a = W::uni(C.cstart[back]), b = W::uni(C.cend[back]);
+          mark_vertex_cyclic(a);
+          mark_vertex_cyclic(b);
+        }
+      }
+    }
+  }
+
+  /* one lane's relaxation of edge ce (start's seeding when unconditional,
+     ref algorithms.c:671-677; otherwise algorithms.c:706-723).  q selects the
+     participating lanes; they must have distinct end slots nb. */
+  GTS_HD bool relax_distinct(bool q, uint32_t nb, uint32_t ce, float distance,
+                             int64_t pushd, bool unconditional)
+  {
+    const uint32_t lane = W::lane();
+    float old = 0.0f;
+    if (q) old = C.distmap[nb];
+    const bool imp = q && (unconditional || old == GTS_DIST_UNSET || old > distance);
+    const bool fresh = imp && old == GTS_DIST_UNSET;
+    const uint64_t im = W::ballot(imp), fm = W::ballot(fresh);
+    const uint32_t ni = W::popc(im);
+    if (qn + ni - qh > qcap) { err = GTS_CERR_WALKQ_OVERFLOW; return false; }
+    if (imp) {
+      C.distmap[nb] = distance;
+      C.edgemap[nb] = ce;
+      const uint64_t slot = qbase + (qn + W::popc_below(im, lane)) % qcap;
+      C.wq_edge[slot] = ce;
+      C.wq_dist[slot] = pushd;
+    }
+    if (fresh) C.touched[s0 + ntouch + W::popc_below(fm, lane)] = nb;
+    qn += ni;
+    ntouch += W::popc(fm);
+    W::fence();
+    return true;
+  }
+
+  /* the same for lanes that may share an end slot (self loops only): one
+     lane at a time, in list order */
+  GTS_HD bool relax_ordered(bool q, uint32_t nb, uint32_t ce, float distance,
+                            int64_t pushd, bool unconditional)
+  {
+    const uint32_t lane = W::lane();
+    uint64_t qm = W::ballot(q);
+    while (qm) {
+      const uint32_t l = W::ctz(qm);
+      qm &= qm - 1;
+      if (!relax_distinct(q && lane == l, nb, ce, distance, pushd, unconditional))
+        return false;
+    }
+    return true;
+  }
+
+  /* ---- ref algorithms.c:620-763.  Runs the label-correcting search from
+     terminal `start`, evaluates the reached terminals and, if the best walk is
+     longer than cc_len, stores it in cc_best (edge order as the reference:
+     from the far terminal back to start).  Returns false on error. ---- */
+  GTS_HD bool create_walk(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
+  {
+    const uint32_t lane = W::lane();
+    const uint32_t gv = C.slot_v[start];
+    if (W::uni(C.G.row[gv + 1]) == W::uni(C.G.row[gv])) return true; /* :655 */
+    qbase = C.wq_off[c]; qcap = C.wq_off[c + 1] - qbase;
+    qh = 0; qn = 0; ntouch = 0;
+    uint32_t nwt = 0, popseq = 0;
+    bool ok = true;
+    /* seed with the start's live edges, algorithms.c:661-679 */
+    {
+      const uint32_t eb = W::uni(C.coff[start]), ee = W::uni(C.coff[start + 1]);
+      for (uint32_t base = eb; base < ee && ok; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool live = false;
+        uint32_t nb = 0;
+        int64_t d = 0;
+        if (ce < ee) {
+          live = !gts_edge_is_marked(C.cstate[ce]);
+          nb = C.cend[ce];
+          d = C.cdist[ce];
+        }
+        if (W::popc(W::ballot(live && nb == start)) >= 2)
+          ok = relax_ordered(live, nb, ce, (float)d, d, true);
+        else
+          ok = relax_distinct(live, nb, ce, (float)d, d, true);
+      }
+    }
+    uint64_t pops = 0;
+    while (ok && qh < qn) {
+      const uint64_t slot = qbase + qh % qcap;
+      const uint32_t pe = W::uni(C.wq_edge[slot]);
+      const int64_t nd = W::uni64(C.wq_dist[slot]);
+      ++qh;
+      if (++pops > C.max_pops) { err = GTS_CERR_WALK_LOOP; ok = false; break; }
+      const uint32_t endv = W::uni(C.cend[pe]), from = W::uni(C.cstart[pe]);
+      const bool dir = gts_next_dir((uint8_t)W::uni((uint32_t)C.cflags[pe]));
+      const uint32_t eb = W::uni(C.coff[endv]), ee = W::uni(C.coff[endv + 1]);
+      bool has_s = false, has_a = false;
+      for (uint32_t base = eb; base < ee && ok; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool live = false, sense = false, q = false;
+        uint32_t nb = 0;
+        float distance = 0.0f;
+        if (ce < ee) {
+          live = !gts_edge_is_marked(C.cstate[ce]);
+          sense = (C.cflags[ce] & GTS_F_SENSE) != 0;
+          nb = C.cend[ce];
+          /* is_twin(edge, nextedge), algorithms.c:702: nextedge ends where
+             edge started */
+          q = live && sense == dir && nb != from &&
+              !gts_vertex_is_marked(C.vst[nb]);
+          distance = (float)(nd + C.cdist[ce]);
+        }
+        has_s |= W::ballot(live && sense) != 0;
+        has_a |= W::ballot(live && !sense) != 0;
+        if (W::popc(W::ballot(q && nb == endv)) >= 2)
+          ok = relax_ordered(q, nb, ce, distance, (int64_t)distance, false);
+        else
+          ok = relax_distinct(q, nb, ce, distance, (int64_t)distance, false);
+      }
+      /* terminal bookkeeping, algorithms.c:694-695: remember the LAST pop */
+      if (!(has_s && has_a)) {
+        if (W::uni(C.lastpop[endv]) == 0) C.wterm[s0 + nwt++] = endv;
+        C.lastpop[endv] = ++popseq;
+        W::fence();
+      }
+    }
+    /* evaluate the reached terminals, algorithms.c:732-756: the reference pops
+       them from the back and keeps a strictly longer walk, i.e. it returns the
+       longest walk and, among equals, the terminal popped last.  Each lane
+       back-tracks its own terminals. */
+    uint64_t best_len = 0;
+    uint32_t best_pop = 0, best_t = GTS_NONE;
+    if (ok) {
+      const uint32_t limit = s1 - s0 + 1;
+      bool loop_err = false;
+      for (uint32_t k = lane; k < nwt; k += W::WIDTH) {
+        const uint32_t t = C.wterm[s0 + k];
+        uint64_t len = (uint64_t)C.cseq[start];
+        uint32_t cv = t, steps = 0;
+        while (cv != start) {
+          const uint32_t re = C.edgemap[cv];
+          len += (uint64_t)C.cseq[cv];
+          cv = C.cstart[re];
+          if (++steps > limit) { loop_err = true; break; }
+        }
+        const uint32_t lp = C.lastpop[t];
+        if (len > best_len || (len == best_len && len > 0 && lp > best_pop)) {
+          best_len = len; best_pop = lp; best_t = t;
+        }
+      }
+      if (W::ballot(loop_err)) { err = GTS_CERR_WALK_LOOP; ok = false; }
+      /* wave arg-max on (len, lastpop) */
+      for (uint32_t off = W::WIDTH / 2; off > 0; off >>= 1) {
+        const uint64_t ol = W::shfl64(best_len, lane ^ off);
+        const uint32_t op = W::shfl(best_pop, lane ^ off);
+        const uint32_t ot = W::shfl(best_t, lane ^ off);
+        if (ol > best_len || (ol == best_len && op > best_pop)) {
+          best_len = ol; best_pop = op; best_t = ot;
+        }
+      }
+      best_len = W::uni64((int64_t)best_len);
+      best_t = W::uni(best_t);
+    }
+    /* makescaffold keeps the first strictly longer walk, algorithms.c:826-832 */
+    if (ok && best_t != GTS_NONE && best_len > cc_len) {
+      uint32_t cv = best_t, n = 0;
+      while (cv != start) {
+        const uint32_t re = W::uni(C.edgemap[cv]);
+        C.cc_best[s0 + n++] = re;
+        cv = W::uni(C.cstart[re]);
+      }
+      cc_len = best_len;
+      cc_n = n;
+      W::fence();
+    }
+    /* leave the maps clean for the next walk */
+    for (uint32_t k = lane; k < ntouch; k += W::WIDTH)
+      C.distmap[C.touched[s0 + k]] = GTS_DIST_UNSET;
+    for (uint32_t k = lane; k < nwt; k += W::WIDTH)
+      C.lastpop[C.wterm[s0 + k]] = 0;
+    W::fence();
+    return ok;
+  }
+
+  /* ---- ref algorithms.c:767-868 (after its removecycles call) ---- */
+  GTS_HD void makescaffold()
+  {
+    const uint32_t lane = W::lane();
+    calc_cc();
+    const uint32_t *ccoff = ccoffs();
+    for (uint32_t i = 0; i < ncc && !err; ++i) {
+      const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
+      if (te - tb == 1) {                    /* algorithms.c:790-807 */
+        const uint32_t v = W::uni(C.term[s0 + tb]);
+        const uint32_t eb = W::uni(C.coff[v]), ee = W::uni(C.coff[v + 1]);
+        bool any_live = false;
+        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+          const uint32_t ce = base + lane;
+          const bool live = ce < ee && !gts_edge_is_marked(C.cstate[ce]);
+          any_live |= W::ballot(live) != 0;
+        }
+        if (!any_live) C.vst[v] = GIS_SCAFFOLD;
+        W::fence();
+      }
+      if (te - tb > 1) {
+        uint64_t cc_len = 0;
+        uint32_t cc_n = 0;
+        for (uint32_t j = tb; j < te; ++j)
+          if (!create_walk(W::uni(C.term[s0 + j]), cc_len, cc_n)) break;
+        if (err) break;
+        /* mark the best walk, algorithms.c:835-848 (a walk without edges is
+           undefined behaviour there and is left unmarked here) */
+        if (cc_n > 0) {
+          for (uint32_t k = lane; k < cc_n; k += W::WIDTH) {
+            const uint32_t ce = C.cc_best[s0 + k];
+            const uint32_t p = C.cgpos[ce], t = C.G.twin[p];
+            C.cstate[ce] = GIS_SCAFFOLD;
+            C.G.state[p] = GIS_SCAFFOLD;
+            C.G.state[t] = GIS_SCAFFOLD;
+            const uint32_t ct = C.cmap[t];
+            if (ct != GTS_NONE) C.cstate[ct] = GIS_SCAFFOLD;
+            C.vst[C.cend[ce]] = GIS_SCAFFOLD;
+            C.vst[C.cstart[ce]] = GIS_SCAFFOLD;
+          }
+          W::fence();
+        }
+      }
+    }
+  }
+
+  GTS_HD void run(int mode)
+  {
+    const uint32_t lane = W::lane();
+    removecycles();
+    if (mode == GTS_MODE_MAKESCAFFOLD) makescaffold();
+    for (uint32_t s = s0 + lane; s < s1; s += W::WIDTH) {
+      const uint8_t st = C.vst[s];
+      /* removecycles leaves every unmarked vertex UNVISITED (algorithms.c:
+         513-517, 550-553); makescaffold leaves VISITED or SCAFFOLD */
+      C.G.vstate[C.slot_v[s]] = st;
+    }
+    if (lane == 0) C.cerr[c] = err;
+    W::fence();
+  }
+};
+
+/* host / test wave policy: one lane */
+struct GtsWave1 {
+  static const uint32_t WIDTH = 1;
+  static GTS_HD uint32_t lane() { return 0; }
+  static GTS_HD uint64_t ballot(bool p) { return p ? 1u : 0u; }
+  static GTS_HD uint32_t popc(uint64_t m) { return (uint32_t)(m & 1u); }
+  static GTS_HD uint32_t popc_below(uint64_t, uint32_t) { return 0; }
+  static GTS_HD uint32_t ctz(uint64_t) { return 0; }
+  static GTS_HD uint32_t msb(uint64_t) { return 0; }
+  static GTS_HD uint32_t shfl(uint32_t v, uint32_t) { return v; }
+  static GTS_HD uint64_t shfl64(uint64_t v, uint32_t) { return v; }
+  static GTS_HD uint32_t uni(uint32_t v) { return v; }
+  static GTS_HD int64_t uni64(int64_t v) { return v; }
+  static GTS_HD void fence() {}
+};
+
+#endif

@@ -1,0 +1,73 @@
+"""The engine's data-parallel reformulation (time-stamped filter, per weak
+component cycle removal / scaffold construction) checked against the oracle on
+the host.  The same sources are compiled into the gfx950 kernels."""
+import numpy as np
+import pytest
+
+from helpers import DEFAULTS, HostSimGraph, csr_from_oracle, make_inputs, oracle_from_inputs
+
+
+def run_both(g, ocutoff=400, pcutoff=0.01, cncutoff=1.5, stages=("rep", "filter", "cyc", "mk")):
+    og = oracle_from_inputs(g)
+    hs = HostSimGraph(csr_from_oracle(og))
+    out = []
+    og.mark_repeats(); hs.mark_repeats()
+    out.append(("rep", og.vertex_states(), og.edge_states(), hs.vertex_states(), hs.edge_states()))
+    og.filter(pcutoff, cncutoff, ocutoff); hs.filter(pcutoff, cncutoff, ocutoff)
+    out.append(("filter", og.vertex_states(), og.edge_states(), hs.vertex_states(), hs.edge_states()))
+    if "cyc" in stages:
+        og.removecycles(); assert hs.removecycles() == 0
+        out.append(("cyc", og.vertex_states(), og.edge_states(), hs.vertex_states(), hs.edge_states()))
+    if "mk" in stages:
+        og.makescaffold(True); assert hs.makescaffold() == 0
+        out.append(("mk", og.vertex_states(), og.edge_states(), hs.vertex_states(), hs.edge_states()))
+    return out, hs
+
+
+def check(out):
+    for tag, ov, oe, hv, he in out:
+        assert np.array_equal(ov, hv), "%s vertex states differ at %s" % (tag, np.nonzero(ov != hv)[0][:10])
+        assert np.array_equal(oe, he), "%s edge states differ at %s" % (tag, np.nonzero(oe != he)[0][:10])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_small_random_graphs(seed):
+    g = make_inputs(300 + 37 * seed, seed, p_chimeric=0.03, p_bubble=0.05, p_repeat=0.03)
+    out, _ = run_both(g)
+    check(out)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_dense_noise(seed):
+    # many chimeric links: cycles, inconsistent overlaps, asymmetric edge states
+    g = make_inputs(400, 100 + seed, p_chimeric=0.3, p_bubble=0.1, p_repeat=0.05, links_per_side=3)
+    out, _ = run_both(g)
+    check(out)
+
+
+@pytest.mark.parametrize("ocutoff", [-1, 0, 50, 100000])
+def test_overlap_cutoffs(ocutoff):
+    g = make_inputs(500, 7, p_chimeric=0.1)
+    out, _ = run_both(g, ocutoff=ocutoff)
+    check(out)
+
+
+@pytest.mark.parametrize("pcutoff,cncutoff", [(0.0, 1.5), (0.2, 3.0), (0.49, 10.0), (-1.0, 100.0), (0.6, 1.5)])
+def test_poly_cutoffs(pcutoff, cncutoff):
+    g = make_inputs(500, 9, p_bubble=0.1)
+    out, _ = run_both(g, pcutoff=pcutoff, cncutoff=cncutoff)
+    check(out)
+
+
+def test_tie_heavy_walks():
+    # small distance range provokes equal-distance paths and equal-length walks
+    g = make_inputs(600, 21, dist_range_small=True, contig_median=300)
+    out, _ = run_both(g)
+    check(out)
+
+
+def test_medium():
+    g = make_inputs(20000, 5)
+    out, hs = run_both(g)
+    check(out)
+    assert hs.ncomp > 100
