@@ -1,0 +1,1293 @@
+/*
+  gts_engine.hip -- MI355X (gfx950) scaffold-graph engine behind the C ABI of
+  include/gt_scaffold_hip.h.
+
+  Pipeline (all on one HIP stream, graph resident in HBM):
+    build      records -> (pair key, record#) radix sort -> segment scan picks
+               the creating record and the surviving estimate per direction
+               (ref parser.c:357-378) -> edge ids by prefix sum -> stable sort
+               by start vertex -> CSR in adjacency order, twin positions.
+    repeats    ref algorithms.c:155-167 as one vertex pass + one edge pass.
+    filter     gts_filter.hpp: pair pass, two lexicographic fixpoints solved in
+               rounds, last-writer edge states.
+    components weak components (atomic min-root hooking), slots sorted by
+               (component, vertex), compact CSR of live edges, then one
+               wavefront per component runs gts_component.hpp.
+*/
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gt_scaffold_hip.h"
+#include "gts_amb_host.h"
+#include "gts_component.hpp"
+#include "gts_defs.h"
+#include "gts_filter.hpp"
+#include "gts_prims.hpp"
+
+/* ------------------------------------------------------------------ */
+/* engine object                                                       */
+
+struct GtsgEngine {
+  int device = 0;
+  hipStream_t st = nullptr;
+  bool own_stream = false;
+  std::string err;
+  /* vertices */
+  uint32_t n = 0;
+  int64_t *seq_len = nullptr;
+  float *astat = nullptr, *copy_num = nullptr;
+  uint8_t *vstate = nullptr;
+  /* edges, CSR / adjacency order */
+  uint32_t m = 0;
+  uint32_t *row = nullptr, *estart = nullptr, *eend = nullptr, *twin = nullptr,
+           *eid = nullptr, *pos_of_eid = nullptr;
+  int64_t *dist = nullptr, *npairs = nullptr;
+  float *sd = nullptr;
+  uint8_t *flags = nullptr, *state = nullptr;
+  uint32_t nhub = 0;
+  uint32_t *hubs = nullptr;
+  /* workspace */
+  char *pool = nullptr;
+  size_t pool_cap = 0, pool_used = 0;
+  uint32_t *d_scalars = nullptr;   /* 16 x u64 device scalars */
+  /* options */
+  int64_t walk_queue_factor = 8, max_walk_pops = 1ll << 32, hub_degree = 32;
+  bool profile = false;
+  /* profiling */
+  struct Pending { const char *name; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+  std::map<std::string, std::pair<uint64_t, double>> ktimes;
+  std::map<std::string, int64_t> stats;
+};
+
+static int fail(GtsgEngine *e, int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf;
+  return code;
+}
+
+#define HIPCHK(call)                                                          \
+  do {                                                                        \
+    hipError_t _r = (call);                                                   \
+    if (_r != hipSuccess)                                                     \
+      return fail(e, GTSG_EHIP, "%s failed: %s (%s:%d)", #call,               \
+                  hipGetErrorString(_r), __FILE__, __LINE__);                 \
+  } while (0)
+
+static hipEvent_t get_event(GtsgEngine *e)
+{
+  if (!e->free_events.empty()) {
+    hipEvent_t ev = e->free_events.back();
+    e->free_events.pop_back();
+    return ev;
+  }
+  hipEvent_t ev;
+  hipEventCreate(&ev);
+  return ev;
+}
+
+/* launch with optional hipEvent bracketing on the engine's stream */
+#define LAUNCH(name, kern, grid, block, ...)                                  \
+  do {                                                                        \
+    hipEvent_t _a = nullptr, _b = nullptr;                                    \
+    if (e->profile) { _a = get_event(e); _b = get_event(e);                   \
+                      hipEventRecord(_a, e->st); }                            \
+    kern<<<(grid), (block), 0, e->st>>>(__VA_ARGS__);                         \
+    if (e->profile) { hipEventRecord(_b, e->st);                              \
+                      e->pending.push_back({name, _a, _b}); }                 \
+  } while (0)
+
+/* bracket a host-side composite (scan / sort) as one entry */
+struct ProfScope {
+  GtsgEngine *e; const char *name; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(GtsgEngine *en, const char *nm) : e(en), name(nm)
+  { if (e->profile) { a = get_event(e); b = get_event(e); hipEventRecord(a, e->st); } }
+  ~ProfScope()
+  { if (e->profile) { hipEventRecord(b, e->st); e->pending.push_back({name, a, b}); } }
+};
+
+static void collect_times(GtsgEngine *e)
+{
+  for (auto &p : e->pending) {
+    float ms = 0;
+    hipEventSynchronize(p.b);
+    hipEventElapsedTime(&ms, p.a, p.b);
+    auto &k = e->ktimes[p.name];
+    k.first++; k.second += ms;
+    e->free_events.push_back(p.a);
+    e->free_events.push_back(p.b);
+  }
+  e->pending.clear();
+}
+
+static int sync_stream(GtsgEngine *e)
+{
+  HIPCHK(hipStreamSynchronize(e->st));
+  HIPCHK(hipGetLastError());
+  collect_times(e);
+  return 0;
+}
+
+/* ---- workspace: one region, bump-allocated per call, grown between calls */
+static int pool_reserve(GtsgEngine *e, size_t bytes)
+{
+  e->pool_used = 0;
+  if (bytes <= e->pool_cap) return 0;
+  HIPCHK(hipStreamSynchronize(e->st));
+  if (e->pool) HIPCHK(hipFree(e->pool));
+  e->pool = nullptr; e->pool_cap = 0;
+  bytes += bytes / 8 + (1u << 20);
+  hipError_t r = hipMalloc((void **)&e->pool, bytes);
+  if (r != hipSuccess)
+    return fail(e, GTSG_ENOMEM, "workspace of %zu bytes: %s", bytes,
+                hipGetErrorString(r));
+  e->pool_cap = bytes;
+  return 0;
+}
+template <typename T>
+static T *pool_alloc(GtsgEngine *e, size_t count)
+{
+  size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+  if (e->pool_used + bytes > e->pool_cap) {
+    fail(e, GTSG_ENOMEM, "workspace exhausted (%zu + %zu > %zu)", e->pool_used,
+         bytes, e->pool_cap);
+    return nullptr;
+  }
+  T *p = (T *)(e->pool + e->pool_used);
+  e->pool_used += bytes;
+  return p;
+}
+#define PALLOC(var, T, count)                                                 \
+  T *var = pool_alloc<T>(e, (count));                                         \
+  if (!var) return GTSG_ENOMEM
+
+template <typename T>
+static int dev_alloc(GtsgEngine *e, T **p, size_t count)
+{
+  if (*p) { hipFree(*p); *p = nullptr; }
+  hipError_t r = hipMalloc((void **)p, (count ? count : 1) * sizeof(T));
+  if (r != hipSuccess)
+    return fail(e, GTSG_ENOMEM, "hipMalloc(%zu): %s", count * sizeof(T),
+                hipGetErrorString(r));
+  return 0;
+}
+
+static int read_u32(GtsgEngine *e, const uint32_t *d, uint32_t *h)
+{
+  HIPCHK(hipMemcpyAsync(h, d, 4, hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+static int read_u64(GtsgEngine *e, const uint64_t *d, uint64_t *h)
+{
+  HIPCHK(hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+
+static inline uint32_t nblk(uint64_t n, uint32_t per = GTS_BLOCK)
+{
+  uint64_t b = (n + per - 1) / per;
+  return (uint32_t)(b ? b : 1);
+}
+static int bits_for(uint64_t n)
+{
+  int b = 1;
+  while (b < 32 && (1ull << b) < n) ++b;
+  return b;
+}
+
+/* ------------------------------------------------------------------ */
+/* small kernels                                                       */
+
+template <typename T>
+__global__ void k_fill(T *p, T v, uint64_t n)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_iota(uint32_t *p, uint64_t n)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+
+/* ---- build ---- */
+__global__ void k_pair_keys(const uint32_t *root, const uint32_t *ctg,
+                            uint64_t *keys, uint32_t *vals, uint64_t nrec)
+{
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nrec) return;
+  uint32_t a = root[k], b = ctg[k];
+  uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  keys[k] = ((uint64_t)hi << 32) | lo;
+  vals[k] = (uint32_t)k;
+}
+
+/* One thread per sorted position; the head of a key segment folds the
+   segment (records of one contig pair in file order): the first record
+   creates both edges, a later record listed from the same root replaces the
+   estimate of "its" direction when its std_dev is strictly larger
+   (ref parser.c:359-366, graph.c:219-235). */
+__global__ void k_pair_segments(const uint64_t *keys, const uint32_t *recs,
+                                const uint32_t *root, const float *sd,
+                                uint32_t *is_creator, uint32_t *fwd_win,
+                                uint32_t *bwd_win, uint64_t nrec)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrec) return;
+  const uint64_t key = keys[i];
+  if (i > 0 && keys[i - 1] == key) return;
+  const uint32_t k0 = recs[i];
+  const uint32_t r0 = root[k0];
+  const bool selfloop = (uint32_t)(key >> 32) == (uint32_t)key;
+  uint32_t fw = k0, bw = k0;
+  float fsd = sd[k0], bsd = fsd;
+  for (uint64_t j = i + 1; j < nrec && keys[j] == key; ++j) {
+    const uint32_t k = recs[j];
+    const float s = sd[k];
+    if (selfloop || root[k] == r0) { if (fsd < s) { fsd = s; fw = k; } }
+    else { if (bsd < s) { bsd = s; bw = k; } }
+  }
+  is_creator[k0] = 1;
+  fwd_win[k0] = fw;
+  bwd_win[k0] = bw;
+}
+
+struct __attribute__((aligned(32))) GtsEdgeRec {
+  int64_t dist;
+  int64_t npairs;
+  uint32_t end;
+  float sd;
+  uint32_t flags;
+  uint32_t pad;
+};
+
+__global__ void k_emit_edges(const uint32_t *is_creator, const uint32_t *jidx,
+                             const uint32_t *fwd_win, const uint32_t *bwd_win,
+                             const uint32_t *root, const uint32_t *ctg,
+                             const int64_t *dist, const float *sd,
+                             const int64_t *npairs, const uint8_t *flags,
+                             uint32_t *estart, GtsEdgeRec *rec, uint64_t nrec)
+{
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nrec || !is_creator[k]) return;
+  const uint64_t e0 = 2ull * jidx[k];
+  const uint32_t r = root[k], c = ctg[k];
+  const uint32_t fw = fwd_win[k], bw = bwd_win[k];
+  GtsEdgeRec a, b;
+  a.dist = dist[fw]; a.npairs = npairs ? npairs[fw] : 0; a.end = c;
+  a.sd = sd[fw]; a.flags = flags[fw] & 3u; a.pad = 0;
+  b.dist = dist[bw]; b.npairs = npairs ? npairs[bw] : 0; b.end = r;
+  b.sd = sd[bw]; b.pad = 0;
+  if (bw == k) {  /* twin of the creating record, ref parser.c:369-377 */
+    const uint32_t f = flags[k];
+    const bool sense = f & GTS_F_SENSE, same = f & GTS_F_SAME;
+    const bool twin_dir = same ? !sense : sense;
+    b.flags = (twin_dir ? GTS_F_SENSE : 0u) | (same ? GTS_F_SAME : 0u);
+  } else
+    b.flags = flags[bw] & 3u;
+  estart[e0] = r; estart[e0 + 1] = c;
+  rec[e0] = a; rec[e0 + 1] = b;
+}
+
+__global__ void k_row_offsets(const uint32_t *sorted_start, uint32_t *row,
+                              uint32_t n, uint32_t m)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > m) return;
+  const uint32_t lo = i == 0 ? 0u : sorted_start[i - 1] + 1u;
+  const uint32_t hi = i == m ? n : sorted_start[i];
+  for (uint32_t v = lo; v <= hi; ++v) row[v] = (uint32_t)i;
+}
+
+__global__ void k_gather_csr(const uint32_t *perm, const GtsEdgeRec *rec,
+                             uint32_t *eend, int64_t *dist, int64_t *npairs,
+                             float *sd, uint8_t *flags, uint8_t *state,
+                             uint32_t *pos_of_eid, uint32_t m)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t id = perm[p];
+  const GtsEdgeRec r = rec[id];
+  eend[p] = r.end; dist[p] = r.dist; npairs[p] = r.npairs; sd[p] = r.sd;
+  flags[p] = (uint8_t)r.flags; state[p] = GIS_UNVISITED;
+  pos_of_eid[id] = (uint32_t)p;
+}
+__global__ void k_twins(const uint32_t *eid, const uint32_t *pos_of_eid,
+                        uint32_t *twin, uint32_t m)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < m) twin[p] = pos_of_eid[eid[p] ^ 1u];
+}
+__global__ void k_hub_flags(const uint32_t *row, uint32_t *flag, uint32_t n,
+                            uint32_t hub_degree)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) flag[v] = (row[v + 1] - row[v]) > hub_degree ? 1u : 0u;
+}
+__global__ void k_compact_ids(const uint32_t *flag, const uint32_t *idx,
+                              uint32_t *out, uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n && flag[v]) out[idx[v]] = (uint32_t)v;
+}
+
+/* ---- mark_repeats ---- */
+__global__ void k_repeat_vertices(const float *astat, const float *cn,
+                                  uint8_t *vstate, uint32_t n, int have_file,
+                                  float cncut, float acut)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n && gts_is_repeat(astat[v], cn[v], have_file, cncut, acut))
+    vstate[v] = GIS_REPEAT;
+}
+/* an edge turns REPEAT iff one of its ends is marked by THIS call
+   (mark_vertex marks the vertex' edges and their twins, algorithms.c:61-87) */
+__global__ void k_repeat_edges(const uint32_t *estart, const uint32_t *eend,
+                               const float *astat, const float *cn,
+                               uint8_t *state, uint32_t m, int have_file,
+                               float cncut, float acut)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t a = estart[p], b = eend[p];
+  if (gts_is_repeat(astat[a], cn[a], have_file, cncut, acut) ||
+      gts_is_repeat(astat[b], cn[b], have_file, cncut, acut))
+    state[p] = GIS_REPEAT;
+}
+
+/* ---- filter ---- */
+__global__ void k_filter_pairs(GtsGraphView G, GtsFilterParams P, uint8_t *prop,
+                               uint8_t *vinfo, uint32_t hub_degree)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= G.n) return;
+  if (gts_vertex_is_marked(G.vstate[v])) { vinfo[v] = GTS_VI_INACTIVE; return; }
+  if (G.row[v + 1] - G.row[v] > hub_degree) { vinfo[v] = 0; return; }
+  vinfo[v] = (uint8_t)gts_filter_pairs(G, P, (uint32_t)v, 0, 1, prop);
+}
+/* hub vertices: one wavefront per vertex, the outer pair index strided over
+   the lanes */
+__global__ void __launch_bounds__(GTS_BLOCK)
+k_filter_pairs_hub(GtsGraphView G, GtsFilterParams P, uint8_t *prop,
+                   uint8_t *vinfo, const uint32_t *hubs, uint32_t nhub)
+{
+  const uint32_t w = (blockIdx.x * GTS_BLOCK + threadIdx.x) >> 6;
+  if (w >= nhub) return;
+  const uint32_t v = hubs[w];
+  if (gts_vertex_is_marked(G.vstate[v])) return;
+  uint32_t bits = gts_filter_pairs(G, P, v, gts_lane(), GTS_WAVE, prop);
+  const bool s = __ballot(bits & GTS_VI_OVALL_S) != 0;
+  const bool a = __ballot(bits & GTS_VI_OVALL_A) != 0;
+  if (gts_lane() == 0)
+    vinfo[v] = (uint8_t)((s ? GTS_VI_OVALL_S : 0u) | (a ? GTS_VI_OVALL_A : 0u));
+}
+__global__ void k_filter_active_round(GtsGraphView G, const uint8_t *prop,
+                                      uint8_t *vinfo, uint32_t *pending)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= G.n) return;
+  const uint8_t cur = vinfo[v];
+  if (cur & (GTS_VI_ACTIVE0 | GTS_VI_INACTIVE)) return;
+  const uint32_t r = gts_filter_active_round(G, (uint32_t)v, prop, vinfo);
+  if (r) vinfo[v] = (uint8_t)(cur | r);
+  else *pending = 1;
+}
+__global__ void k_filter_tpoly(GtsGraphView G, const uint8_t *prop,
+                               const uint8_t *vinfo, uint32_t *tpoly)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= G.n) return;
+  tpoly[v] = gts_vertex_is_marked(G.vstate[v])
+                 ? GTS_NONE
+                 : gts_filter_tpoly(G, (uint32_t)v, prop, vinfo);
+}
+__global__ void k_filter_ovf_init(GtsGraphView G, GtsFilterParams P,
+                                  const uint8_t *vinfo, const uint32_t *tpoly,
+                                  uint8_t *ovf, int zero_ovf,
+                                  uint32_t hub_degree)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= G.n) return;
+  const uint8_t vi = vinfo[v];
+  if (!(vi & GTS_VI_ACTIVE0) || tpoly[v] == (uint32_t)v) { ovf[v] = GTS_OV_KNOWN; return; }
+  uint32_t o = GTS_OV_ACTIVE1;
+  if (zero_ovf) o |= GTS_OV0_A | GTS_OV0_S;
+  else if (vi & (GTS_VI_OVALL_A | GTS_VI_OVALL_S)) {
+    if (G.row[v + 1] - G.row[v] > hub_degree) { ovf[v] = (uint8_t)o; return; } /* hub pass */
+    o |= gts_filter_ovf0(G, P, (uint32_t)v, 0, 1, tpoly);
+  }
+  if (!zero_ovf && !(o & (GTS_OV0_A | GTS_OV0_S))) o |= GTS_OV_KNOWN;
+  ovf[v] = (uint8_t)o;
+}
+__global__ void __launch_bounds__(GTS_BLOCK)
+k_filter_ovf_init_hub(GtsGraphView G, GtsFilterParams P, const uint8_t *vinfo,
+                      const uint32_t *tpoly, uint8_t *ovf, const uint32_t *hubs,
+                      uint32_t nhub)
+{
+  const uint32_t w = (blockIdx.x * GTS_BLOCK + threadIdx.x) >> 6;
+  if (w >= nhub) return;
+  const uint32_t v = hubs[w];
+  const uint8_t vi = vinfo[v];
+  if (!(vi & GTS_VI_ACTIVE0) || tpoly[v] == v) return;
+  if (!(vi & (GTS_VI_OVALL_A | GTS_VI_OVALL_S))) return;
+  uint32_t bits = gts_filter_ovf0(G, P, v, gts_lane(), GTS_WAVE, tpoly);
+  uint32_t o = GTS_OV_ACTIVE1;
+  if (__ballot(bits & GTS_OV0_S)) o |= GTS_OV0_S;
+  if (__ballot(bits & GTS_OV0_A)) o |= GTS_OV0_A;
+  if (!(o & (GTS_OV0_A | GTS_OV0_S))) o |= GTS_OV_KNOWN;
+  if (gts_lane() == 0) ovf[v] = (uint8_t)o;
+}
+__global__ void k_filter_hit_round(GtsGraphView G, uint8_t *ovf, int zero_ovf,
+                                   uint32_t *pending)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= G.n) return;
+  if (ovf[v] & GTS_OV_KNOWN) return;
+  const uint32_t r = gts_filter_hit_round(G, (uint32_t)v, ovf, zero_ovf != 0);
+  if (r) ovf[v] = (uint8_t)r;
+  else *pending = 1;
+}
+__global__ void k_filter_lasthit(GtsGraphView G, const uint8_t *ovf,
+                                 uint32_t *lasthit)
+{
+  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= G.n) return;
+  uint32_t out[2];
+  gts_filter_lasthit(G, (uint32_t)a, ovf, out);
+  lasthit[2 * a] = out[0];
+  lasthit[2 * a + 1] = out[1];
+}
+__global__ void k_filter_final(GtsGraphView G, const uint32_t *estart,
+                               const uint32_t *tpoly, const uint8_t *ovf,
+                               const uint32_t *lasthit, uint8_t *newstate)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= G.m) return;
+  newstate[p] = gts_filter_final_edge(G, estart[p], (uint32_t)p, tpoly, ovf, lasthit);
+}
+__global__ void k_filter_final_vertices(uint8_t *vstate, const uint32_t *tpoly,
+                                        uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n && tpoly[v] != GTS_NONE) vstate[v] = GIS_POLYMORPHIC;
+}
+
+/* ---- components ---- */
+__device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
+{
+  uint32_t p = parent[x];
+  while (p != x) {
+    const uint32_t gp = parent[p];
+    if (gp != p) parent[x] = gp;   /* path halving, benign race */
+    x = p; p = gp;
+  }
+  return x;
+}
+/* live edge: unmarked edge between unmarked vertices.  Hooks the larger root
+   under the smaller one, so a component's label is its smallest vertex. */
+__global__ void k_live_union(GtsGraphView G, const uint32_t *estart,
+                             uint8_t *live, uint8_t *touched, uint32_t *parent)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= G.m) return;
+  const uint32_t a = estart[p], b = G.end[p];
+  const bool lv = !gts_edge_is_marked(G.state[p]) &&
+                  !gts_vertex_is_marked(G.vstate[a]) &&
+                  !gts_vertex_is_marked(G.vstate[b]);
+  live[p] = lv ? 1 : 0;
+  if (!lv) return;
+  touched[a] = 1; touched[b] = 1;
+  uint32_t x = a, y = b;
+  for (;;) {
+    x = uf_find(parent, x); y = uf_find(parent, y);
+    if (x == y) break;
+    if (x < y) { const uint32_t t = x; x = y; y = t; }   /* x > y */
+    const uint32_t old = atomicCAS(&parent[x], x, y);
+    if (old == x) break;
+  }
+}
+__global__ void k_component_vertices(const uint8_t *touched, uint8_t *vstate,
+                                     uint32_t *parent, uint32_t *flag,
+                                     uint32_t n, int mode)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const bool marked = gts_vertex_is_marked(vstate[v]);
+  const bool in = !marked && touched[v];
+  flag[v] = in ? 1u : 0u;
+  if (!marked && !touched[v])   /* lonesome vertex: algorithms.c:790-806 */
+    vstate[v] = mode == GTS_MODE_MAKESCAFFOLD ? GIS_SCAFFOLD : GIS_UNVISITED;
+}
+__global__ void k_slot_keys(const uint32_t *flag, const uint32_t *idx,
+                            uint32_t *parent, uint32_t *keys, uint32_t *vals,
+                            uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n || !flag[v]) return;
+  keys[idx[v]] = uf_find(parent, (uint32_t)v);
+  vals[idx[v]] = (uint32_t)v;
+}
+__global__ void k_slot_heads(const uint32_t *labels, uint32_t *head,
+                             uint32_t nslots)
+{
+  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nslots) head[s] = (s == 0 || labels[s] != labels[s - 1]) ? 1u : 0u;
+}
+__global__ void k_slot_finish(const uint32_t *labels, const uint32_t *cidx,
+                              const uint32_t *slot_v, const int64_t *seq_len,
+                              const uint8_t *vstate, uint32_t *comp_off,
+                              uint32_t *slot_of, int64_t *cseq, uint8_t *vst,
+                              uint32_t nslots)
+{
+  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  if (s == 0 || labels[s] != labels[s - 1]) comp_off[cidx[s]] = (uint32_t)s;
+  const uint32_t v = slot_v[s];
+  slot_of[v] = (uint32_t)s;
+  cseq[s] = seq_len[v];
+  vst[s] = vstate[v];
+}
+/* an edge enters the compact graph if it or its twin is live: marking a walk
+   edge's twin SCAFFOLD (algorithms.c:842-845) revives a marked twin */
+__global__ void k_compact_count(GtsGraphView G, const uint8_t *live,
+                                const uint32_t *slot_v, uint32_t *cnt,
+                                uint32_t nslots)
+{
+  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  const uint32_t v = slot_v[s];
+  uint32_t k = 0;
+  for (uint32_t p = G.row[v]; p < G.row[v + 1]; ++p)
+    if (live[p] || live[G.twin[p]]) ++k;
+  cnt[s] = k;
+}
+__global__ void k_compact_fill(GtsGraphView G, const uint8_t *live,
+                               const uint32_t *slot_v, const uint32_t *slot_of,
+                               const uint32_t *coff, uint32_t *cstart,
+                               uint32_t *cend, int64_t *cdist, uint8_t *cflags,
+                               uint32_t *cgpos, uint8_t *cstate, uint32_t *cmap,
+                               uint32_t nslots)
+{
+  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  const uint32_t v = slot_v[s];
+  uint32_t k = coff[s];
+  for (uint32_t p = G.row[v]; p < G.row[v + 1]; ++p)
+    if (live[p] || live[G.twin[p]]) {
+      cstart[k] = (uint32_t)s; cend[k] = slot_of[G.end[p]];
+      cdist[k] = G.dist[p]; cflags[k] = G.flags[p]; cgpos[k] = p;
+      cstate[k] = G.state[p]; cmap[p] = k;
+      ++k;
+    }
+}
+__global__ void k_walkq_sizes(const uint32_t *comp_off, const uint32_t *coff,
+                              uint64_t *sz, uint32_t ncomp, uint64_t factor)
+{
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < ncomp)
+    sz[c] = factor * (uint64_t)(coff[comp_off[c + 1]] - coff[comp_off[c]]) + 64;
+}
+
+/* gfx950 wave policy of gts_component.hpp */
+struct GtsWave64 {
+  static const uint32_t WIDTH = 64;
+  static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
+  static __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+  static __device__ __forceinline__ uint32_t popc(uint64_t m) { return (uint32_t)__popcll(m); }
+  static __device__ __forceinline__ uint32_t popc_below(uint64_t m, uint32_t l)
+  { return (uint32_t)__popcll(m & ((1ull << l) - 1ull)); }
+  static __device__ __forceinline__ uint32_t ctz(uint64_t m) { return (uint32_t)__ffsll((long long)m) - 1u; }
+  static __device__ __forceinline__ uint32_t msb(uint64_t m) { return 63u - (uint32_t)__clzll((long long)m); }
+  static __device__ __forceinline__ uint32_t shfl(uint32_t v, uint32_t l) { return (uint32_t)__shfl((int)v, (int)l); }
+  static __device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t l)
+  {
+    const uint32_t lo = shfl((uint32_t)v, l), hi = shfl((uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  static __device__ __forceinline__ uint32_t uni(uint32_t v)
+  { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+  static __device__ __forceinline__ int64_t uni64(int64_t v)
+  {
+    const uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+  }
+  static __device__ __forceinline__ void fence()
+  { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+};
+
+/* one wavefront per component; `order` lists components largest first */
+__global__ void __launch_bounds__(GTS_WAVE)
+k_components(GtsCompView C, const uint32_t *order, int mode)
+{
+  const uint32_t i = blockIdx.x;
+  if (i >= C.ncomp) return;
+  const uint32_t c = order ? order[i] : i;
+  GtsComponent<GtsWave64> prog(C, c);
+  prog.run(mode);
+}
+__global__ void k_comp_size_keys(const uint32_t *comp_off, uint32_t *keys,
+                                 uint32_t *vals, uint32_t ncomp)
+{
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncomp) return;
+  keys[c] = ~(comp_off[c + 1] - comp_off[c]);   /* ascending sort = largest first */
+  vals[c] = (uint32_t)c;
+}
+__global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
+                               uint32_t *out /* [0]=overflow, [1]=loop */)
+{
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncomp) return;
+  if (cerr[c] == GTS_CERR_WALKQ_OVERFLOW) atomicAdd(&out[0], 1u);
+  else if (cerr[c] != 0) atomicAdd(&out[1], 1u);
+}
+__global__ void k_max_u32_diff(const uint32_t *off, uint32_t n, uint32_t *out)
+{
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) atomicMax(out, off[c + 1] - off[c]);
+}
+
+/* ---- results ---- */
+__global__ void k_states_by_id(const uint8_t *state, const uint32_t *eid,
+                               uint8_t *out, uint32_t m)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < m) out[eid[p]] = state[p];
+}
+__global__ void k_edges_by_id(const uint32_t *eid, const uint32_t *estart,
+                              const uint32_t *eend, const int64_t *dist,
+                              const float *sd, const int64_t *np,
+                              const uint8_t *flags, uint32_t *ostart,
+                              uint32_t *oend, int64_t *odist, float *osd,
+                              int64_t *onp, uint8_t *oflags, uint32_t m)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m) return;
+  const uint32_t id = eid[p];
+  ostart[id] = estart[p]; oend[id] = eend[p]; odist[id] = dist[p];
+  osd[id] = sd[p]; onp[id] = np[p]; oflags[id] = flags[p];
+}
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+/* sum over items of mix(id, state): independent of storage order */
+__global__ void k_digest(const uint8_t *state, const uint32_t *ids, uint64_t n,
+                         unsigned long long *out)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t h = 0;
+  if (i < n) h = mix64(((uint64_t)(ids ? ids[i] : (uint32_t)i) << 8) | state[i]);
+  for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)h);
+}
+
+/* diagnostic: the device's ambiguous-order test on caller-supplied pairs */
+__global__ void k_amb_test(const int64_t *d1, const float *s1, const int64_t *d2,
+                           const float *s2, uint8_t *out, uint64_t n,
+                           GtsAmbThresholds t)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = gts_ambiguous(d1[i], s1[i], d2[i], s2[i], t) ? 1 : 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* host side of the C ABI                                              */
+
+static GtsGraphView view_of(GtsgEngine *e)
+{
+  GtsGraphView G;
+  G.n = e->n; G.m = e->m; G.row = e->row; G.seq_len = e->seq_len;
+  G.astat = e->astat; G.copy_num = e->copy_num; G.vstate = e->vstate;
+  G.end = e->eend; G.dist = e->dist; G.sd = e->sd; G.flags = e->flags;
+  G.state = e->state; G.twin = e->twin; G.eid = e->eid;
+  return G;
+}
+
+template <typename T>
+static int upload(GtsgEngine *e, T *dst, const T *src, size_t count, int on_device)
+{
+  if (!count) return 0;
+  HIPCHK(hipMemcpyAsync(dst, src, count * sizeof(T),
+                        on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                        e->st));
+  return 0;
+}
+
+extern "C" {
+
+int gtsg_create(GtsgEngine **out, int device, void *stream)
+{
+  if (!out) return GTSG_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    fprintf(stderr, "gtsg_create: no HIP device %d (found %d); the engine has "
+                    "no CPU path\n", device, ndev);
+    return GTSG_EHIP;
+  }
+  GtsgEngine *e = new GtsgEngine();
+  e->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete e; return GTSG_EHIP; }
+  if (stream) e->st = (hipStream_t)stream;
+  else {
+    if (hipStreamCreate(&e->st) != hipSuccess) { delete e; return GTSG_EHIP; }
+    e->own_stream = true;
+  }
+  if (hipMalloc((void **)&e->d_scalars, 256) != hipSuccess) { delete e; return GTSG_ENOMEM; }
+  *out = e;
+  return 0;
+}
+
+static void free_graph(GtsgEngine *e)
+{
+  void *ptrs[] = {e->row, e->estart, e->eend, e->twin, e->eid, e->pos_of_eid,
+                  e->dist, e->npairs, e->sd, e->flags, e->state, e->hubs};
+  for (void *p : ptrs) if (p) hipFree(p);
+  e->row = e->estart = e->eend = e->twin = e->eid = e->pos_of_eid = e->hubs = nullptr;
+  e->dist = e->npairs = nullptr; e->sd = nullptr; e->flags = e->state = nullptr;
+  e->m = 0; e->nhub = 0;
+}
+
+void gtsg_destroy(GtsgEngine *e)
+{
+  if (!e) return;
+  hipSetDevice(e->device);
+  hipStreamSynchronize(e->st);
+  collect_times(e);
+  free_graph(e);
+  void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->pool, e->d_scalars};
+  for (void *p : ptrs) if (p) hipFree(p);
+  for (auto ev : e->free_events) hipEventDestroy(ev);
+  if (e->own_stream) hipStreamDestroy(e->st);
+  delete e;
+}
+
+const char *gtsg_last_error(const GtsgEngine *e) { return e ? e->err.c_str() : "no engine"; }
+
+int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
+{
+  if (!e || !name) return GTSG_EINVAL;
+  if (!strcmp(name, "walk_queue_factor") && value >= 1) e->walk_queue_factor = value;
+  else if (!strcmp(name, "max_walk_pops") && value >= 1) e->max_walk_pops = value;
+  else if (!strcmp(name, "hub_degree") && value >= 1) e->hub_degree = value;
+  else if (!strcmp(name, "profile")) e->profile = value != 0;
+  else return fail(e, GTSG_EINVAL, "unknown option %s", name);
+  return 0;
+}
+
+int gtsg_set_contigs(GtsgEngine *e, uint64_t n, const int64_t *seq_len,
+                     const float *astat, const float *copy_num, int on_device)
+{
+  if (!e || (n && !seq_len)) return GTSG_EINVAL;
+  if (n >= (1ull << 31)) return fail(e, GTSG_ELIMIT, "more than 2^31-1 contigs");
+  HIPCHK(hipSetDevice(e->device));
+  free_graph(e);
+  e->n = (uint32_t)n;
+  int rc;
+  if ((rc = dev_alloc(e, &e->seq_len, n))) return rc;
+  if ((rc = dev_alloc(e, &e->astat, n))) return rc;
+  if ((rc = dev_alloc(e, &e->copy_num, n))) return rc;
+  if ((rc = dev_alloc(e, &e->vstate, n))) return rc;
+  if ((rc = upload(e, e->seq_len, seq_len, n, on_device))) return rc;
+  if (astat) { if ((rc = upload(e, e->astat, astat, n, on_device))) return rc; }
+  else HIPCHK(hipMemsetAsync(e->astat, 0, n * 4, e->st));
+  if (copy_num) { if ((rc = upload(e, e->copy_num, copy_num, n, on_device))) return rc; }
+  else HIPCHK(hipMemsetAsync(e->copy_num, 0, n * 4, e->st));
+  HIPCHK(hipMemsetAsync(e->vstate, GIS_UNVISITED, n ? n : 1, e->st));
+  return sync_stream(e);
+}
+
+int gtsg_set_astat(GtsgEngine *e, const float *astat, const float *copy_num,
+                   int on_device)
+{
+  if (!e || !astat || !copy_num) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = upload(e, e->astat, astat, e->n, on_device))) return rc;
+  if ((rc = upload(e, e->copy_num, copy_num, e->n, on_device))) return rc;
+  return sync_stream(e);
+}
+
+int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
+                            const uint32_t *ctg, const int64_t *dist,
+                            const float *std_dev, const int64_t *num_pairs,
+                            const uint8_t *flags, int on_device)
+{
+  if (!e || (nrec && (!root || !ctg || !dist || !std_dev || !flags))) return GTSG_EINVAL;
+  if (nrec >= (1ull << 31) - 1) return fail(e, GTSG_ELIMIT, "too many records");
+  HIPCHK(hipSetDevice(e->device));
+  free_graph(e);
+  const uint32_t n = e->n;
+  int rc;
+  /* workspace estimate (bytes per record / edge, generous) */
+  const size_t ws = nrec * (on_device ? 64 : 96) + (size_t)n * 16 +
+                    (gts_sort_tmp_elems(2 * nrec + 16) + gts_scan_tmp_elems(2 * nrec + n + 16)) * 8 +
+                    2 * nrec * (sizeof(GtsEdgeRec) + 24) + (64u << 20);
+  if ((rc = pool_reserve(e, ws))) return rc;
+  /* records on the device */
+  const uint32_t *d_root = root, *d_ctg = ctg;
+  const int64_t *d_dist = dist, *d_np = num_pairs;
+  const float *d_sd = std_dev;
+  const uint8_t *d_flags = flags;
+  if (!on_device && nrec) {
+    PALLOC(t_root, uint32_t, nrec); PALLOC(t_ctg, uint32_t, nrec);
+    PALLOC(t_dist, int64_t, nrec); PALLOC(t_sd, float, nrec);
+    PALLOC(t_flags, uint8_t, nrec);
+    upload(e, t_root, root, nrec, 0); upload(e, t_ctg, ctg, nrec, 0);
+    upload(e, t_dist, dist, nrec, 0); upload(e, t_sd, std_dev, nrec, 0);
+    upload(e, t_flags, flags, nrec, 0);
+    d_root = t_root; d_ctg = t_ctg; d_dist = t_dist; d_sd = t_sd; d_flags = t_flags;
+    if (num_pairs) {
+      PALLOC(t_np, int64_t, nrec);
+      upload(e, t_np, num_pairs, nrec, 0);
+      d_np = t_np;
+    }
+  }
+  uint32_t npairs_created = 0;
+  uint32_t *is_creator = nullptr, *jidx = nullptr, *fwd = nullptr, *bwd = nullptr;
+  if (nrec) {
+    PALLOC(k0, uint64_t, nrec); PALLOC(k1, uint64_t, nrec);
+    PALLOC(v0, uint32_t, nrec); PALLOC(v1, uint32_t, nrec);
+    PALLOC(stmp, uint32_t, gts_sort_tmp_elems(nrec));
+    LAUNCH("build_pair_keys", k_pair_keys, nblk(nrec), GTS_BLOCK, d_root, d_ctg, k0, v0, nrec);
+    const int vb = bits_for(n);
+    int shifts[8], np = 0;
+    for (int s = 0; s < vb; s += 8) shifts[np++] = s;
+    for (int s = 0; s < vb; s += 8) shifts[np++] = 32 + s;
+    int where;
+    { ProfScope ps(e, "build_sort_pairs");
+      where = gts_radix_sort<uint64_t>(k0, v0, k1, v1, nrec, shifts, np, stmp, e->st); }
+    uint64_t *ks = where ? k1 : k0;
+    uint32_t *vs = where ? v1 : v0;
+    /* reuse the other value buffer and fresh arrays for the segment fold */
+    is_creator = where ? v0 : v1;
+    PALLOC(t_fwd, uint32_t, nrec); PALLOC(t_bwd, uint32_t, nrec);
+    PALLOC(t_jidx, uint32_t, nrec);
+    PALLOC(sctmp, uint32_t, gts_scan_tmp_elems(nrec));
+    fwd = t_fwd; bwd = t_bwd; jidx = t_jidx;
+    HIPCHK(hipMemsetAsync(is_creator, 0, nrec * 4, e->st));
+    LAUNCH("build_pair_segments", k_pair_segments, nblk(nrec), GTS_BLOCK, ks, vs, d_root,
+           d_sd, is_creator, fwd, bwd, nrec);
+    { ProfScope ps(e, "build_scan_creators");
+      gts_exscan<uint32_t, uint32_t>(is_creator, jidx, nrec, sctmp, e->d_scalars, e->st); }
+    if ((rc = read_u32(e, e->d_scalars, &npairs_created))) return rc;
+  }
+  const uint64_t m64 = 2ull * npairs_created;
+  if (m64 >= 0xFFFFFFFEull) return fail(e, GTSG_ELIMIT, "more than 2^32-2 edges");
+  const uint32_t m = (uint32_t)m64;
+  e->m = m;
+  if ((rc = dev_alloc(e, &e->row, (size_t)n + 1))) return rc;
+  if ((rc = dev_alloc(e, &e->estart, m))) return rc;
+  if ((rc = dev_alloc(e, &e->eend, m))) return rc;
+  if ((rc = dev_alloc(e, &e->twin, m))) return rc;
+  if ((rc = dev_alloc(e, &e->eid, m))) return rc;
+  if ((rc = dev_alloc(e, &e->pos_of_eid, m))) return rc;
+  if ((rc = dev_alloc(e, &e->dist, m))) return rc;
+  if ((rc = dev_alloc(e, &e->npairs, m))) return rc;
+  if ((rc = dev_alloc(e, &e->sd, m))) return rc;
+  if ((rc = dev_alloc(e, &e->flags, m))) return rc;
+  if ((rc = dev_alloc(e, &e->state, m))) return rc;
+  HIPCHK(hipMemsetAsync(e->vstate, GIS_UNVISITED, n ? n : 1, e->st));
+  if (m) {
+    PALLOC(es0, uint32_t, m); PALLOC(es1, uint32_t, m);
+    PALLOC(id0, uint32_t, m); PALLOC(id1, uint32_t, m);
+    PALLOC(rec, GtsEdgeRec, m);
+    PALLOC(stmp2, uint32_t, gts_sort_tmp_elems(m));
+    LAUNCH("build_emit_edges", k_emit_edges, nblk(nrec), GTS_BLOCK, is_creator, jidx, fwd,
+           bwd, d_root, d_ctg, d_dist, d_sd, d_np, d_flags, es0, rec, nrec);
+    LAUNCH("iota", k_iota, nblk(m), GTS_BLOCK, id0, (uint64_t)m);
+    const int vb = bits_for(n);
+    int shifts[4], np = 0;
+    for (int s = 0; s < vb; s += 8) shifts[np++] = s;
+    int where;
+    { ProfScope ps(e, "build_sort_csr");
+      where = gts_radix_sort<uint32_t>(es0, id0, es1, id1, m, shifts, np, stmp2, e->st); }
+    const uint32_t *ss = where ? es1 : es0, *perm = where ? id1 : id0;
+    HIPCHK(hipMemcpyAsync(e->estart, ss, (size_t)m * 4, hipMemcpyDeviceToDevice, e->st));
+    HIPCHK(hipMemcpyAsync(e->eid, perm, (size_t)m * 4, hipMemcpyDeviceToDevice, e->st));
+    LAUNCH("build_row_offsets", k_row_offsets, nblk((uint64_t)m + 1), GTS_BLOCK, e->estart,
+           e->row, n, m);
+    LAUNCH("build_gather_csr", k_gather_csr, nblk(m), GTS_BLOCK, e->eid, rec, e->eend,
+           e->dist, e->npairs, e->sd, e->flags, e->state, e->pos_of_eid, m);
+    LAUNCH("build_twins", k_twins, nblk(m), GTS_BLOCK, e->eid, e->pos_of_eid, e->twin, m);
+  } else
+    HIPCHK(hipMemsetAsync(e->row, 0, ((size_t)n + 1) * 4, e->st));
+  /* hub list */
+  if (n) {
+    PALLOC(hflag, uint32_t, n); PALLOC(hidx, uint32_t, n);
+    PALLOC(htmp, uint32_t, gts_scan_tmp_elems(n));
+    LAUNCH("build_hub_flags", k_hub_flags, nblk(n), GTS_BLOCK, e->row, hflag, n,
+           (uint32_t)e->hub_degree);
+    gts_exscan<uint32_t, uint32_t>(hflag, hidx, n, htmp, e->d_scalars + 2, e->st);
+    uint32_t nh = 0;
+    if ((rc = read_u32(e, e->d_scalars + 2, &nh))) return rc;
+    e->nhub = nh;
+    if ((rc = dev_alloc(e, &e->hubs, nh))) return rc;
+    if (nh) LAUNCH("build_hub_list", k_compact_ids, nblk(n), GTS_BLOCK, hflag, hidx, e->hubs, n);
+  }
+  e->stats["hubs"] = e->nhub;
+  return sync_stream(e);
+}
+
+int gtsg_mark_repeats(GtsgEngine *e, int have_file, float copy_num_cutoff,
+                      float astat_cutoff)
+{
+  if (!e || !e->row) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  if (e->n)
+    LAUNCH("repeat_vertices", k_repeat_vertices, nblk(e->n), GTS_BLOCK, e->astat,
+           e->copy_num, e->vstate, e->n, have_file, copy_num_cutoff, astat_cutoff);
+  if (e->m)
+    LAUNCH("repeat_edges", k_repeat_edges, nblk(e->m), GTS_BLOCK, e->estart, e->eend,
+           e->astat, e->copy_num, e->state, e->m, have_file, copy_num_cutoff, astat_cutoff);
+  return sync_stream(e);
+}
+
+int gtsg_filter(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff)
+{
+  if (!e || !e->row) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  const uint32_t n = e->n, m = e->m;
+  if (!n) return 0;
+  int rc;
+  if ((rc = pool_reserve(e, (size_t)m * 2 + (size_t)n * 24 + (8u << 20)))) return rc;
+  GtsGraphView G = view_of(e);
+  GtsFilterParams P;
+  P.amb = gts_amb_thresholds(pcutoff);
+  P.cncutoff = cncutoff;
+  P.ocutoff = ocutoff;
+  const int zero_ovf = 0 > ocutoff;
+  PALLOC(prop, uint8_t, (size_t)m + 1); PALLOC(newstate, uint8_t, (size_t)m + 1);
+  PALLOC(vinfo, uint8_t, n); PALLOC(ovf, uint8_t, n);
+  PALLOC(tpoly, uint32_t, n); PALLOC(lasthit, uint32_t, 2 * (size_t)n);
+  uint32_t *pending = e->d_scalars + 4;
+  HIPCHK(hipMemsetAsync(prop, 0, (size_t)m + 1, e->st));
+  LAUNCH("filter_pairs", k_filter_pairs, nblk(n), GTS_BLOCK, G, P, prop, vinfo,
+         (uint32_t)e->hub_degree);
+  if (e->nhub)
+    LAUNCH("filter_pairs_hub", k_filter_pairs_hub, nblk((uint64_t)e->nhub * GTS_WAVE),
+           GTS_BLOCK, G, P, prop, vinfo, e->hubs, e->nhub);
+  int64_t rounds_p = 0, rounds_i = 0;
+  for (;;) {
+    uint32_t h = 0;
+    HIPCHK(hipMemsetAsync(pending, 0, 4, e->st));
+    LAUNCH("filter_active_round", k_filter_active_round, nblk(n), GTS_BLOCK, G, prop, vinfo,
+           pending);
+    ++rounds_p;
+    if ((rc = read_u32(e, pending, &h))) return rc;
+    if (!h) break;
+  }
+  LAUNCH("filter_tpoly", k_filter_tpoly, nblk(n), GTS_BLOCK, G, prop, vinfo, tpoly);
+  LAUNCH("filter_ovf_init", k_filter_ovf_init, nblk(n), GTS_BLOCK, G, P, vinfo, tpoly, ovf,
+         zero_ovf, (uint32_t)e->hub_degree);
+  if (e->nhub && !zero_ovf)
+    LAUNCH("filter_ovf_init_hub", k_filter_ovf_init_hub,
+           nblk((uint64_t)e->nhub * GTS_WAVE), GTS_BLOCK, G, P, vinfo, tpoly, ovf, e->hubs,
+           e->nhub);
+  for (;;) {
+    uint32_t h = 0;
+    HIPCHK(hipMemsetAsync(pending, 0, 4, e->st));
+    LAUNCH("filter_hit_round", k_filter_hit_round, nblk(n), GTS_BLOCK, G, ovf, zero_ovf,
+           pending);
+    ++rounds_i;
+    if ((rc = read_u32(e, pending, &h))) return rc;
+    if (!h) break;
+  }
+  LAUNCH("filter_lasthit", k_filter_lasthit, nblk(n), GTS_BLOCK, G, ovf, lasthit);
+  if (m) {
+    LAUNCH("filter_final", k_filter_final, nblk(m), GTS_BLOCK, G, e->estart, tpoly, ovf,
+           lasthit, newstate);
+    HIPCHK(hipMemcpyAsync(e->state, newstate, m, hipMemcpyDeviceToDevice, e->st));
+  }
+  LAUNCH("filter_final_vertices", k_filter_final_vertices, nblk(n), GTS_BLOCK, e->vstate,
+         tpoly, n);
+  e->stats["filter_rounds_p"] = rounds_p;
+  e->stats["filter_rounds_i"] = rounds_i;
+  return sync_stream(e);
+}
+
+static int run_components(GtsgEngine *e, int mode)
+{
+  if (!e || !e->row) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  const uint32_t n = e->n, m = e->m;
+  if (!n) return 0;
+  int rc;
+  int64_t factor = e->walk_queue_factor;
+  int64_t retries = 0;
+  /* snapshot for the (rare) walk-queue retry */
+  uint8_t *snap_v = nullptr, *snap_e = nullptr;
+  for (;;) {
+    /* phase A: sizes are data dependent, so the workspace is reserved in two
+       steps (the pool cannot grow while pointers into it are live) */
+    const size_t wsA = (size_t)m * (2 + 4) + (size_t)n * 40 +
+                       (gts_sort_tmp_elems(n) + 2 * gts_scan_tmp_elems((uint64_t)n + m)) * 8 +
+                       (size_t)n + m + (16u << 20);
+    /* upper bounds for phase B: slots <= n, compact edges <= m */
+    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8) + (size_t)m * (4 * 3 + 8 + 2) +
+                       ((size_t)m * factor + 64ull * n) * 12 + (size_t)n * 24 + (16u << 20);
+    if (!e->pool || e->pool_cap < wsA + wsB) {
+      if ((rc = pool_reserve(e, wsA + wsB))) return rc;
+    } else
+      e->pool_used = 0;
+    GtsGraphView G = view_of(e);
+    PALLOC(sv, uint8_t, (size_t)n + 1); PALLOC(se, uint8_t, (size_t)m + 1);
+    snap_v = sv; snap_e = se;
+    HIPCHK(hipMemcpyAsync(snap_v, e->vstate, n, hipMemcpyDeviceToDevice, e->st));
+    if (m) HIPCHK(hipMemcpyAsync(snap_e, e->state, m, hipMemcpyDeviceToDevice, e->st));
+    PALLOC(live, uint8_t, (size_t)m + 1); PALLOC(touched, uint8_t, n);
+    PALLOC(parent, uint32_t, n); PALLOC(flag, uint32_t, n); PALLOC(idx, uint32_t, n);
+    PALLOC(sctmp, uint32_t, gts_scan_tmp_elems((uint64_t)n + m + 16));
+    HIPCHK(hipMemsetAsync(touched, 0, n, e->st));
+    LAUNCH("iota", k_iota, nblk(n), GTS_BLOCK, parent, (uint64_t)n);
+    if (m)
+      LAUNCH("comp_live_union", k_live_union, nblk(m), GTS_BLOCK, G, e->estart, live,
+             touched, parent);
+    LAUNCH("comp_vertices", k_component_vertices, nblk(n), GTS_BLOCK, touched, e->vstate,
+           parent, flag, n, mode);
+    gts_exscan<uint32_t, uint32_t>(flag, idx, n, sctmp, e->d_scalars, e->st);
+    uint32_t nslots = 0;
+    if ((rc = read_u32(e, e->d_scalars, &nslots))) return rc;
+    e->stats["slots"] = nslots;
+    e->stats["components"] = 0; e->stats["max_component"] = 0;
+    e->stats["compact_edges"] = 0;
+    if (!nslots) break;
+    PALLOC(lk0, uint32_t, nslots); PALLOC(lk1, uint32_t, nslots);
+    PALLOC(sv0, uint32_t, nslots); PALLOC(sv1, uint32_t, nslots);
+    PALLOC(stmp, uint32_t, gts_sort_tmp_elems(nslots));
+    LAUNCH("comp_slot_keys", k_slot_keys, nblk(n), GTS_BLOCK, flag, idx, parent, lk0, sv0, n);
+    {
+      const int vb = bits_for(n);
+      int shifts[4], np = 0;
+      for (int s = 0; s < vb; s += 8) shifts[np++] = s;
+      ProfScope ps(e, "comp_sort_slots");
+      const int where = gts_radix_sort<uint32_t>(lk0, sv0, lk1, sv1, nslots, shifts, np,
+                                                 stmp, e->st);
+      if (where) { uint32_t *t = lk0; lk0 = lk1; lk1 = t; t = sv0; sv0 = sv1; sv1 = t; }
+    }
+    uint32_t *labels = lk0, *slot_v = sv0, *head = lk1, *cidx = sv1;
+    LAUNCH("comp_slot_heads", k_slot_heads, nblk(nslots), GTS_BLOCK, labels, head, nslots);
+    gts_exscan<uint32_t, uint32_t>(head, cidx, nslots, sctmp, e->d_scalars, e->st);
+    uint32_t ncomp = 0;
+    if ((rc = read_u32(e, e->d_scalars, &ncomp))) return rc;
+    PALLOC(comp_off, uint32_t, (size_t)ncomp + 1);
+    PALLOC(slot_of, uint32_t, n); PALLOC(cseq, int64_t, nslots); PALLOC(vst, uint8_t, nslots);
+    LAUNCH("comp_slot_finish", k_slot_finish, nblk(nslots), GTS_BLOCK, labels, cidx, slot_v,
+           e->seq_len, e->vstate, comp_off, slot_of, cseq, vst, nslots);
+    LAUNCH("fill", k_fill<uint32_t>, 1, 1, comp_off + ncomp, nslots, (uint64_t)1);
+    PALLOC(coff, uint32_t, (size_t)nslots + 1);
+    LAUNCH("comp_compact_count", k_compact_count, nblk(nslots), GTS_BLOCK, G, live, slot_v,
+           coff, nslots);
+    gts_exscan<uint32_t, uint32_t>(coff, coff, nslots, sctmp, e->d_scalars, e->st);
+    uint32_t nce = 0;
+    if ((rc = read_u32(e, e->d_scalars, &nce))) return rc;
+    LAUNCH("fill", k_fill<uint32_t>, 1, 1, coff + nslots, nce, (uint64_t)1);
+    PALLOC(cstart, uint32_t, (size_t)nce + 1); PALLOC(cend, uint32_t, (size_t)nce + 1);
+    PALLOC(cgpos, uint32_t, (size_t)nce + 1); PALLOC(cdist, int64_t, (size_t)nce + 1);
+    PALLOC(cflags, uint8_t, (size_t)nce + 1); PALLOC(cstate, uint8_t, (size_t)nce + 1);
+    PALLOC(cmap, uint32_t, (size_t)m + 1);
+    HIPCHK(hipMemsetAsync(cmap, 0xFF, ((size_t)m + 1) * 4, e->st));
+    LAUNCH("comp_compact_fill", k_compact_fill, nblk(nslots), GTS_BLOCK, G, live, slot_v,
+           slot_of, coff, cstart, cend, cdist, cflags, cgpos, cstate, cmap, nslots);
+    /* walk queues */
+    PALLOC(wq_off, uint64_t, (size_t)ncomp + 1);
+    PALLOC(wtmp, uint64_t, gts_scan_tmp_elems(ncomp));
+    LAUNCH("comp_walkq_sizes", k_walkq_sizes, nblk(ncomp), GTS_BLOCK, comp_off, coff, wq_off,
+           ncomp, (uint64_t)factor);
+    gts_exscan<uint64_t, uint64_t>(wq_off, wq_off, ncomp, wtmp, (uint64_t *)(e->d_scalars + 8),
+                                   e->st);
+    uint64_t wq_total = 0;
+    if ((rc = read_u64(e, (uint64_t *)(e->d_scalars + 8), &wq_total))) return rc;
+    LAUNCH("fill", k_fill<uint64_t>, 1, 1, wq_off + ncomp, wq_total, (uint64_t)1);
+    PALLOC(wq_edge, uint32_t, wq_total + 1); PALLOC(wq_dist, int64_t, wq_total + 1);
+    /* per-slot scratch */
+    PALLOC(s_queue, uint32_t, nslots); PALLOC(s_term, uint32_t, nslots);
+    PALLOC(s_visited, uint32_t, nslots); PALLOC(s_stv, uint32_t, nslots);
+    PALLOC(s_stpar, uint32_t, nslots); PALLOC(s_stcur, uint32_t, nslots);
+    PALLOC(s_edgemap, uint32_t, nslots); PALLOC(s_lastpop, uint32_t, nslots);
+    PALLOC(s_wterm, uint32_t, nslots); PALLOC(s_touched, uint32_t, nslots);
+    PALLOC(s_ccbest, uint32_t, nslots); PALLOC(s_stdir, uint8_t, nslots);
+    PALLOC(s_distmap, float, nslots); PALLOC(s_ccoff, uint32_t, (size_t)nslots + ncomp + 1);
+    PALLOC(cerr, uint32_t, ncomp);
+    PALLOC(ok0, uint32_t, ncomp); PALLOC(ok1, uint32_t, ncomp);
+    PALLOC(ov0, uint32_t, ncomp); PALLOC(ov1, uint32_t, ncomp);
+    PALLOC(otmp, uint32_t, gts_sort_tmp_elems(ncomp));
+    HIPCHK(hipMemsetAsync(s_lastpop, 0, (size_t)nslots * 4, e->st));
+    HIPCHK(hipMemsetAsync(cerr, 0, (size_t)ncomp * 4, e->st));
+    LAUNCH("fill", k_fill<float>, nblk(nslots), GTS_BLOCK, s_distmap, GTS_DIST_UNSET,
+           (uint64_t)nslots);
+    /* largest components first */
+    LAUNCH("comp_size_keys", k_comp_size_keys, nblk(ncomp), GTS_BLOCK, comp_off, ok0, ov0, ncomp);
+    const uint32_t *order;
+    {
+      int shifts[4] = {0, 8, 16, 24};
+      const int where = gts_radix_sort<uint32_t>(ok0, ov0, ok1, ov1, ncomp, shifts, 4, otmp, e->st);
+      order = where ? ov1 : ov0;
+    }
+    HIPCHK(hipMemsetAsync(e->d_scalars + 12, 0, 16, e->st));
+    LAUNCH("comp_max_size", k_max_u32_diff, nblk(ncomp), GTS_BLOCK, comp_off, ncomp,
+           e->d_scalars + 14);
+    GtsCompView C;
+    C.G = G; C.cmap = cmap; C.ncomp = ncomp; C.comp_off = comp_off; C.slot_v = slot_v;
+    C.cseq = cseq; C.coff = coff; C.cstart = cstart; C.cend = cend; C.cdist = cdist;
+    C.cflags = cflags; C.cgpos = cgpos; C.cstate = cstate; C.vst = vst;
+    C.queue = s_queue; C.term = s_term; C.visited = s_visited; C.st_v = s_stv;
+    C.st_par = s_stpar; C.st_cur = s_stcur; C.edgemap = s_edgemap; C.lastpop = s_lastpop;
+    C.wterm = s_wterm; C.touched = s_touched; C.cc_best = s_ccbest; C.st_dir = s_stdir;
+    C.distmap = s_distmap; C.ccoff = s_ccoff; C.wq_off = wq_off; C.wq_edge = wq_edge;
+    C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
+    LAUNCH(mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold" : "components_removecycles",
+           k_components, ncomp, GTS_WAVE, C, order, mode);
+    LAUNCH("comp_count_errors", k_count_errors, nblk(ncomp), GTS_BLOCK, cerr, ncomp,
+           e->d_scalars + 12);
+    uint32_t res[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 12, hipMemcpyDeviceToHost, e->st));
+    if ((rc = sync_stream(e))) return rc;
+    e->stats["components"] = ncomp;
+    e->stats["max_component"] = res[2];
+    e->stats["compact_edges"] = nce;
+    if (res[1])
+      return fail(e, GTSG_EWALK, "%u components exceeded max_walk_pops=%lld or hold a "
+                  "cyclic distance map", res[1], (long long)e->max_walk_pops);
+    if (!res[0]) break;
+    /* walk queue too small somewhere: restore and retry with more room */
+    HIPCHK(hipMemcpyAsync(e->vstate, snap_v, n, hipMemcpyDeviceToDevice, e->st));
+    if (m) HIPCHK(hipMemcpyAsync(e->state, snap_e, m, hipMemcpyDeviceToDevice, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    factor *= 4;
+    if (++retries > 6) return fail(e, GTSG_EWALK, "walk queues keep overflowing");
+  }
+  e->stats["walk_retries"] = retries;
+  return sync_stream(e);
+}
+
+int gtsg_removecycles(GtsgEngine *e) { return run_components(e, GTS_MODE_REMOVECYCLES); }
+int gtsg_makescaffold(GtsgEngine *e) { return run_components(e, GTS_MODE_MAKESCAFFOLD); }
+
+uint64_t gtsg_num_vertices(const GtsgEngine *e) { return e ? e->n : 0; }
+uint64_t gtsg_num_edges(const GtsgEngine *e) { return e ? e->m : 0; }
+
+int gtsg_get_vertex_states(GtsgEngine *e, uint8_t *out)
+{
+  if (!e || !out) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  if (e->n) HIPCHK(hipMemcpyAsync(out, e->vstate, e->n, hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+
+int gtsg_get_edge_states(GtsgEngine *e, uint8_t *out)
+{
+  if (!e || !out) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->m) return 0;
+  int rc;
+  if (e->pool_cap < (size_t)e->m + 4096) { if ((rc = pool_reserve(e, (size_t)e->m + 4096))) return rc; }
+  else e->pool_used = 0;
+  PALLOC(tmp, uint8_t, e->m);
+  LAUNCH("states_by_id", k_states_by_id, nblk(e->m), GTS_BLOCK, e->state, e->eid, tmp, e->m);
+  HIPCHK(hipMemcpyAsync(out, tmp, e->m, hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+
+int gtsg_get_edges(GtsgEngine *e, uint32_t *start, uint32_t *end, int64_t *dist,
+                   float *std_dev, int64_t *num_pairs, uint8_t *flags)
+{
+  if (!e || !start || !end || !dist || !std_dev || !num_pairs || !flags) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  const uint32_t m = e->m;
+  if (!m) return 0;
+  int rc;
+  const size_t need = (size_t)m * 32 + (1u << 20);
+  if (e->pool_cap < need) { if ((rc = pool_reserve(e, need))) return rc; }
+  else e->pool_used = 0;
+  PALLOC(os, uint32_t, m); PALLOC(oe, uint32_t, m); PALLOC(od, int64_t, m);
+  PALLOC(osd, float, m); PALLOC(onp, int64_t, m); PALLOC(of, uint8_t, m);
+  LAUNCH("edges_by_id", k_edges_by_id, nblk(m), GTS_BLOCK, e->eid, e->estart, e->eend,
+         e->dist, e->sd, e->npairs, e->flags, os, oe, od, osd, onp, of, m);
+  HIPCHK(hipMemcpyAsync(start, os, (size_t)m * 4, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(hipMemcpyAsync(end, oe, (size_t)m * 4, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(hipMemcpyAsync(dist, od, (size_t)m * 8, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(hipMemcpyAsync(std_dev, osd, (size_t)m * 4, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(hipMemcpyAsync(num_pairs, onp, (size_t)m * 8, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(hipMemcpyAsync(flags, of, (size_t)m, hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+
+int gtsg_state_digest(GtsgEngine *e, uint64_t *vd, uint64_t *ed)
+{
+  if (!e || !vd || !ed) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  unsigned long long *acc = (unsigned long long *)(e->d_scalars + 8);
+  HIPCHK(hipMemsetAsync(acc, 0, 16, e->st));
+  if (e->n)
+    LAUNCH("digest", k_digest, nblk(e->n), GTS_BLOCK, e->vstate, (const uint32_t *)nullptr,
+           (uint64_t)e->n, acc);
+  if (e->m)
+    LAUNCH("digest", k_digest, nblk(e->m), GTS_BLOCK, e->state, e->eid, (uint64_t)e->m, acc + 1);
+  uint64_t h[2];
+  HIPCHK(hipMemcpyAsync(h, acc, 16, hipMemcpyDeviceToHost, e->st));
+  int rc = sync_stream(e);
+  *vd = h[0]; *ed = h[1];
+  return rc;
+}
+
+int gtsg_selftest_ambiguous(GtsgEngine *e, uint64_t n, const int64_t *d1,
+                            const float *s1, const int64_t *d2, const float *s2,
+                            float pcutoff, uint8_t *out)
+{
+  if (!e || !d1 || !s1 || !d2 || !s2 || !out) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  int rc;
+  if ((rc = pool_reserve(e, n * 32 + (1u << 20)))) return rc;
+  PALLOC(a, int64_t, n); PALLOC(b, float, n); PALLOC(c, int64_t, n);
+  PALLOC(d, float, n); PALLOC(o, uint8_t, n);
+  upload(e, a, d1, n, 0); upload(e, b, s1, n, 0); upload(e, c, d2, n, 0); upload(e, d, s2, n, 0);
+  LAUNCH("amb_test", k_amb_test, nblk(n), GTS_BLOCK, a, b, c, d, o, n, gts_amb_thresholds(pcutoff));
+  HIPCHK(hipMemcpyAsync(out, o, n, hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+
+int gtsg_get_kernel_times(GtsgEngine *e, GtsgKernelTime *out, int cap)
+{
+  if (!e) return GTSG_EINVAL;
+  collect_times(e);
+  int i = 0;
+  for (auto &kv : e->ktimes) {
+    if (out && i < cap) {
+      memset(&out[i], 0, sizeof out[i]);
+      strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+      out[i].calls = kv.second.first;
+      out[i].ms = kv.second.second;
+    }
+    ++i;
+  }
+  return i;
+}
+void gtsg_reset_kernel_times(GtsgEngine *e) { if (e) { collect_times(e); e->ktimes.clear(); } }
+
+int64_t gtsg_get_stat(const GtsgEngine *e, const char *name)
+{
+  if (!e || !name) return -1;
+  auto it = e->stats.find(name);
+  return it == e->stats.end() ? -1 : it->second;
+}
+
+} /* extern "C" */

@@ -1,0 +1,230 @@
+"""ctypes binding of the engine's C ABI (include/gt_scaffold_hip.h).
+
+There is no CPU path: loading fails if csrc/libgtscaffold_hip.so has not been
+built, and Engine() raises if no GPU is visible.  Arrays cross the boundary as
+raw pointers: numpy arrays (host) or anything with a CUDA/HIP data_ptr()
+(torch tensors on the engine's device)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgtscaffold_hip.so")
+_LIB = None
+
+SYMBOLS = [
+    "gtsg_create", "gtsg_destroy", "gtsg_last_error", "gtsg_set_contigs",
+    "gtsg_build_from_records", "gtsg_set_astat", "gtsg_mark_repeats", "gtsg_filter",
+    "gtsg_removecycles", "gtsg_makescaffold", "gtsg_num_vertices", "gtsg_num_edges",
+    "gtsg_get_vertex_states", "gtsg_get_edge_states", "gtsg_get_edges", "gtsg_state_digest",
+    "gtsg_set_option", "gtsg_selftest_ambiguous", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
+]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("calls", C.c_uint64), ("ms", C.c_double)]
+
+
+def lib():
+    """dlopen the engine; raises if it is missing (build with __graft_entry__.build())."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built: run `python __graft_entry__.py` (hipcc, gfx950); "
+                              "the engine has no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            getattr(L, s)  # AttributeError if a declared entry point is missing
+        vp, u64, i64, f32, ci = C.c_void_p, C.c_uint64, C.c_int64, C.c_float, C.c_int
+        L.gtsg_create.argtypes = [C.POINTER(vp), ci, vp]
+        L.gtsg_destroy.argtypes = [vp]
+        L.gtsg_last_error.argtypes = [vp]
+        L.gtsg_last_error.restype = C.c_char_p
+        L.gtsg_set_contigs.argtypes = [vp, u64, vp, vp, vp, ci]
+        L.gtsg_build_from_records.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, ci]
+        L.gtsg_set_astat.argtypes = [vp, vp, vp, ci]
+        L.gtsg_mark_repeats.argtypes = [vp, ci, f32, f32]
+        L.gtsg_filter.argtypes = [vp, f32, f32, i64]
+        L.gtsg_removecycles.argtypes = [vp]
+        L.gtsg_makescaffold.argtypes = [vp]
+        L.gtsg_num_vertices.argtypes = [vp]
+        L.gtsg_num_vertices.restype = u64
+        L.gtsg_num_edges.argtypes = [vp]
+        L.gtsg_num_edges.restype = u64
+        L.gtsg_get_vertex_states.argtypes = [vp, vp]
+        L.gtsg_get_edge_states.argtypes = [vp, vp]
+        L.gtsg_get_edges.argtypes = [vp] + [vp] * 6
+        L.gtsg_state_digest.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+        L.gtsg_selftest_ambiguous.argtypes = [vp, u64, vp, vp, vp, vp, f32, vp]
+        L.gtsg_set_option.argtypes = [vp, C.c_char_p, i64]
+        L.gtsg_get_kernel_times.argtypes = [vp, C.POINTER(KernelTime), ci]
+        L.gtsg_reset_kernel_times.argtypes = [vp]
+        L.gtsg_get_stat.argtypes = [vp, C.c_char_p]
+        L.gtsg_get_stat.restype = i64
+        _LIB = L
+    return _LIB
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _ptr(a, dtype):
+    """(pointer, on_device, keepalive) of a numpy array or a device tensor."""
+    if a is None:
+        return None, None, None
+    if isinstance(a, np.ndarray):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        return a.ctypes.data_as(C.c_void_p), 0, a
+    # torch tensor (or anything exposing data_ptr / is_cuda)
+    if not a.is_contiguous():
+        a = a.contiguous()
+    if a.element_size() != np.dtype(dtype).itemsize:
+        raise TypeError("tensor element size %d does not match %s" % (a.element_size(), dtype))
+    return C.c_void_p(a.data_ptr()), (1 if a.is_cuda else 0), a
+
+
+class Engine:
+    """One scaffold graph resident on one GPU.  Method names follow the
+    reference's API (gt_scaffolder_graph_* / gt_scaffolder_*)."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.gtsg_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise EngineError("gtsg_create failed (%d): no usable HIP device; the engine has no "
+                              "CPU fallback" % rc)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gtsg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError("%s (code %d)" % (self._L.gtsg_last_error(self._h).decode(), rc))
+
+    def _same_side(self, sides):
+        sides = [s for s in sides if s is not None]
+        if len(set(sides)) > 1:
+            raise TypeError("mixing host and device arrays in one call")
+        return sides[0] if sides else 0
+
+    # ---- construction ----
+    def set_contigs(self, seq_len, astat=None, copy_num=None):
+        p0, d0, k0 = _ptr(seq_len, np.int64)
+        p1, d1, k1 = _ptr(astat, np.float32)
+        p2, d2, k2 = _ptr(copy_num, np.float32)
+        self._chk(self._L.gtsg_set_contigs(self._h, len(seq_len), p0, p1, p2,
+                                           self._same_side([d0, d1, d2])))
+
+    def build_from_records(self, root, ctg, dist, std_dev, num_pairs, flags):
+        a = [_ptr(root, np.uint32), _ptr(ctg, np.uint32), _ptr(dist, np.int64),
+             _ptr(std_dev, np.float32), _ptr(num_pairs, np.int64), _ptr(flags, np.uint8)]
+        self._chk(self._L.gtsg_build_from_records(self._h, len(root), *[x[0] for x in a],
+                                                  self._same_side([x[1] for x in a])))
+
+    def set_astat(self, astat, copy_num):
+        p1, d1, k1 = _ptr(astat, np.float32)
+        p2, d2, k2 = _ptr(copy_num, np.float32)
+        self._chk(self._L.gtsg_set_astat(self._h, p1, p2, self._same_side([d1, d2])))
+
+    # ---- algorithms ----
+    def mark_repeats(self, have_file=True, copy_num_cutoff=0.3, astat_cutoff=20.0):
+        self._chk(self._L.gtsg_mark_repeats(self._h, int(have_file), copy_num_cutoff, astat_cutoff))
+
+    def filter(self, pcutoff=0.01, cncutoff=1.5, ocutoff=400):
+        self._chk(self._L.gtsg_filter(self._h, pcutoff, cncutoff, int(ocutoff)))
+
+    def removecycles(self):
+        self._chk(self._L.gtsg_removecycles(self._h))
+
+    def makescaffold(self):
+        self._chk(self._L.gtsg_makescaffold(self._h))
+
+    # ---- results ----
+    @property
+    def nv(self):
+        return int(self._L.gtsg_num_vertices(self._h))
+
+    @property
+    def ne(self):
+        return int(self._L.gtsg_num_edges(self._h))
+
+    def vertex_states(self):
+        out = np.zeros(max(self.nv, 1), np.uint8)
+        self._chk(self._L.gtsg_get_vertex_states(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out[:self.nv]
+
+    def edge_states(self):
+        out = np.zeros(max(self.ne, 1), np.uint8)
+        self._chk(self._L.gtsg_get_edge_states(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out[:self.ne]
+
+    def edges(self):
+        m = self.ne
+        n = max(m, 1)
+        o = dict(start=np.zeros(n, np.uint32), end=np.zeros(n, np.uint32),
+                 dist=np.zeros(n, np.int64), std_dev=np.zeros(n, np.float32),
+                 num_pairs=np.zeros(n, np.int64), flags=np.zeros(n, np.uint8))
+        self._chk(self._L.gtsg_get_edges(self._h, *[o[k].ctypes.data_as(C.c_void_p) for k in
+                                                    ("start", "end", "dist", "std_dev",
+                                                     "num_pairs", "flags")]))
+        return {k: v[:m] for k, v in o.items()}
+
+    def digest(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self._L.gtsg_state_digest(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def selftest_ambiguous(self, d1, s1, d2, s2, pcutoff):
+        d1 = np.ascontiguousarray(d1, np.int64); d2 = np.ascontiguousarray(d2, np.int64)
+        s1 = np.ascontiguousarray(s1, np.float32); s2 = np.ascontiguousarray(s2, np.float32)
+        out = np.zeros(len(d1), np.uint8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._chk(self._L.gtsg_selftest_ambiguous(self._h, len(d1), p(d1), p(s1), p(d2), p(s2),
+                                                  pcutoff, p(out)))
+        return out
+
+    # ---- tuning / measurement ----
+    def set_option(self, name, value):
+        self._chk(self._L.gtsg_set_option(self._h, name.encode(), int(value)))
+
+    def stat(self, name):
+        return int(self._L.gtsg_get_stat(self._h, name.encode()))
+
+    def kernel_times(self):
+        n = self._L.gtsg_get_kernel_times(self._h, None, 0)
+        buf = (KernelTime * max(n, 1))()
+        n = self._L.gtsg_get_kernel_times(self._h, buf, n)
+        return {buf[i].name.decode(): (int(buf[i].calls), float(buf[i].ms)) for i in range(n)}
+
+    def reset_kernel_times(self):
+        self._L.gtsg_reset_kernel_times(self._h)
+
+
+def state_digest_host(vstates, estates):
+    """Host restatement of gtsg_state_digest (for comparing with oracle states)."""
+    def mix(x):
+        x = x.astype(np.uint64)
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xff51afd7ed558ccd)
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xc4ceb9fe1a85ec53)
+        x ^= x >> np.uint64(33)
+        return x
+
+    with np.errstate(over="ignore"):
+        def dig(s):
+            ids = np.arange(len(s), dtype=np.uint64)
+            return int(mix((ids << np.uint64(8)) | s.astype(np.uint64)).sum(dtype=np.uint64))
+        return dig(vstates), dig(estates)

@@ -1,0 +1,126 @@
+/*
+  gt_scaffold_hip.h -- C ABI of the MI355X scaffold-graph engine
+  (libgtscaffold_hip.so).  Plain pointers and sizes only.
+
+  It replaces, function by function, the compute path of the reference's
+  GtScaffolderGraph C API.  A GenomeTools build keeps gt_scaffolder_graph.h /
+  gt_scaffolder_algorithms.h unchanged and routes their bodies here
+  (INTEGRATION.md shows the shim); the host layer in gt_scaffolder_host.h does
+  the same with plain C types in place of GtStr / GtError / GtFile.
+
+  Conventions
+    * every call returns 0 on success, a negative GTSG_E* code on failure and
+      leaves a message retrievable with gtsg_last_error();
+    * vertex ids are the reference's: contigs sorted by header
+      (ref src/gt_scaffolder_parser.c:172), edge ids are creation order
+      (ref src/gt_scaffolder_graph.c:137-170);
+    * states are GraphItemState values (ref src/gt_scaffolder_graph.h:29-31);
+    * record/edge flags: bit0 = sense, bit1 = same (ref graph.h:63-69);
+    * `on_device` != 0: the array arguments are device pointers valid on the
+      engine's GPU (e.g. torch tensors' data_ptr()), consumed on the engine's
+      stream; 0: host pointers, copied with hipMemcpyAsync.
+*/
+#ifndef GT_SCAFFOLD_HIP_H
+#define GT_SCAFFOLD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct GtsgEngine GtsgEngine;
+
+enum {
+  GTSG_OK = 0,
+  GTSG_EINVAL = -1,    /* bad argument / call order */
+  GTSG_EHIP = -2,      /* HIP runtime error */
+  GTSG_ENOMEM = -3,
+  GTSG_EWALK = -4,     /* a walk exceeded its pop bound (cyclic distance maps) */
+  GTSG_ELIMIT = -5     /* more than 2^31-1 contigs or 2^32-2 edges */
+};
+
+/* Engine bound to HIP device `device`.  `stream` is a hipStream_t (NULL: the
+   engine creates its own).  Fails loudly if no gfx950-capable GPU is present:
+   there is no CPU fallback. */
+int gtsg_create(GtsgEngine **out, int device, void *stream);
+void gtsg_destroy(GtsgEngine *e);
+const char *gtsg_last_error(const GtsgEngine *e);
+
+/* Contigs = vertices.  replaces gt_scaffolder_graph_add_vertex in the loop of
+   gt_scaffolder_parser_read_contigs (ref parser.c:524-549, graph.c:105-131).
+   astat / copy_num may be NULL (0.0, as for FASTA headers without
+   annotation, ref parser.c:434-435). */
+int gtsg_set_contigs(GtsgEngine *e, uint64_t n, const int64_t *seq_len,
+                     const float *astat, const float *copy_num, int on_device);
+
+/* DistEst records in file order -> edges + CSR.  replaces
+   gt_scaffolder_parser_read_distances' per-record graph updates
+   (ref parser.c:357-378: find_edge / alter_edge / two add_edge calls,
+   graph.c:137-235).  num_pairs may be NULL. */
+int gtsg_build_from_records(GtsgEngine *e, uint64_t n_records,
+                            const uint32_t *root, const uint32_t *ctg,
+                            const int64_t *dist, const float *std_dev,
+                            const int64_t *num_pairs, const uint8_t *flags,
+                            int on_device);
+
+/* A-statistics / copy numbers read from the .astat file, per vertex
+   (ref algorithms.c:118-149, the file part of mark_repeats). */
+int gtsg_set_astat(GtsgEngine *e, const float *astat, const float *copy_num,
+                   int on_device);
+
+/* ref gt_scaffolder_algorithms.h: gt_scaffolder_graph_mark_repeats (marking
+   loop algorithms.c:155-167; have_file = strlen(filename) != 0) */
+int gtsg_mark_repeats(GtsgEngine *e, int have_file, float copy_num_cutoff,
+                      float astat_cutoff);
+/* ref gt_scaffolder_graph_filter, algorithms.c:261-343 */
+int gtsg_filter(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff);
+/* ref gt_scaffolder_removecycles, algorithms.c:495-578 */
+int gtsg_removecycles(GtsgEngine *e);
+/* ref gt_scaffolder_makescaffold, algorithms.c:767-868 */
+int gtsg_makescaffold(GtsgEngine *e);
+
+uint64_t gtsg_num_vertices(const GtsgEngine *e);
+uint64_t gtsg_num_edges(const GtsgEngine *e);
+/* results to HOST buffers; edges in the reference's edge-id order */
+int gtsg_get_vertex_states(GtsgEngine *e, uint8_t *out);
+int gtsg_get_edge_states(GtsgEngine *e, uint8_t *out);
+int gtsg_get_edges(GtsgEngine *e, uint32_t *start, uint32_t *end, int64_t *dist,
+                   float *std_dev, int64_t *num_pairs, uint8_t *flags);
+/* order-independent 64-bit digest of (vertex states, edge states by id),
+   computed on the device: used to compare full-size runs */
+int gtsg_state_digest(GtsgEngine *e, uint64_t *vertex_digest,
+                      uint64_t *edge_digest);
+
+/* diagnostic: evaluates the engine's ambiguous-order test (ref algorithms.c:
+   175-193) on n host-side pairs (dist1, std_dev1, dist2, std_dev2) on the
+   device; out[i] = 1 if ambiguous.  Used by the parity tests to pin the
+   device's int64->float / double sqrt / double divide roundings. */
+int gtsg_selftest_ambiguous(GtsgEngine *e, uint64_t n, const int64_t *d1,
+                            const float *s1, const int64_t *d2, const float *s2,
+                            float pcutoff, uint8_t *out);
+
+/* tuning */
+int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
+/*   "walk_queue_factor" (default 8), "max_walk_pops" (default 2^32),
+     "hub_degree" (default 32), "profile" (0/1) */
+
+/* per-kernel timing collected with hipEvents on the engine's stream while
+   option "profile" is 1.  Fills up to cap entries, returns the number of
+   distinct kernels. */
+typedef struct {
+  char name[48];
+  uint64_t calls;
+  double ms;
+} GtsgKernelTime;
+int gtsg_get_kernel_times(GtsgEngine *e, GtsgKernelTime *out, int cap);
+void gtsg_reset_kernel_times(GtsgEngine *e);
+/* counters of the last calls: "filter_rounds_p", "filter_rounds_i",
+   "components", "max_component", "slots", "compact_edges", "hubs",
+   "walk_retries" */
+int64_t gtsg_get_stat(const GtsgEngine *e, const char *name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

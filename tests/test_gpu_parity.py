@@ -1,0 +1,143 @@
+"""Parity of the HIP engine (through the C ABI) with the CPU oracle, stage by
+stage, on seeded synthetic graphs and on the reference's own test data.
+Integer / state work: bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import DEFAULTS, make_inputs, oracle_from_inputs, pkg
+from oracle.oracle_py import OracleGraph, lib as oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_from_inputs(g, **opts):
+    eng = pkg.engine.Engine(0)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    eng.set_contigs(g["seq_len"].astype(np.int64), g["astat"], g["copy_num"])
+    eng.build_from_records(g["root"], g["ctg"], g["dist"], g["std_dev"],
+                           g["num_pairs"].astype(np.int64), g["flags"])
+    return eng
+
+
+def assert_same_graph(eng, og):
+    assert eng.nv == og.nv and eng.ne == og.ne, (eng.nv, og.nv, eng.ne, og.ne)
+    a, b = eng.edges(), og.edges()
+    for k in ("start", "end", "dist", "std_dev", "flags"):
+        assert np.array_equal(a[k], b[k]), "edge field %s differs at %s" % (k, np.nonzero(a[k] != b[k])[0][:8])
+    assert np.array_equal(a["num_pairs"].astype(np.uint64), b["num_pairs"])
+
+
+def assert_same_states(eng, og, tag):
+    ev, ov = eng.vertex_states(), og.vertex_states()
+    assert np.array_equal(ev, ov), "%s: vertex states differ at %s" % (tag, np.nonzero(ev != ov)[0][:8])
+    ee, oe = eng.edge_states(), og.edge_states()
+    assert np.array_equal(ee, oe), "%s: edge states differ at %s" % (tag, np.nonzero(ee != oe)[0][:8])
+
+
+def run_pipeline(g, pcutoff=0.01, cncutoff=1.5, ocutoff=400, **opts):
+    og = oracle_from_inputs(g)
+    eng = engine_from_inputs(g, **opts)
+    assert_same_graph(eng, og)
+    og.mark_repeats(); eng.mark_repeats()
+    assert_same_states(eng, og, "mark_repeats")
+    og.filter(pcutoff, cncutoff, ocutoff); eng.filter(pcutoff, cncutoff, ocutoff)
+    assert_same_states(eng, og, "filter")
+    og.removecycles(); eng.removecycles()
+    assert_same_states(eng, og, "removecycles")
+    og.makescaffold(True); eng.makescaffold()
+    assert_same_states(eng, og, "makescaffold")
+    return eng, og
+
+
+def test_device_rounding_of_ambiguous_order():
+    rng = np.random.default_rng(0)
+    n = 400000
+    d1 = rng.integers(-5000, 5000, n); d2 = d1 + rng.integers(-40, 40, n)
+    big = rng.random(n) < 0.1            # int64 -> float rounding
+    d1 = np.where(big, d1 * (1 << 40) + rng.integers(0, 1 << 30, n), d1)
+    s1 = (rng.random(n) * 30).astype(np.float32); s2 = (rng.random(n) * 30).astype(np.float32)
+    s1[rng.random(n) < 0.01] = 0; s2[rng.random(n) < 0.01] = 0
+    eng = pkg.engine.Engine(0)
+    L = oracle_lib()
+    for pc in (0.01, 0.2, 0.0):
+        got = eng.selftest_ambiguous(d1, s1, d2, s2, pc)
+        want = np.array([L.ora_ambiguousorder(int(a), float(b), int(c), float(d), pc)
+                         for a, b, c, d in zip(d1[:60000], s1[:60000], d2[:60000], s2[:60000])], np.uint8)
+        assert np.array_equal(got[:60000], want)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_small_graphs_stage_by_stage(seed):
+    g = make_inputs(400 + 211 * seed, seed, p_chimeric=0.03, p_bubble=0.05, p_repeat=0.03)
+    run_pipeline(g)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_noisy_graphs(seed):
+    g = make_inputs(3000, 100 + seed, p_chimeric=0.3, p_bubble=0.1, p_repeat=0.05, links_per_side=3)
+    run_pipeline(g)
+
+
+@pytest.mark.parametrize("ocutoff,pcutoff,cncutoff", [(-1, 0.01, 1.5), (0, 0.2, 3.0), (100000, 0.49, 10.0),
+                                                      (50, -1.0, 100.0), (400, 0.6, 1.5)])
+def test_cutoff_corner_cases(ocutoff, pcutoff, cncutoff):
+    g = make_inputs(2000, 7, p_chimeric=0.1, p_bubble=0.1)
+    run_pipeline(g, pcutoff=pcutoff, cncutoff=cncutoff, ocutoff=ocutoff)
+
+
+def test_tie_heavy_walks():
+    g = make_inputs(3000, 21, dist_range_small=True, contig_median=300)
+    run_pipeline(g)
+
+
+def test_hub_vertices_take_the_wave_path():
+    g = make_inputs(4000, 11, p_repeat=0.02, repeat_degree=300, p_chimeric=0.05)
+    eng, _ = run_pipeline(g, hub_degree=8)
+    assert eng.stat("hubs") > 100
+
+
+def test_walk_queue_retry():
+    g = make_inputs(20000, 5)
+    eng, _ = run_pipeline(g, walk_queue_factor=1)
+    assert eng.stat("walk_retries") >= 1
+
+
+def test_empty_and_ragged_inputs():
+    # contigs without any record; records only between two contigs
+    g = make_inputs(50, 1)
+    for k in ("root", "ctg", "dist", "std_dev", "num_pairs", "flags"):
+        g[k] = g[k][:0]
+    eng = engine_from_inputs(g)
+    assert eng.ne == 0
+    eng.mark_repeats(); eng.filter(); eng.removecycles(); eng.makescaffold()
+    og = oracle_from_inputs(g); og.mark_repeats(); og.filter(); og.removecycles(); og.makescaffold(True)
+    assert_same_states(eng, og, "no edges")
+
+
+def test_reference_test_data(golden_dir):
+    # ref testdata/primary-contigs.fa + libPE.de + libPE.astat (BASELINE configs[0])
+    og = OracleGraph.from_files(golden_dir + "/primary-contigs.fa", golden_dir + "/libPE.de")
+    # records re-derived from the oracle's parse: each edge pair once, in id order
+    e, v = og.edges(), og.vertices()
+    og.mark_repeats_file(golden_dir + "/libPE.astat")
+    v2 = og.vertices()
+    eng = pkg.engine.Engine(0)
+    eng.set_contigs(v["seq_len"].astype(np.int64), v["astat"], v["copy_num"])
+    sel = np.arange(0, og.ne, 2)
+    eng.build_from_records(e["start"][sel], e["end"][sel], e["dist"][sel], e["std_dev"][sel],
+                           e["num_pairs"][sel].astype(np.int64), e["flags"][sel])
+    assert_same_graph(eng, og)
+    eng.set_astat(v2["astat"], v2["copy_num"])
+    eng.mark_repeats(True, DEFAULTS["copy_num_cutoff"], DEFAULTS["astat_cutoff"])
+    assert_same_states(eng, og, "mark_repeats")
+    og.filter(); eng.filter(); assert_same_states(eng, og, "filter")
+    og.removecycles(); eng.removecycles(); assert_same_states(eng, og, "removecycles")
+    og.makescaffold(False); eng.makescaffold(); assert_same_states(eng, og, "makescaffold")
+
+
+def test_medium_graph_and_digest():
+    g = make_inputs(100000, 5)
+    eng, og = run_pipeline(g)
+    assert eng.digest() == pkg.engine.state_digest_host(og.vertex_states(), og.edge_states())
+    assert eng.stat("components") > 1000
