@@ -22,9 +22,12 @@
 static inline bool gts_amb_pipeline(float interval, float cutoff)
 {
   float prob12, prob21, p_wrong;
-  prob12 = 0.5 * (1 + erf(interval));
-  prob21 = 1.0 - prob12;
-  p_wrong = 1.0 - (prob12 > prob21 ? prob12 : prob21);
+  /* the reference is C: erf() takes the double overload.  Spell the
+     promotion out, this header is compiled as C++ (erf(float) would bind to
+     erff there). */
+  prob12 = (float)(0.5 * (1.0 + erf((double)interval)));
+  prob21 = (float)(1.0 - (double)prob12);
+  p_wrong = (float)(1.0 - (double)(prob12 > prob21 ? prob12 : prob21));
   return p_wrong > cutoff;
 }
 
