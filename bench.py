@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the scaffold-graph hot path on MI355X.
+
+metric : scaffold-graph edges processed/sec (build + mark_repeats + filter +
+         makescaffold), BASELINE.json.
+step   : one pass of the hot path over one synthetic batch whose inputs
+         (contig table + DistEst records in file order) are already resident
+         in HBM when the timed region starts.
+N > 1  : one process per GPU (torch.distributed / RCCL only for the barrier
+         and the max-over-ranks of the time); every rank scaffolds its own
+         shard of independent connected components (its own synthetic genome
+         shard), no data-path collective -> weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from __graft_entry__ import load_package  # noqa: E402
+
+# the configuration BASELINE.json's metric is quoted on (configs[2], the
+# north_star's 10M-contig / 100M-edge graph; it fits one GPU)
+WORKLOAD = dict(name="synthetic 10M-contig / 100M-edge scaffold graph",
+                n_contigs=10_000_000,
+                gen=dict(links_per_side=5, p_repeat=0.03, repeat_degree=43))
+CUTS = dict(copy_num_cutoff=0.3, astat_cutoff=20.0, pcutoff=0.01, cncutoff=1.5, ocutoff=400)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(name, n, m, nrec, eng):
+    """Algorithmic HBM bytes of ONE launch of a kernel ('Kernels'):
+    every input element read once, every output element written once."""
+    vb = max(1, (int(n - 1).bit_length() + 7) // 8)         # 8-bit digits per vertex id
+    nce = max(eng.stat("compact_edges"), 0)
+    ns = max(eng.stat("slots"), 0)
+    table = {
+        # 64-bit pair keys + record ids: per digit pass read twice, written once
+        "build_sort_pairs": 2 * vb * nrec * (8 + (8 + 4) + (8 + 4)),
+        "build_sort_csr": vb * m * (4 + (4 + 4) + (4 + 4)),
+        "build_pair_keys": nrec * (8 + 12),
+        "build_pair_segments": nrec * (12 + 4 + 4),
+        "build_emit_edges": nrec * 8 + m * (29 + 36),
+        "build_gather_csr": m * (4 + 32 + 30),
+        "build_twins": m * 12,
+        "build_row_offsets": m * 4 + n * 4,
+        "repeat_edges": m * (8 + 1) + n * 8,
+        "filter_pairs": m * (4 + 8 + 4 + 1 + 1) + n * (4 + 4 + 8 + 2),
+        "filter_final": m * (4 + 4 + 1 + 1 + 1) + n * (4 + 4 + 1 + 8),
+        "comp_live_union": m * (4 + 4 + 1 + 1) + n * 6,
+        "comp_compact_fill": m * (4 + 1 + 4) + nce * 26 + ns * 8,
+        # the compact graph is read once and the marks written once
+        "components_makescaffold": nce * (4 + 4 + 8 + 1 + 1 + 4) + ns * (8 + 4 + 1) + m * 1 + n * 1,
+    }
+    return table.get(name)
+
+
+def make_inputs(pkg, n_contigs, seed, device, gen):
+    g = pkg.synth.make_graph(n_contigs, seed=seed, device=device, **gen)
+    return g
+
+
+def run_step(eng, g):
+    eng.set_contigs(g["seq_len"], g["astat"], g["copy_num"])
+    eng.build_from_records(g["root"], g["ctg"], g["dist"], g["std_dev"], g["num_pairs"], g["flags"])
+    eng.mark_repeats(True, CUTS["copy_num_cutoff"], CUTS["astat_cutoff"])
+    eng.filter(CUTS["pcutoff"], CUTS["cncutoff"], CUTS["ocutoff"])
+    eng.makescaffold()
+    return eng.ne
+
+
+def cpu_baseline(pkg, n_sample, gen, seed):
+    """The oracle (a single-threaded port of the reference's algorithms) on a
+    bounded sample of the same workload, on this host's cores."""
+    from oracle.oracle_py import OracleGraph
+    g = pkg.synth.to_numpy(pkg.synth.make_graph(n_sample, seed=seed, device="cpu", **gen))
+    t0 = time.perf_counter()
+    og = OracleGraph.from_records(g["seq_len"], g["astat"], g["copy_num"], g["root"], g["ctg"],
+                                  g["dist"], g["std_dev"], g["num_pairs"], g["flags"])
+    og.mark_repeats(True, CUTS["copy_num_cutoff"], CUTS["astat_cutoff"])
+    og.filter(CUTS["pcutoff"], CUTS["cncutoff"], CUTS["ocutoff"])
+    og.makescaffold(True)
+    dt = time.perf_counter() - t0
+    return dict(value=og.ne / dt, unit="edges/s", cores=1, kind="port",
+                sample="%d-contig / %d-edge graph from the same generator, %.1f s; oracle with "
+                       "epoch-stamped distance maps (the reference's per-walk O(|V|) map "
+                       "initialisation, algorithms.c:648-650, would be slower still)"
+                       % (n_sample, og.ne, dt)), og, g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--contigs", type=int, default=WORKLOAD["n_contigs"],
+                    help="contigs per GPU (default: the BASELINE configuration)")
+    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="also run the oracle on the FULL workload and compare digests (slow)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    pkg = load_package()
+    dev = "cuda:%d" % local_rank
+
+    g = make_inputs(pkg, args.contigs, 1234 + rank, dev, WORKLOAD["gen"])
+    g["num_pairs"] = g["num_pairs"].to(torch.int64)
+    nrec = g["root"].numel()
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = pkg.engine.Engine(local_rank, stream)
+    eng.set_option("profile", 1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_step(eng, g)
+    eng.reset_kernel_times()
+    barrier()
+    t0 = time.perf_counter()
+    edges = 0
+    for _ in range(args.steps):
+        edges += run_step(eng, g)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    etot = torch.tensor([edges], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(etot, op=dist.ReduceOp.SUM)
+    dt_max, edges_all = float(tmax.item()), float(etot.item())
+
+    if rank == 0:
+        n, m = eng.nv, eng.ne
+        kt = eng.kernel_times()
+        dom = max(kt.items(), key=lambda kv: kv[1][1])
+        dname, (dcalls, dms) = dom
+        avg_ms = dms / max(dcalls, 1)
+        ab = algorithmic_bytes(dname, n, m, nrec, eng)
+        roof = dict(bound="hbm", kernel=dname, launches=dcalls, avg_ms=avg_ms,
+                    achieved=(ab / (avg_ms * 1e-3) / 1e9) if ab else None, peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=None, traffic=None, algorithmic_bytes=ab)
+        if roof["achieved"] is not None:
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        out = dict(metric="scaffold-graph edges processed/sec (build+filter+makescaffold)",
+                   value=edges_all / dt_max, unit="edges/s", n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=dt_max / args.steps * 1e3,
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int64/u8",
+                   data="synthetic",
+                   config=dict(workload=WORKLOAD["name"], contigs_per_gpu=n, edges_per_gpu=m,
+                               records_per_gpu=nrec, components=eng.stat("components"),
+                               max_component=eng.stat("max_component"),
+                               parallelism="components sharded, %d GPU(s)" % world),
+                   roofline=roof,
+                   kernels_ms_per_step={k: round(v[1] / args.steps, 3) for k, v in
+                                        sorted(kt.items(), key=lambda kv: -kv[1][1])[:12]})
+        if not args.no_cpu_baseline:
+            cb, og, gs = cpu_baseline(pkg, args.cpu_sample, WORKLOAD["gen"], 99)
+            out["cpu_baseline"] = cb
+        if args.verify:
+            from oracle.oracle_py import OracleGraph
+            gn = pkg.synth.to_numpy(g)
+            og = OracleGraph.from_records(gn["seq_len"], gn["astat"], gn["copy_num"], gn["root"],
+                                          gn["ctg"], gn["dist"], gn["std_dev"], gn["num_pairs"],
+                                          gn["flags"])
+            og.mark_repeats(True, CUTS["copy_num_cutoff"], CUTS["astat_cutoff"])
+            og.filter(CUTS["pcutoff"], CUTS["cncutoff"], CUTS["ocutoff"])
+            og.makescaffold(True)
+            out["verified_against_oracle"] = (eng.digest() == pkg.engine.state_digest_host(
+                og.vertex_states(), og.edge_states()))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
