@@ -67,6 +67,12 @@ struct GtsCompView {
   int64_t *wq_dist;
   uint32_t *cerr;            /* ncomp: error code per component */
   uint64_t max_pops;         /* bound on queue pops of one walk */
+  /* linear-time walk (create_walk_fast) */
+  int fast_walks;            /* 0: always run the reference's search */
+  int64_t *nd;               /* slot -> integer label pushed with the node */
+  uint64_t *plen;            /* slot -> contig length of the tree path */
+  uint8_t *tight;            /* slot -> number of tight in-arcs (saturating) */
+  uint32_t *stat_fast, *stat_slow;  /* per component: walks by path taken */
 };
 
 /* (float)GT_WORD_MAX, ref algorithms.c:650 */
@@ -81,10 +87,12 @@ struct GtsComponent {
   /* walk-queue state of the walk in flight */
   uint64_t qbase, qcap, qh, qn;
   uint32_t ntouch;
+  uint32_t nfast, nslow;
 
   GTS_HD GtsComponent(const GtsCompView &cv, uint32_t comp)
       : C(cv), c(comp), s0(cv.comp_off[comp]), s1(cv.comp_off[comp + 1]),
-        nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0), ntouch(0) {}
+        nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0), ntouch(0),
+        nfast(0), nslow(0) {}
 
   GTS_HD uint32_t *ccoffs() const { return C.ccoff + s0 + c; }
 
@@ -315,7 +323,7 @@ struct GtsComponent {
      terminal `start`, evaluates the reached terminals and, if the best walk is
      longer than cc_len, stores it in cc_best (edge order as the reference:
      from the far terminal back to start).  Returns false on error. ---- */
-  GTS_HD bool create_walk(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
+  GTS_HD bool create_walk_reference(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t lane = W::lane();
     const uint32_t gv = C.slot_v[start];
@@ -441,11 +449,186 @@ struct GtsComponent {
     return ok;
   }
 
+
+  /* ---- linear-time equivalent of create_walk for the common case ----
+     The reference's search (algorithms.c:681-728) is a FIFO label-correcting
+     relaxation: on scaffolds with multi-hop links every vertex is re-queued
+     once per hop count, O(L^2) pops for a chain of L contigs.  Its RESULT is
+     order-independent whenever
+       (a) the (vertex, leaving direction) states reachable from the start form
+           a DAG in which every vertex occurs with ONE direction (then the twin
+           exclusion of algorithms.c:702 never applies either),
+       (b) every reached vertex has exactly ONE in-arc that attains its final
+           label (edgemap keeps the FIRST arc that sets the final value; with a
+           single candidate the order does not matter),
+       (c) one reached terminal has the strictly longest tree path (the
+           reference breaks length ties by pop order).
+     The final label is min over paths of the nested float roundings
+     fl(int(label) + dist); fl is monotone, so a relaxation in topological
+     order computes it with the very same operations.  Any violated condition
+     returns false with the scratch restored, and the caller runs the
+     reference's search instead. */
+  GTS_HD bool create_walk_fast(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
+  {
+    const uint32_t lane = W::lane();
+    uint32_t *R = C.queue, *TQ = C.visited, *indeg = C.st_v;
+    uint8_t *orient = C.st_dir;
+    /* all live edges of the start must leave in one direction */
+    bool has_s = false, has_a = false;
+    {
+      const uint32_t eb = W::uni(C.coff[start]), ee = W::uni(C.coff[start + 1]);
+      for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool live = false, sense = false;
+        if (ce < ee) {
+          live = !gts_edge_is_marked(C.cstate[ce]);
+          sense = (C.cflags[ce] & GTS_F_SENSE) != 0;
+        }
+        has_s |= W::ballot(live && sense) != 0;
+        has_a |= W::ballot(live && !sense) != 0;
+      }
+    }
+    if (has_s && has_a) return false;
+    if (!has_s && !has_a) return true;          /* nothing reachable: empty walk */
+    /* pass 1: reachable states, in-degrees */
+    uint32_t nr = 1, rh = 0;
+    bool bad = false;
+    R[s0] = start;
+    orient[start] = has_s ? 2 : 1;              /* direction + 1 */
+    indeg[start] = 0;
+    W::fence();
+    while (rh < nr && !bad) {
+      const uint32_t u = W::uni(R[s0 + rh]);
+      ++rh;
+      const bool du = W::uni((uint32_t)orient[u]) == 2;
+      const uint32_t eb = W::uni(C.coff[u]), ee = W::uni(C.coff[u + 1]);
+      for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool arc = false, fresh = false, clash = false;
+        uint32_t v = 0, od = 0;
+        if (ce < ee) {
+          const uint32_t fl = C.cflags[ce];
+          arc = !gts_edge_is_marked(C.cstate[ce]) && ((fl & GTS_F_SENSE) != 0) == du;
+          if (arc) {
+            v = C.cend[ce];
+            od = gts_next_dir((uint8_t)fl) ? 2u : 1u;
+            const uint32_t ov = orient[v];
+            clash = v == u || v == start || gts_vertex_is_marked(C.vst[v]) ||
+                    (ov != 0 && ov != od);
+            fresh = ov == 0;
+          }
+        }
+        if (W::ballot(clash)) { bad = true; break; }
+        const uint64_t fm = W::ballot(arc && fresh);
+        if (arc) {
+          if (fresh) {
+            orient[v] = (uint8_t)od;
+            indeg[v] = 1;
+            R[s0 + nr + W::popc_below(fm, lane)] = v;
+          } else
+            indeg[v] = indeg[v] + 1;
+        }
+        nr += W::popc(fm);
+        W::fence();
+      }
+    }
+    /* pass 2: relaxation in topological order */
+    uint32_t nq = 1, qh2 = 0, processed = 0, nbest = 0, best_t = GTS_NONE;
+    uint64_t best_len = 0;
+    if (!bad) {
+      TQ[s0] = start;
+      C.plen[start] = (uint64_t)C.cseq[start];
+      W::fence();
+      while (qh2 < nq && !bad) {
+        const uint32_t u = W::uni(TQ[s0 + qh2]);
+        ++qh2; ++processed;
+        const bool du = W::uni((uint32_t)orient[u]) == 2;
+        const int64_t ndu = u == start ? 0 : W::uni64(C.nd[u]);
+        const uint64_t plu = (uint64_t)W::uni64((int64_t)C.plen[u]);
+        if (u != start && W::uni((uint32_t)C.tight[u]) != 1) { bad = true; break; }
+        const uint32_t eb = W::uni(C.coff[u]), ee = W::uni(C.coff[u + 1]);
+        bool us = false, ua = false;
+        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+          const uint32_t ce = base + lane;
+          bool live = false, sense = false, arc = false, ready = false;
+          uint32_t v = 0;
+          if (ce < ee) {
+            live = !gts_edge_is_marked(C.cstate[ce]);
+            sense = (C.cflags[ce] & GTS_F_SENSE) != 0;
+            arc = live && sense == du;
+            if (arc) {
+              v = C.cend[ce];
+              const int64_t w = C.cdist[ce];
+              const float cand = u == start ? (float)w : (float)(ndu + w);
+              const float old = C.distmap[v];
+              if (old == GTS_DIST_UNSET || old > cand) {
+                C.distmap[v] = cand;
+                C.edgemap[v] = ce;
+                C.nd[v] = u == start ? w : (int64_t)cand;
+                C.plen[v] = plu + (uint64_t)C.cseq[v];
+                C.tight[v] = 1;
+              } else if (old == cand) {
+                const uint8_t t = C.tight[v];
+                if (t < 255) C.tight[v] = t + 1;
+              }
+              const uint32_t d = indeg[v] - 1;
+              indeg[v] = d;
+              ready = d == 0;
+            }
+          }
+          us |= W::ballot(live && sense) != 0;
+          ua |= W::ballot(live && !sense) != 0;
+          const uint64_t rm = W::ballot(ready);
+          if (ready) TQ[s0 + nq + W::popc_below(rm, lane)] = v;
+          nq += W::popc(rm);
+          W::fence();
+        }
+        /* reached terminal (algorithms.c:694): candidate end of the walk */
+        if (u != start && !(us && ua)) {
+          if (plu > best_len) { best_len = plu; best_t = u; nbest = 1; }
+          else if (plu == best_len) ++nbest;
+        }
+      }
+      if (processed != nr) bad = true;                    /* cycle */
+      if (best_t != GTS_NONE && nbest != 1) bad = true;   /* length tie */
+    }
+    if (!bad && best_t != GTS_NONE && best_len > cc_len) {
+      uint32_t cv = best_t, n = 0;
+      while (cv != start) {
+        const uint32_t re = W::uni(C.edgemap[cv]);
+        C.cc_best[s0 + n++] = re;
+        cv = W::uni(C.cstart[re]);
+      }
+      cc_len = best_len;
+      cc_n = n;
+    }
+    /* restore the scratch */
+    for (uint32_t k = lane; k < nr; k += W::WIDTH) {
+      const uint32_t v = R[s0 + k];
+      orient[v] = 0;
+      C.distmap[v] = GTS_DIST_UNSET;
+      C.tight[v] = 0;
+    }
+    W::fence();
+    return !bad;
+  }
+
+  GTS_HD bool create_walk(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
+  {
+    const uint32_t gv = C.slot_v[start];
+    if (W::uni(C.G.row[gv + 1]) == W::uni(C.G.row[gv])) return true; /* :655 */
+    if (C.fast_walks && create_walk_fast(start, cc_len, cc_n)) { ++nfast; return true; }
+    ++nslow;
+    return create_walk_reference(start, cc_len, cc_n);
+  }
+
   /* ---- ref algorithms.c:767-868 (after its removecycles call) ---- */
   GTS_HD void makescaffold()
   {
     const uint32_t lane = W::lane();
     calc_cc();
+    for (uint32_t s = s0 + lane; s < s1; s += W::WIDTH) { C.st_dir[s] = 0; C.tight[s] = 0; }
+    W::fence();
     const uint32_t *ccoff = ccoffs();
     for (uint32_t i = 0; i < ncc && !err; ++i) {
       const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
@@ -498,7 +681,7 @@ struct GtsComponent {
          513-517, 550-553); makescaffold leaves VISITED or SCAFFOLD */
       C.G.vstate[C.slot_v[s]] = st;
     }
-    if (lane == 0) C.cerr[c] = err;
+    if (lane == 0) { C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow; }
     W::fence();
   }
 };

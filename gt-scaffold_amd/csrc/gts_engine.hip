@@ -61,6 +61,7 @@ struct GtsgEngine {
   uint32_t *d_scalars = nullptr;   /* 16 x u64 device scalars */
   /* options */
   int64_t walk_queue_factor = 8, max_walk_pops = 1ll << 32, hub_degree = 32;
+  int64_t fast_walks = 1;
   bool profile = false;
   /* profiling */
   struct Pending { const char *name; hipEvent_t a, b; };
@@ -656,6 +657,11 @@ __global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
   if (cerr[c] == GTS_CERR_WALKQ_OVERFLOW) atomicAdd(&out[0], 1u);
   else if (cerr[c] != 0) atomicAdd(&out[1], 1u);
 }
+__global__ void k_sum_u32(const uint32_t *a, uint32_t n, unsigned long long *out)
+{
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n && a[c]) atomicAdd(out, (unsigned long long)a[c]);
+}
 __global__ void k_max_u32_diff(const uint32_t *off, uint32_t n, uint32_t *out)
 {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -751,7 +757,7 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
     if (hipStreamCreate(&e->st) != hipSuccess) { delete e; return GTSG_EHIP; }
     e->own_stream = true;
   }
-  if (hipMalloc((void **)&e->d_scalars, 256) != hipSuccess) { delete e; return GTSG_ENOMEM; }
+  if (hipMalloc((void **)&e->d_scalars, 1024) != hipSuccess) { delete e; return GTSG_ENOMEM; }
   *out = e;
   return 0;
 }
@@ -788,6 +794,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   if (!strcmp(name, "walk_queue_factor") && value >= 1) e->walk_queue_factor = value;
   else if (!strcmp(name, "max_walk_pops") && value >= 1) e->max_walk_pops = value;
   else if (!strcmp(name, "hub_degree") && value >= 1) e->hub_degree = value;
+  else if (!strcmp(name, "fast_walks")) e->fast_walks = value != 0;
   else if (!strcmp(name, "profile")) e->profile = value != 0;
   else return fail(e, GTSG_EINVAL, "unknown option %s", name);
   return 0;
@@ -1042,7 +1049,7 @@ static int run_components(GtsgEngine *e, int mode)
                        (gts_sort_tmp_elems(n) + 2 * gts_scan_tmp_elems((uint64_t)n + m)) * 8 +
                        (size_t)n + m + (16u << 20);
     /* upper bounds for phase B: slots <= n, compact edges <= m */
-    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8) + (size_t)m * (4 * 3 + 8 + 2) +
+    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 32) + (size_t)m * (4 * 3 + 8 + 2) +
                        ((size_t)m * factor + 64ull * n) * 12 + (size_t)n * 24 + (16u << 20);
     if (!e->pool || e->pool_cap < wsA + wsB) {
       if ((rc = pool_reserve(e, wsA + wsB))) return rc;
@@ -1127,6 +1134,8 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(s_ccbest, uint32_t, nslots); PALLOC(s_stdir, uint8_t, nslots);
     PALLOC(s_distmap, float, nslots); PALLOC(s_ccoff, uint32_t, (size_t)nslots + ncomp + 1);
     PALLOC(cerr, uint32_t, ncomp);
+    PALLOC(s_nd, int64_t, nslots); PALLOC(s_plen, uint64_t, nslots); PALLOC(s_tight, uint8_t, nslots);
+    PALLOC(stat_fast, uint32_t, ncomp); PALLOC(stat_slow, uint32_t, ncomp);
     PALLOC(ok0, uint32_t, ncomp); PALLOC(ok1, uint32_t, ncomp);
     PALLOC(ov0, uint32_t, ncomp); PALLOC(ov1, uint32_t, ncomp);
     PALLOC(otmp, uint32_t, gts_sort_tmp_elems(ncomp));
@@ -1154,13 +1163,24 @@ static int run_components(GtsgEngine *e, int mode)
     C.wterm = s_wterm; C.touched = s_touched; C.cc_best = s_ccbest; C.st_dir = s_stdir;
     C.distmap = s_distmap; C.ccoff = s_ccoff; C.wq_off = wq_off; C.wq_edge = wq_edge;
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
+    C.fast_walks = (int)e->fast_walks; C.nd = s_nd; C.plen = s_plen; C.tight = s_tight;
+    C.stat_fast = stat_fast; C.stat_slow = stat_slow;
     LAUNCH(mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold" : "components_removecycles",
            k_components, ncomp, GTS_WAVE, C, order, mode);
     LAUNCH("comp_count_errors", k_count_errors, nblk(ncomp), GTS_BLOCK, cerr, ncomp,
            e->d_scalars + 12);
+    HIPCHK(hipMemsetAsync(e->d_scalars + 16, 0, 16, e->st));
+    LAUNCH("comp_walk_stats", k_sum_u32, nblk(ncomp), GTS_BLOCK, stat_fast, ncomp,
+           (unsigned long long *)(e->d_scalars + 16));
+    LAUNCH("comp_walk_stats", k_sum_u32, nblk(ncomp), GTS_BLOCK, stat_slow, ncomp,
+           (unsigned long long *)(e->d_scalars + 18));
     uint32_t res[3] = {0, 0, 0};
+    uint64_t wstat[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 12, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 16, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
+    e->stats["fast_walks"] = (int64_t)wstat[0];
+    e->stats["slow_walks"] = (int64_t)wstat[1];
     e->stats["components"] = ncomp;
     e->stats["max_component"] = res[2];
     e->stats["compact_edges"] = nce;

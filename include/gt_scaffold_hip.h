@@ -103,7 +103,9 @@ int gtsg_selftest_ambiguous(GtsgEngine *e, uint64_t n, const int64_t *d1,
 /* tuning */
 int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
 /*   "walk_queue_factor" (default 8), "max_walk_pops" (default 2^32),
-     "hub_degree" (default 32), "profile" (0/1) */
+     "hub_degree" (default 32), "profile" (0/1),
+     "fast_walks" (default 1; 0 forces the reference's label-correcting search
+     for every walk) */
 
 /* per-kernel timing collected with hipEvents on the engine's stream while
    option "profile" is 1.  Fills up to cap entries, returns the number of
@@ -117,7 +119,7 @@ int gtsg_get_kernel_times(GtsgEngine *e, GtsgKernelTime *out, int cap);
 void gtsg_reset_kernel_times(GtsgEngine *e);
 /* counters of the last calls: "filter_rounds_p", "filter_rounds_i",
    "components", "max_component", "slots", "compact_edges", "hubs",
-   "walk_retries" */
+   "walk_retries", "fast_walks", "slow_walks" */
 int64_t gtsg_get_stat(const GtsgEngine *e, const char *name);
 
 #ifdef __cplusplus

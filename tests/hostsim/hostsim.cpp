@@ -128,7 +128,8 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
                        const uint8_t *flags, uint8_t *state,
                        const uint32_t *twin, int mode, uint32_t wq_factor,
                        uint64_t max_pops, uint32_t *out_ncomp,
-                       uint32_t *out_maxcomp)
+                       uint32_t *out_maxcomp, int fast_walks,
+                       uint64_t *out_fast, uint64_t *out_slow)
 {
   GtsGraphView G = {n, m, row, seq_len, nullptr, nullptr, vstate, end, dist,
                     nullptr, flags, state, twin, nullptr};
@@ -220,12 +221,20 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   C.st_dir = st_dir.data(); C.distmap = distmap.data(); C.ccoff = ccoff.data();
   C.wq_off = wq_off.data(); C.wq_edge = wq_edge.data(); C.wq_dist = wq_dist.data();
   C.cerr = cerr.data(); C.max_pops = max_pops;
+  std::vector<int64_t> nd(S); std::vector<uint64_t> plen(S); std::vector<uint8_t> tight(S, 0);
+  std::vector<uint32_t> sf(ncomp ? ncomp : 1, 0), ss(ncomp ? ncomp : 1, 0);
+  C.fast_walks = fast_walks; C.nd = nd.data(); C.plen = plen.data(); C.tight = tight.data();
+  C.stat_fast = sf.data(); C.stat_slow = ss.data();
   uint32_t nerr = 0;
   for (uint32_t c = 0; c < ncomp; c++) {
     GtsComponent<GtsWave1> prog(C, c);
     prog.run(mode);
     if (cerr[c]) nerr++;
   }
+  uint64_t tf = 0, ts = 0;
+  for (uint32_t c = 0; c < ncomp; c++) { tf += sf[c]; ts += ss[c]; }
+  if (out_fast) *out_fast = tf;
+  if (out_slow) *out_slow = ts;
   if (out_ncomp) *out_ncomp = ncomp;
   if (out_maxcomp) *out_maxcomp = maxcomp;
   return nerr;

@@ -99,8 +99,21 @@ def test_hub_vertices_take_the_wave_path():
 
 def test_walk_queue_retry():
     g = make_inputs(20000, 5)
-    eng, _ = run_pipeline(g, walk_queue_factor=1)
+    eng, _ = run_pipeline(g, walk_queue_factor=1, fast_walks=0)
     assert eng.stat("walk_retries") >= 1
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_reference_search_for_every_walk(seed):
+    g = make_inputs(5000, 60 + seed, p_chimeric=0.05)
+    eng, _ = run_pipeline(g, fast_walks=0)
+    assert eng.stat("fast_walks") == 0 and eng.stat("slow_walks") > 0
+
+
+def test_fast_walks_fall_back_on_ties():
+    g = make_inputs(3000, 21, dist_range_small=True, contig_median=300)
+    eng, _ = run_pipeline(g)
+    assert eng.stat("fast_walks") > 0 and eng.stat("slow_walks") > 0
 
 
 def test_empty_and_ragged_inputs():

@@ -71,3 +71,22 @@ def test_medium():
     out, hs = run_both(g)
     check(out)
     assert hs.ncomp > 100
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+def test_walk_paths_agree(fast):
+    # fast = 1: linear-time walks with fall-back; fast = 0: the reference's search
+    for seed, kw in [(31, {}), (32, dict(dist_range_small=True, contig_median=300)),
+                     (33, dict(p_chimeric=0.2))]:
+        g = make_inputs(2500, seed, **kw)
+        og = oracle_from_inputs(g)
+        hs = HostSimGraph(csr_from_oracle(og))
+        og.mark_repeats(); hs.mark_repeats(); og.filter(); hs.filter()
+        og.makescaffold(True)
+        assert hs.makescaffold(fast_walks=fast) == 0
+        assert np.array_equal(og.vertex_states(), hs.vertex_states())
+        assert np.array_equal(og.edge_states(), hs.edge_states())
+        if fast:
+            assert hs.fast_walks > 0
+        else:
+            assert hs.fast_walks == 0 and hs.slow_walks > 0
