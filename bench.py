@@ -174,6 +174,12 @@ def main():
                                max_component=eng.stat("max_component"),
                                parallelism="components sharded, %d GPU(s)" % world),
                    roofline=roof,
+                   component_kernel=dict(
+                       walks_fast=eng.stat("fast_walks"), walks_reference=eng.stat("slow_walks"),
+                       **{k: eng.stat(k) for k in
+                          ("us_sum_removecycles", "us_max_removecycles", "us_sum_makescaffold_other",
+                           "us_max_makescaffold_other", "us_sum_walks_fast", "us_max_walks_fast",
+                           "us_sum_walks_reference", "us_max_walks_reference")}),
                    kernels_ms_per_step={k: round(v[1] / args.steps, 3) for k, v in
                                         sorted(kt.items(), key=lambda kv: -kv[1][1])[:12]})
         if not args.no_cpu_baseline:

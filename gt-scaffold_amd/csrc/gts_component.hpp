@@ -73,6 +73,8 @@ struct GtsCompView {
   uint64_t *plen;            /* slot -> contig length of the tree path */
   uint8_t *tight;            /* slot -> number of tight in-arcs (saturating) */
   uint32_t *stat_fast, *stat_slow;  /* per component: walks by path taken */
+  uint64_t *tstat;           /* per component x4: ticks in removecycles, makescaffold
+                                outside walks, fast walks, reference walks */
 };
 
 /* (float)GT_WORD_MAX, ref algorithms.c:650 */
@@ -88,11 +90,12 @@ struct GtsComponent {
   uint64_t qbase, qcap, qh, qn;
   uint32_t ntouch;
   uint32_t nfast, nslow;
+  uint64_t tfast, tslow;
 
   GTS_HD GtsComponent(const GtsCompView &cv, uint32_t comp)
       : C(cv), c(comp), s0(cv.comp_off[comp]), s1(cv.comp_off[comp + 1]),
         nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0), ntouch(0),
-        nfast(0), nslow(0) {}
+        nfast(0), nslow(0), tfast(0), tslow(0) {}
 
   GTS_HD uint32_t *ccoffs() const { return C.ccoff + s0 + c; }
 
@@ -617,9 +620,16 @@ struct GtsComponent {
   {
     const uint32_t gv = C.slot_v[start];
     if (W::uni(C.G.row[gv + 1]) == W::uni(C.G.row[gv])) return true; /* :655 */
-    if (C.fast_walks && create_walk_fast(start, cc_len, cc_n)) { ++nfast; return true; }
+    const uint64_t t0 = W::clock();
+    if (C.fast_walks && create_walk_fast(start, cc_len, cc_n)) {
+      ++nfast; tfast += W::clock() - t0; return true;
+    }
+    const uint64_t t1 = W::clock();
+    tfast += t1 - t0;
     ++nslow;
-    return create_walk_reference(start, cc_len, cc_n);
+    const bool ok = create_walk_reference(start, cc_len, cc_n);
+    tslow += W::clock() - t1;
+    return ok;
   }
 
   /* ---- ref algorithms.c:767-868 (after its removecycles call) ---- */
@@ -673,15 +683,24 @@ struct GtsComponent {
   GTS_HD void run(int mode)
   {
     const uint32_t lane = W::lane();
+    const uint64_t t0 = W::clock();
     removecycles();
+    const uint64_t t1 = W::clock();
     if (mode == GTS_MODE_MAKESCAFFOLD) makescaffold();
+    const uint64_t t2 = W::clock();
     for (uint32_t s = s0 + lane; s < s1; s += W::WIDTH) {
       const uint8_t st = C.vst[s];
       /* removecycles leaves every unmarked vertex UNVISITED (algorithms.c:
          513-517, 550-553); makescaffold leaves VISITED or SCAFFOLD */
       C.G.vstate[C.slot_v[s]] = st;
     }
-    if (lane == 0) { C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow; }
+    if (lane == 0) {
+      C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow;
+      C.tstat[4 * (uint64_t)c] = t1 - t0;
+      C.tstat[4 * (uint64_t)c + 1] = t2 - t1 - tfast - tslow;
+      C.tstat[4 * (uint64_t)c + 2] = tfast;
+      C.tstat[4 * (uint64_t)c + 3] = tslow;
+    }
     W::fence();
   }
 };
@@ -700,6 +719,7 @@ struct GtsWave1 {
   static GTS_HD uint32_t uni(uint32_t v) { return v; }
   static GTS_HD int64_t uni64(int64_t v) { return v; }
   static GTS_HD void fence() {}
+  static GTS_HD uint64_t clock() { return 0; }
 };
 
 #endif

@@ -629,6 +629,8 @@ struct GtsWave64 {
   }
   static __device__ __forceinline__ void fence()
   { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+  /* constant 100 MHz counter (s_memrealtime) */
+  static __device__ __forceinline__ uint64_t clock() { return wall_clock64(); }
 };
 
 /* one wavefront per component; `order` lists components largest first */
@@ -656,6 +658,16 @@ __global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
   if (c >= ncomp) return;
   if (cerr[c] == GTS_CERR_WALKQ_OVERFLOW) atomicAdd(&out[0], 1u);
   else if (cerr[c] != 0) atomicAdd(&out[1], 1u);
+}
+/* out[k] = sum, out[4+k] = max of column k of the per-component tick table */
+__global__ void k_tstat_reduce(const uint64_t *t, uint32_t ncomp, unsigned long long *out)
+{
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncomp) return;
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long v = t[4 * c + k];
+    if (v) { atomicAdd(&out[k], v); atomicMax(&out[4 + k], v); }
+  }
 }
 __global__ void k_sum_u32(const uint32_t *a, uint32_t n, unsigned long long *out)
 {
@@ -1049,7 +1061,7 @@ static int run_components(GtsgEngine *e, int mode)
                        (gts_sort_tmp_elems(n) + 2 * gts_scan_tmp_elems((uint64_t)n + m)) * 8 +
                        (size_t)n + m + (16u << 20);
     /* upper bounds for phase B: slots <= n, compact edges <= m */
-    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 32) + (size_t)m * (4 * 3 + 8 + 2) +
+    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64) + (size_t)m * (4 * 3 + 8 + 2) +
                        ((size_t)m * factor + 64ull * n) * 12 + (size_t)n * 24 + (16u << 20);
     if (!e->pool || e->pool_cap < wsA + wsB) {
       if ((rc = pool_reserve(e, wsA + wsB))) return rc;
@@ -1136,6 +1148,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cerr, uint32_t, ncomp);
     PALLOC(s_nd, int64_t, nslots); PALLOC(s_plen, uint64_t, nslots); PALLOC(s_tight, uint8_t, nslots);
     PALLOC(stat_fast, uint32_t, ncomp); PALLOC(stat_slow, uint32_t, ncomp);
+    PALLOC(tstat, uint64_t, 4 * (size_t)ncomp);
     PALLOC(ok0, uint32_t, ncomp); PALLOC(ok1, uint32_t, ncomp);
     PALLOC(ov0, uint32_t, ncomp); PALLOC(ov1, uint32_t, ncomp);
     PALLOC(otmp, uint32_t, gts_sort_tmp_elems(ncomp));
@@ -1164,7 +1177,7 @@ static int run_components(GtsgEngine *e, int mode)
     C.distmap = s_distmap; C.ccoff = s_ccoff; C.wq_off = wq_off; C.wq_edge = wq_edge;
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
     C.fast_walks = (int)e->fast_walks; C.nd = s_nd; C.plen = s_plen; C.tight = s_tight;
-    C.stat_fast = stat_fast; C.stat_slow = stat_slow;
+    C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat;
     LAUNCH(mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold" : "components_removecycles",
            k_components, ncomp, GTS_WAVE, C, order, mode);
     LAUNCH("comp_count_errors", k_count_errors, nblk(ncomp), GTS_BLOCK, cerr, ncomp,
@@ -1174,11 +1187,23 @@ static int run_components(GtsgEngine *e, int mode)
            (unsigned long long *)(e->d_scalars + 16));
     LAUNCH("comp_walk_stats", k_sum_u32, nblk(ncomp), GTS_BLOCK, stat_slow, ncomp,
            (unsigned long long *)(e->d_scalars + 18));
+    HIPCHK(hipMemsetAsync(e->d_scalars + 32, 0, 64, e->st));
+    LAUNCH("comp_walk_stats", k_tstat_reduce, nblk(ncomp), GTS_BLOCK, tstat, ncomp,
+           (unsigned long long *)(e->d_scalars + 32));
+    uint64_t ts[8];
+    HIPCHK(hipMemcpyAsync(ts, e->d_scalars + 32, 64, hipMemcpyDeviceToHost, e->st));
     uint32_t res[3] = {0, 0, 0};
     uint64_t wstat[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 12, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 16, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
+    {
+      static const char *nm[4] = {"removecycles", "makescaffold_other", "walks_fast", "walks_reference"};
+      for (int k = 0; k < 4; ++k) {   /* 100 MHz ticks -> microseconds */
+        e->stats[std::string("us_sum_") + nm[k]] = (int64_t)(ts[k] / 100);
+        e->stats[std::string("us_max_") + nm[k]] = (int64_t)(ts[4 + k] / 100);
+      }
+    }
     e->stats["fast_walks"] = (int64_t)wstat[0];
     e->stats["slow_walks"] = (int64_t)wstat[1];
     e->stats["components"] = ncomp;
