@@ -1,1 +1,718 @@
-/* placeholder, replaced below */
+/*
+  gt_scaffolder_host.c -- C host layer: the reference's public API
+  (include/gt_scaffolder_host.h) on top of the GPU engine
+  (include/gt_scaffold_hip.h).
+
+  Host work: parsing contigs (.fa), distance estimates (.de) and A-statistics
+  (.astat) into flat record arrays, writing .dot / .scaf, and the scaffold
+  record walk.  Everything between -- edge construction, repeat marking,
+  filtering, cycle removal, scaffold construction -- is a call into the engine.
+  There is no host implementation of those steps.
+*/
+#define _GNU_SOURCE
+#include "gt_scaffolder_host.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gt_scaffold_hip.h"
+
+#define LINE_MAX_REF 1023 /* the reference reads lines with fgets(line, 1024) */
+
+static int g_device = 0;
+void gt_scaffolder_set_device(int device) { g_device = device; }
+
+typedef struct {
+  char *name;
+  uint64_t seq_len;
+  float astat, copy_num;
+} Contig;
+
+typedef struct {   /* hand-built or downloaded edge, id order */
+  uint32_t start, end;
+  int64_t dist;
+  float std_dev;
+  int64_t num_pairs;
+  uint8_t flags;
+} HEdge;
+
+struct GtScaffolderGraph {
+  Contig *ctg;
+  uint64_t nof_vertices, max_nof_vertices;
+  HEdge *edges;              /* host copy (hand-built, or cached download) */
+  uint64_t nof_edges, max_nof_edges;
+  bool edges_cached;
+  uint8_t *vstate, *estate;  /* host copies, refreshed from the engine */
+  GtsgEngine *eng;           /* NULL for hand-built graphs */
+  char err[512];
+};
+
+struct GtScaffolderGraphRecords {
+  const GtScaffolderGraph *g;
+  uint64_t n, cap;
+  uint64_t *root;
+  uint64_t *off;             /* n+1 offsets into edge */
+  uint64_t *edge, nedge, capedge;
+};
+
+static int seterr(char *err, size_t n, const char *fmt, ...)
+{
+  if (err && n) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err, n, fmt, ap);
+    va_end(ap);
+  }
+  return -1;
+}
+
+static void *xcalloc(size_t n, size_t sz)
+{
+  void *p = calloc(n ? n : 1, sz);
+  if (!p) { fprintf(stderr, "gt_scaffolder: out of memory\n"); abort(); }
+  return p;
+}
+static void *xrealloc(void *q, size_t sz)
+{
+  void *p = realloc(q, sz ? sz : 1);
+  if (!p) { fprintf(stderr, "gt_scaffolder: out of memory\n"); abort(); }
+  return p;
+}
+
+/* whole file into memory, NUL-terminated */
+static char *slurp(const char *path, size_t *len)
+{
+  FILE *f = fopen(path, "rb");
+  char *buf;
+  long sz;
+  if (!f) return NULL;
+  if (fseek(f, 0, SEEK_END) != 0 || (sz = ftell(f)) < 0) { fclose(f); return NULL; }
+  rewind(f);
+  buf = malloc((size_t)sz + 1);
+  if (!buf || fread(buf, 1, (size_t)sz, f) != (size_t)sz) { free(buf); fclose(f); return NULL; }
+  buf[sz] = '\0';
+  fclose(f);
+  *len = (size_t)sz;
+  return buf;
+}
+
+/* ------------------------------------------------------------------ */
+GtScaffolderGraph *gt_scaffolder_graph_new(uint64_t max_v, uint64_t max_e)
+{
+  GtScaffolderGraph *g = xcalloc(1, sizeof *g);
+  g->max_nof_vertices = max_v;
+  g->max_nof_edges = max_e;
+  g->ctg = xcalloc(max_v, sizeof *g->ctg);
+  g->edges = xcalloc(max_e, sizeof *g->edges);
+  g->vstate = xcalloc(max_v, 1);
+  g->estate = xcalloc(max_e, 1);
+  return g;
+}
+
+void gt_scaffolder_graph_delete(GtScaffolderGraph *g)
+{
+  uint64_t i;
+  if (!g) return;
+  for (i = 0; i < g->nof_vertices; i++) free(g->ctg[i].name);
+  free(g->ctg); free(g->edges); free(g->vstate); free(g->estate);
+  if (g->eng) gtsg_destroy(g->eng);
+  free(g);
+}
+
+int gt_scaffolder_graph_add_vertex(GtScaffolderGraph *g, const char *header,
+                                   uint64_t seq_len, float astat, float copy_num)
+{
+  Contig *c;
+  if (!g || g->nof_vertices >= g->max_nof_vertices) return -1;
+  c = g->ctg + g->nof_vertices;
+  c->name = strdup(header ? header : "");
+  c->seq_len = seq_len; c->astat = astat; c->copy_num = copy_num;
+  g->vstate[g->nof_vertices++] = 0;
+  return 0;
+}
+
+int gt_scaffolder_graph_add_edge(GtScaffolderGraph *g, uint64_t vstart,
+                                 uint64_t vend, int64_t dist, float std_dev,
+                                 uint64_t num_pairs, bool dir, bool same)
+{
+  HEdge *e;
+  if (!g || g->eng || g->nof_edges >= g->max_nof_edges ||
+      vstart >= g->nof_vertices || vend >= g->nof_vertices)
+    return -1;
+  e = g->edges + g->nof_edges;
+  e->start = (uint32_t)vstart; e->end = (uint32_t)vend; e->dist = dist;
+  e->std_dev = std_dev; e->num_pairs = (int64_t)num_pairs;
+  e->flags = (uint8_t)((dir ? 1 : 0) | (same ? 2 : 0));
+  g->estate[g->nof_edges++] = 0;
+  g->edges_cached = true;
+  return 0;
+}
+
+uint64_t gt_scaffolder_graph_nof_vertices(const GtScaffolderGraph *g) { return g ? g->nof_vertices : 0; }
+uint64_t gt_scaffolder_graph_nof_edges(const GtScaffolderGraph *g) { return g ? g->nof_edges : 0; }
+const char *gt_scaffolder_graph_last_error(const GtScaffolderGraph *g) { return g ? g->err : ""; }
+
+/* ------------------------------------------------------------------ */
+/* contigs                                                             */
+
+static int contig_cmp(const void *a, const void *b)
+{
+  return strcmp(((const Contig *)a)->name, ((const Contig *)b)->name);
+}
+
+static bool find_contig(const GtScaffolderGraph *g, const char *name, uint32_t *id)
+{
+  uint64_t lo = 0, hi = g->nof_vertices;
+  while (lo < hi) {
+    uint64_t mid = lo + (hi - lo) / 2;
+    int c = strcmp(g->ctg[mid].name, name);
+    if (c == 0) { *id = (uint32_t)mid; return true; }
+    if (c < 0) lo = mid + 1; else hi = mid;
+  }
+  return false;
+}
+
+/* FASTA: '>' description newline, then sequence characters up to the next
+   '>' (blanks and line ends do not count).  Keeps contigs longer than
+   min_ctg_len (ref parser.c:481), header cut at the first blank (parser.c:
+   452-458), optional "length= depth= k= astat=" annotation (parser.c:438-450). */
+static int read_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len,
+                        bool annotated, char *err, size_t errlen)
+{
+  size_t len, i = 0;
+  char *buf = slurp(path, &len);
+  uint64_t cap = 0;
+  if (!buf) return seterr(err, errlen, "cannot open file %s", path);
+  if (len == 0) { free(buf); return seterr(err, errlen, "sequence file %s is empty", path); }
+  if (buf[0] != '>') {
+    free(buf);
+    return seterr(err, errlen, "the first character of fasta file %s has to be '>'", path);
+  }
+  while (i < len && buf[i] == '>') {
+    size_t ds = ++i, de;
+    uint64_t slen = 0;
+    float astat = 0.0f, copynum = 0.0f;
+    while (i < len && buf[i] != '\n') i++;
+    de = i;
+    if (de > ds && buf[de - 1] == '\r') de--;
+    if (i < len) i++;
+    while (i < len && buf[i] != '>') {
+      char c = buf[i++];
+      if (c != '\n' && c != '\r' && c != ' ') slen++;
+    }
+    {
+      char save = buf[de];
+      char *desc = buf + ds, *sp;
+      buf[de] = '\0';
+      if (annotated) {
+        char part[1024];
+        long n1, n2;
+        if (sscanf(desc, "%1023s length=%ld depth=%ld k=%f astat=%f", part, &n1, &n2,
+                   &copynum, &astat) != 5) {
+          free(buf);
+          return seterr(err, errlen, "No A-statistic/copy number was found in header");
+        }
+      }
+      if (de == ds) { free(buf); return seterr(err, errlen, "Invalid header length"); }
+      if (slen == 0) { free(buf); return seterr(err, errlen, "Invalid sequence length"); }
+      sp = strchr(desc, ' ');
+      if (sp) *sp = '\0';
+      if (slen > min_len) {
+        if (g->nof_vertices == cap) {
+          cap = cap ? 2 * cap : 1024;
+          g->ctg = xrealloc(g->ctg, cap * sizeof *g->ctg);
+        }
+        g->ctg[g->nof_vertices].name = strdup(desc);
+        g->ctg[g->nof_vertices].seq_len = slen;
+        g->ctg[g->nof_vertices].astat = astat;
+        g->ctg[g->nof_vertices].copy_num = copynum;
+        g->nof_vertices++;
+      }
+      if (sp) *sp = ' ';
+      buf[de] = save;
+    }
+  }
+  free(buf);
+  g->max_nof_vertices = g->nof_vertices;
+  /* vertex ids = rank of the header, ref parser.c:172 */
+  qsort(g->ctg, g->nof_vertices, sizeof *g->ctg, contig_cmp);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* distance estimates                                                  */
+
+typedef struct {
+  uint32_t *root, *ctg;
+  int64_t *dist, *np;
+  float *sd;
+  uint8_t *flags;
+  uint64_t n, cap;
+} Records;
+
+static void rec_push(Records *r, uint32_t root, uint32_t ctg, int64_t dist,
+                     int64_t np, float sd, uint8_t flags)
+{
+  if (r->n == r->cap) {
+    r->cap = r->cap ? 2 * r->cap : 4096;
+    r->root = xrealloc(r->root, r->cap * sizeof *r->root);
+    r->ctg = xrealloc(r->ctg, r->cap * sizeof *r->ctg);
+    r->dist = xrealloc(r->dist, r->cap * sizeof *r->dist);
+    r->np = xrealloc(r->np, r->cap * sizeof *r->np);
+    r->sd = xrealloc(r->sd, r->cap * sizeof *r->sd);
+    r->flags = xrealloc(r->flags, r->cap);
+  }
+  r->root[r->n] = root; r->ctg[r->n] = ctg; r->dist[r->n] = dist;
+  r->np[r->n] = np; r->sd[r->n] = sd; r->flags[r->n] = flags;
+  r->n++;
+}
+static void rec_free(Records *r)
+{
+  free(r->root); free(r->ctg); free(r->dist); free(r->np); free(r->sd); free(r->flags);
+}
+
+/* one "header{+,-},dist,pairs,std" record as the reference scans it with
+   "%[^>,],%ld,%ld,%f" (ref parser.c:212, :340) */
+static bool scan_record(const char *field, char *hdr, long *dist, long *np, float *sd)
+{
+  return sscanf(field, "%1023[^>,],%ld,%ld,%f", hdr, dist, np, sd) == 4;
+}
+
+/* Both passes of the reference over the .de file: the integrity check of
+   parser.c:150-291 (its error messages and conditions) and the record loop of
+   parser.c:295-394, which drops the last character of every line and flips
+   the direction at ';'.  Lines the reference's 1024-byte fgets buffer would
+   split are rejected instead of being mis-parsed. */
+static int read_distance_records(const GtScaffolderGraph *g, const char *path,
+                                 Records *out, char *err, size_t errlen)
+{
+  size_t len, pos;
+  char *buf = slurp(path, &len), *line = NULL, hdr[1024];
+  size_t linecap = 0;
+  uint64_t valid_records = 0;
+  int pass;
+  if (!buf) return seterr(err, errlen, "can not read distance file %s", path);
+  for (pass = 0; pass < 2; pass++) {
+    pos = 0;
+    while (pos < len) {
+      size_t ls = pos, ll;
+      char *save = NULL, *field;
+      uint32_t root = 0, ctg = 0;
+      bool valid, sense = true;
+      long dist, np;
+      float sd;
+      while (pos < len && buf[pos] != '\n') pos++;
+      if (pos < len) pos++;               /* the line keeps its newline, as fgets */
+      ll = pos - ls;
+      if (ll > LINE_MAX_REF) {
+        free(buf); free(line);
+        return seterr(err, errlen, "line longer than %d characters in dist file %s "
+                      "(the reference's line buffer would split it)", LINE_MAX_REF, path);
+      }
+      if (ll + 1 > linecap) { linecap = ll + 64; line = xrealloc(line, linecap); }
+      memcpy(line, buf + ls, ll);
+      line[ll] = '\0';
+      if (pass == 1) line[ll - 1] = '\0';  /* parser.c:325 */
+      field = strtok_r(line, " ", &save);
+      valid = field && find_contig(g, field, &root);
+      if (pass == 0) {
+        field = strtok_r(NULL, " ", &save);
+        if (!field) {
+          free(buf); free(line);
+          return seterr(err, errlen, "Invalid record in dist file %s", path);
+        }
+        if (!valid) continue;
+        for (; field; field = strtok_r(NULL, " ", &save)) {
+          if (scan_record(field, hdr, &dist, &np, &sd)) {
+            size_t hl = strlen(hdr);
+            if (np < 0) {
+              free(buf); free(line);
+              return seterr(err, errlen, "Invalid value for number of pairs in dist file %s", path);
+            }
+            if (hdr[hl - 1] != '+' && hdr[hl - 1] != '-') {
+              free(buf); free(line);
+              return seterr(err, errlen, "Invalid composition sign in dist file %s", path);
+            }
+            hdr[hl - 1] = '\0';
+            if (find_contig(g, hdr, &ctg)) valid_records++;
+          } else if (*field != ';') {
+            free(buf); free(line);
+            return seterr(err, errlen, "Invalid record in dist file %s", path);
+          }
+        }
+      } else {
+        if (!valid) continue;
+        for (; field; field = strtok_r(NULL, " ", &save)) {
+          if (scan_record(field, hdr, &dist, &np, &sd)) {
+            size_t hl = strlen(hdr);
+            bool same = hdr[hl - 1] == '+';
+            hdr[hl - 1] = '\0';
+            if (find_contig(g, hdr, &ctg))
+              rec_push(out, root, ctg, dist, np, sd,
+                       (uint8_t)((sense ? 1 : 0) | (same ? 2 : 0)));
+          } else if (*field == ';')
+            sense = !sense;
+        }
+      }
+    }
+    if (pass == 0 && valid_records == 0) {
+      free(buf); free(line);
+      return seterr(err, errlen, "distance file %s is empty", path);
+    }
+  }
+  free(buf); free(line);
+  return 0;
+}
+
+static int engine_err(GtScaffolderGraph *g, int rc, char *err, size_t errlen)
+{
+  if (rc == 0) return 0;
+  snprintf(g->err, sizeof g->err, "%s", g->eng ? gtsg_last_error(g->eng) : "no engine");
+  seterr(err, errlen, "%s", g->err);
+  return -1;
+}
+
+int gt_scaffolder_graph_new_from_file(GtScaffolderGraph **out, const char *ctg_filename,
+                                      uint64_t min_ctg_len, const char *dist_filename,
+                                      bool astat_is_annotated, char *err, size_t errlen)
+{
+  GtScaffolderGraph *g = xcalloc(1, sizeof *g);
+  Records r;
+  int64_t *seq;
+  float *as, *cn;
+  uint64_t i;
+  int rc;
+  memset(&r, 0, sizeof r);
+  *out = NULL;
+  rc = read_contigs(g, ctg_filename, min_ctg_len, astat_is_annotated, err, errlen);
+  if (!rc) rc = read_distance_records(g, dist_filename, &r, err, errlen);
+  if (rc) { rec_free(&r); gt_scaffolder_graph_delete(g); return -1; }
+  if (gtsg_create(&g->eng, g_device, NULL) != 0) {
+    rec_free(&r); gt_scaffolder_graph_delete(g);
+    return seterr(err, errlen, "no MI355X available: the scaffolder engine has no CPU path");
+  }
+  seq = xcalloc(g->nof_vertices, sizeof *seq);
+  as = xcalloc(g->nof_vertices, sizeof *as);
+  cn = xcalloc(g->nof_vertices, sizeof *cn);
+  for (i = 0; i < g->nof_vertices; i++) {
+    seq[i] = (int64_t)g->ctg[i].seq_len; as[i] = g->ctg[i].astat; cn[i] = g->ctg[i].copy_num;
+  }
+  rc = gtsg_set_contigs(g->eng, g->nof_vertices, seq, as, cn, 0);
+  if (!rc)
+    rc = gtsg_build_from_records(g->eng, r.n, r.root, r.ctg, r.dist, r.sd, r.np, r.flags, 0);
+  free(seq); free(as); free(cn); rec_free(&r);
+  if (rc) { engine_err(g, rc, err, errlen); gt_scaffolder_graph_delete(g); return -1; }
+  g->nof_edges = g->max_nof_edges = gtsg_num_edges(g->eng);
+  g->vstate = xcalloc(g->nof_vertices, 1);
+  g->estate = xcalloc(g->nof_edges, 1);
+  g->edges = xcalloc(g->nof_edges, sizeof *g->edges);
+  *out = g;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* algorithms: thin calls into the engine                              */
+
+int gt_scaffolder_graph_mark_repeats(const char *filename, GtScaffolderGraph *g,
+                                     float copy_num_cutoff, float astat_cutoff,
+                                     char *err, size_t errlen)
+{
+  bool have_file = filename && strlen(filename) != 0;
+  if (!g || !g->eng) return seterr(err, errlen, "graph is not on the GPU");
+  if (have_file) {
+    /* ref algorithms.c:108-153: one record per line, six tab separated fields */
+    size_t len, pos = 0;
+    char *buf = slurp(filename, &len), hdr[1025], line[1025];
+    float *as, *cn;
+    uint64_t i;
+    int rc;
+    if (!buf) return seterr(err, errlen, "can not read A-statistic file %s", filename);
+    while (pos < len) {
+      size_t ls = pos, ll;
+      long n1, n2, n3;
+      float copy_num = 0.0f, astat = 0.0f;
+      uint32_t id;
+      while (pos < len && buf[pos] != '\n') pos++;
+      if (pos < len) pos++;
+      ll = pos - ls;
+      if (ll > LINE_MAX_REF) {
+        free(buf);
+        return seterr(err, errlen, "line longer than %d characters in A-statistic file %s",
+                      LINE_MAX_REF, filename);
+      }
+      memcpy(line, buf + ls, ll);
+      line[ll - 1] = '\0';                 /* algorithms.c:121 */
+      if (sscanf(line, "%1024s\t%ld\t%ld\t%ld\t%f\t%f", hdr, &n1, &n2, &n3, &copy_num,
+                 &astat) != 6) {
+        free(buf);
+        return seterr(err, errlen, "Invalid record in A-statistic file %s", filename);
+      }
+      if (find_contig(g, hdr, &id)) { g->ctg[id].astat = astat; g->ctg[id].copy_num = copy_num; }
+    }
+    free(buf);
+    as = xcalloc(g->nof_vertices, sizeof *as);
+    cn = xcalloc(g->nof_vertices, sizeof *cn);
+    for (i = 0; i < g->nof_vertices; i++) { as[i] = g->ctg[i].astat; cn[i] = g->ctg[i].copy_num; }
+    rc = gtsg_set_astat(g->eng, as, cn, 0);
+    free(as); free(cn);
+    if (rc) return engine_err(g, rc, err, errlen);
+  }
+  return engine_err(g, gtsg_mark_repeats(g->eng, have_file, copy_num_cutoff, astat_cutoff),
+                    err, errlen);
+}
+
+int gt_scaffolder_graph_filter(GtScaffolderGraph *g, float pcutoff, float cncutoff,
+                               int64_t ocutoff)
+{
+  if (!g || !g->eng) return -1;
+  return engine_err(g, gtsg_filter(g->eng, pcutoff, cncutoff, ocutoff), NULL, 0);
+}
+int gt_scaffolder_removecycles(GtScaffolderGraph *g)
+{
+  if (!g || !g->eng) return -1;
+  return engine_err(g, gtsg_removecycles(g->eng), NULL, 0);
+}
+int gt_scaffolder_makescaffold(GtScaffolderGraph *g)
+{
+  if (!g || !g->eng) return -1;
+  return engine_err(g, gtsg_makescaffold(g->eng), NULL, 0);
+}
+
+/* ------------------------------------------------------------------ */
+/* output                                                              */
+
+static int refresh(GtScaffolderGraph *g)
+{
+  int rc = 0;
+  if (!g->eng) return 0;
+  if (!g->edges_cached && g->nof_edges) {
+    uint64_t m = g->nof_edges, i;
+    uint32_t *s = xcalloc(m, 4), *e = xcalloc(m, 4);
+    int64_t *d = xcalloc(m, 8), *np = xcalloc(m, 8);
+    float *sd = xcalloc(m, 4);
+    uint8_t *fl = xcalloc(m, 1);
+    rc = gtsg_get_edges(g->eng, s, e, d, sd, np, fl);
+    for (i = 0; i < m && !rc; i++) {
+      g->edges[i].start = s[i]; g->edges[i].end = e[i]; g->edges[i].dist = d[i];
+      g->edges[i].std_dev = sd[i]; g->edges[i].num_pairs = np[i]; g->edges[i].flags = fl[i];
+    }
+    free(s); free(e); free(d); free(np); free(sd); free(fl);
+    if (rc) return engine_err(g, rc, NULL, 0);
+    g->edges_cached = true;
+  }
+  rc = gtsg_get_vertex_states(g->eng, g->vstate);
+  if (!rc && g->nof_edges) rc = gtsg_get_edge_states(g->eng, g->estate);
+  return engine_err(g, rc, NULL, 0);
+}
+
+/* ref gt_scaffolder_graph.c:269-307 */
+int gt_scaffolder_graph_print(const GtScaffolderGraph *cg, const char *filename,
+                              char *err, size_t errlen)
+{
+  static const char *const color[] = {"black", "gray80", "gainsboro", "ivory3",
+                                      "red", "green", "magenta", "blue"};
+  GtScaffolderGraph *g = (GtScaffolderGraph *)cg;
+  FILE *f;
+  uint64_t i;
+  if (refresh(g)) return seterr(err, errlen, "%s", g->err);
+  f = fopen(filename, "w");
+  if (!f) return seterr(err, errlen, "cannot open %s for writing", filename);
+  fputs("digraph {\n", f);
+  for (i = 0; i < g->nof_vertices; i++)
+    fprintf(f, "%lu [color=\"%s\" label=\"%s\"];\n", (unsigned long)i,
+            color[g->vstate[i] & 7], g->ctg[i].name);
+  for (i = 0; i < g->nof_edges; i++)
+    fprintf(f, "%lu -> %lu [color=\"%s\" label=\"%ld\" arrowhead=\"%s\"];\n",
+            (unsigned long)g->edges[i].start, (unsigned long)g->edges[i].end,
+            color[g->estate[i] & 7], (long)g->edges[i].dist,
+            (g->edges[i].flags & 1) ? "normal" : "inv");
+  fputs("}\n", f);
+  fclose(f);
+  return 0;
+}
+
+/* ref gt_scaffolder_graph.c:421-500; exit status 2 stands for the reference's
+   failing assertion */
+int gt_scaffolder_graph_test(uint64_t max_v, uint64_t max_e, bool init_v,
+                             uint64_t nv, bool init_e, uint64_t ne, bool print_graph,
+                             char *err, size_t errlen)
+{
+  GtScaffolderGraph *g = gt_scaffolder_graph_new(max_v, max_e);
+  uint64_t i, v1 = 0, v2 = 0;
+  int rc = 0;
+  if (init_v)
+    for (i = 0; i < nv && !rc; i++)
+      if (gt_scaffolder_graph_add_vertex(g, "foobar", 100, 20, 40)) rc = 2;
+  if (init_e && !rc)
+    for (i = 0; i < ne && !rc; i++) {
+      if (v2 + 1 < nv) v2++;
+      else if (v1 + 2 < nv) { v1++; v2 = v1 + 1; }
+      if (gt_scaffolder_graph_add_edge(g, v1, v2, 2, 1.5f, 4, true, true)) rc = 2;
+    }
+  if (!rc && print_graph)
+    rc = gt_scaffolder_graph_print(g, "gt_scaffolder_graph_test.dot", err, errlen);
+  gt_scaffolder_graph_delete(g);
+  return rc;
+}
+
+/* ref gt_scaffolder_parser.c:55-147: normalised copy of a .de file */
+int gt_scaffolder_parser_read_distances_test(const char *filename, const char *out,
+                                             char *err, size_t errlen)
+{
+  size_t len, pos = 0;
+  char *buf = slurp(filename, &len), line[1025], hdr[1024];
+  FILE *f;
+  if (!buf) return seterr(err, errlen, "can not read distance file %s", filename);
+  f = fopen(out, "w");
+  if (!f) { free(buf); return seterr(err, errlen, "cannot open %s for writing", out); }
+  while (pos < len) {
+    size_t ls = pos, ll;
+    char *save = NULL, *field;
+    bool sense = true, first_antisense = true;
+    long dist, np;
+    float sd;
+    while (pos < len && buf[pos] != '\n') pos++;
+    if (pos < len) pos++;
+    ll = pos - ls;
+    if (ll > LINE_MAX_REF) ll = LINE_MAX_REF;
+    memcpy(line, buf + ls, ll);
+    line[ll - 1] = '\0';
+    field = strtok_r(line, " ", &save);
+    fprintf(f, "%s", field ? field : "(null)");
+    while (field) {
+      if (scan_record(field, hdr, &dist, &np, &sd)) {
+        size_t hl = strlen(hdr);
+        bool same = hdr[hl - 1] == '+';
+        if (np < 0) {
+          fclose(f); free(buf);
+          return seterr(err, errlen, "Invalid value for number of pairs");
+        }
+        hdr[hl - 1] = '\0';
+        fprintf(f, " %s%c,%ld,%ld,%.1f", hdr, same ? '+' : '-', dist, np, sd);
+      } else if (*field == ';')
+        sense = !sense;
+      field = strtok_r(NULL, " ", &save);
+      if (!sense && first_antisense) { fputs(" ;", f); first_antisense = false; }
+    }
+    if (sense) fputs(" ;", f);
+    fputc('\n', f);
+  }
+  fclose(f);
+  free(buf);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* scaffold records: ref gt_scaffolder_algorithms.c:901-997 on the host copy
+   of the final states (adjacency = edges grouped by start in id order)      */
+
+static bool v_marked(uint8_t s) { return s == 1 || s == 3 || s == 7; }
+static bool e_marked(uint8_t s) { return s == 2 || s == 1 || s == 7 || s == 3; }
+
+GtScaffolderGraphRecords *
+gt_scaffolder_graph_iterate_scaffolds(GtScaffolderGraph *g, uint64_t **scaf_seqlen)
+{
+  GtScaffolderGraphRecords *r;
+  uint64_t n, m, v, k, *row, *adj, *fill, *seqlen = NULL;
+  uint8_t *vs;
+  if (!g || refresh(g)) return NULL;
+  n = g->nof_vertices; m = g->nof_edges;
+  r = xcalloc(1, sizeof *r);
+  r->g = g;
+  row = xcalloc(n + 1, sizeof *row);
+  adj = xcalloc(m, sizeof *adj);
+  fill = xcalloc(n, sizeof *fill);
+  for (k = 0; k < m; k++) row[g->edges[k].start + 1]++;
+  for (v = 0; v < n; v++) row[v + 1] += row[v];
+  for (k = 0; k < m; k++) { uint32_t s = g->edges[k].start; adj[row[s] + fill[s]++] = k; }
+  vs = g->vstate;
+  for (v = 0; v < n; v++)
+    if (!v_marked(vs[v]) && vs[v] != 6) vs[v] = 0;
+  for (v = 0; v < n; v++) {
+    uint64_t nscaf = 0, pick = 0, len;
+    if (vs[v] == 4 || v_marked(vs[v])) continue;
+    for (k = row[v]; k < row[v + 1]; k++)
+      if (g->estate[adj[k]] == 6) { nscaf++; pick = adj[k]; }
+    if (nscaf > 1) continue;
+    if (r->n == r->cap) {
+      r->cap = r->cap ? 2 * r->cap : 256;
+      r->root = xrealloc(r->root, r->cap * sizeof *r->root);
+      r->off = xrealloc(r->off, (r->cap + 1) * sizeof *r->off);
+      seqlen = xrealloc(seqlen, r->cap * sizeof *seqlen);
+    }
+    r->root[r->n] = v;
+    r->off[r->n] = r->nedge;
+    len = g->ctg[v].seq_len;
+    vs[v] = 4;
+    if (nscaf == 1) {
+      uint64_t cur = pick;
+      for (;;) {
+        const HEdge *ce = g->edges + cur;
+        uint32_t w = ce->end;
+        uint64_t cnt = 0, nxt = 0;
+        bool sense = ce->flags & 1, same = ce->flags & 2, dir;
+        if (r->nedge == r->capedge) {
+          r->capedge = r->capedge ? 2 * r->capedge : 1024;
+          r->edge = xrealloc(r->edge, r->capedge * sizeof *r->edge);
+        }
+        r->edge[r->nedge++] = cur;
+        len += (uint64_t)ce->dist;
+        len += g->ctg[w].seq_len;
+        if (vs[w] == 4) break;
+        vs[w] = 4;
+        dir = same ? sense : !sense;
+        for (k = row[w]; k < row[w + 1]; k++) {
+          const HEdge *x = g->edges + adj[k];
+          if (((x->flags & 1) != 0) == dir && !e_marked(g->estate[adj[k]]) &&
+              !(x->end == ce->start && x->start == ce->end) && g->estate[adj[k]] == 6) {
+            cnt++;
+            nxt = adj[k];
+          }
+        }
+        if (cnt != 1) break;
+        cur = nxt;
+      }
+    }
+    seqlen[r->n] = len;
+    r->n++;
+  }
+  if (r->off || r->n == 0) {
+    r->off = xrealloc(r->off, (r->n + 1) * sizeof *r->off);
+    r->off[r->n] = r->nedge;
+  }
+  free(row); free(adj); free(fill);
+  if (scaf_seqlen) *scaf_seqlen = seqlen; else free(seqlen);
+  return r;
+}
+
+uint64_t gt_scaffolder_graph_records_size(const GtScaffolderGraphRecords *r) { return r ? r->n : 0; }
+
+void gt_scaffolder_graph_records_delete(GtScaffolderGraphRecords *r)
+{
+  if (!r) return;
+  free(r->root); free(r->off); free(r->edge); free(r);
+}
+
+/* ref gt_scaffolder_algorithms.c:1000-1042 */
+int gt_scaffolder_graph_write_scaffold(const GtScaffolderGraphRecords *r,
+                                       const char *file_name, char *err, size_t errlen)
+{
+  FILE *f;
+  uint64_t i, j;
+  if (!r) return seterr(err, errlen, "no records");
+  f = fopen(file_name, "w");
+  if (!f) return seterr(err, errlen, "can not create file %s", file_name);
+  for (i = 0; i < r->n; i++) {
+    fprintf(f, "%s", r->g->ctg[r->root[i]].name);
+    for (j = r->off[i]; j < r->off[i + 1]; j++) {
+      const HEdge *e = r->g->edges + r->edge[j];
+      fprintf(f, "\t%s,%ld,%f,%d,%d,", r->g->ctg[e->end].name, (long)e->dist, e->std_dev,
+              (e->flags & 1) ? 1 : 0, (e->flags & 2) ? 1 : 0);
+    }
+    fputc('\n', f);
+  }
+  fclose(f);
+  return 0;
+}

@@ -22,6 +22,19 @@ SYMBOLS = [
 ]
 
 
+HOST_SYMBOLS = [
+    "gt_scaffolder_graph_new", "gt_scaffolder_graph_delete", "gt_scaffolder_graph_add_vertex",
+    "gt_scaffolder_graph_add_edge", "gt_scaffolder_graph_new_from_file",
+    "gt_scaffolder_graph_print", "gt_scaffolder_graph_test",
+    "gt_scaffolder_parser_read_distances_test", "gt_scaffolder_graph_mark_repeats",
+    "gt_scaffolder_graph_filter", "gt_scaffolder_removecycles", "gt_scaffolder_makescaffold",
+    "gt_scaffolder_graph_iterate_scaffolds", "gt_scaffolder_graph_records_size",
+    "gt_scaffolder_graph_records_delete", "gt_scaffolder_graph_write_scaffold",
+    "gt_scaffolder_graph_nof_vertices", "gt_scaffolder_graph_nof_edges",
+    "gt_scaffolder_graph_last_error", "gt_scaffolder_set_device",
+]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("calls", C.c_uint64), ("ms", C.c_double)]
 
@@ -34,7 +47,7 @@ def lib():
             raise ImportError("%s not built: run `python __graft_entry__.py` (hipcc, gfx950); "
                               "the engine has no CPU fallback" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
-        for s in SYMBOLS:
+        for s in SYMBOLS + HOST_SYMBOLS:
             getattr(L, s)  # AttributeError if a declared entry point is missing
         vp, u64, i64, f32, ci = C.c_void_p, C.c_uint64, C.c_int64, C.c_float, C.c_int
         L.gtsg_create.argtypes = [C.POINTER(vp), ci, vp]
@@ -62,6 +75,33 @@ def lib():
         L.gtsg_reset_kernel_times.argtypes = [vp]
         L.gtsg_get_stat.argtypes = [vp, C.c_char_p]
         L.gtsg_get_stat.restype = i64
+        cp, sz, b = C.c_char_p, C.c_size_t, C.c_bool
+        L.gt_scaffolder_graph_new.argtypes = [u64, u64]
+        L.gt_scaffolder_graph_new.restype = vp
+        L.gt_scaffolder_graph_delete.argtypes = [vp]
+        L.gt_scaffolder_graph_add_vertex.argtypes = [vp, cp, u64, f32, f32]
+        L.gt_scaffolder_graph_add_edge.argtypes = [vp, u64, u64, i64, f32, u64, b, b]
+        L.gt_scaffolder_graph_new_from_file.argtypes = [C.POINTER(vp), cp, u64, cp, b, cp, sz]
+        L.gt_scaffolder_graph_print.argtypes = [vp, cp, cp, sz]
+        L.gt_scaffolder_graph_test.argtypes = [u64, u64, b, u64, b, u64, b, cp, sz]
+        L.gt_scaffolder_parser_read_distances_test.argtypes = [cp, cp, cp, sz]
+        L.gt_scaffolder_graph_mark_repeats.argtypes = [cp, vp, f32, f32, cp, sz]
+        L.gt_scaffolder_graph_filter.argtypes = [vp, f32, f32, i64]
+        L.gt_scaffolder_removecycles.argtypes = [vp]
+        L.gt_scaffolder_makescaffold.argtypes = [vp]
+        L.gt_scaffolder_graph_iterate_scaffolds.argtypes = [vp, C.POINTER(C.POINTER(u64))]
+        L.gt_scaffolder_graph_iterate_scaffolds.restype = vp
+        L.gt_scaffolder_graph_records_size.argtypes = [vp]
+        L.gt_scaffolder_graph_records_size.restype = u64
+        L.gt_scaffolder_graph_records_delete.argtypes = [vp]
+        L.gt_scaffolder_graph_write_scaffold.argtypes = [vp, cp, cp, sz]
+        L.gt_scaffolder_graph_nof_vertices.argtypes = [vp]
+        L.gt_scaffolder_graph_nof_vertices.restype = u64
+        L.gt_scaffolder_graph_nof_edges.argtypes = [vp]
+        L.gt_scaffolder_graph_nof_edges.restype = u64
+        L.gt_scaffolder_graph_last_error.argtypes = [vp]
+        L.gt_scaffolder_graph_last_error.restype = cp
+        L.gt_scaffolder_set_device.argtypes = [ci]
         _LIB = L
     return _LIB
 
@@ -210,6 +250,85 @@ class Engine:
 
     def reset_kernel_times(self):
         self._L.gtsg_reset_kernel_times(self._h)
+
+
+class ScaffolderGraph:
+    """The reference's GtScaffolderGraph life cycle through the C host layer
+    (include/gt_scaffolder_host.h): files in, .dot / .scaf out."""
+
+    def __init__(self, handle):
+        self._L = lib()
+        self._h = handle
+
+    @classmethod
+    def from_files(cls, fasta, dist, min_ctg_len=200, astat_is_annotated=False, device=0):
+        L = lib()
+        L.gt_scaffolder_set_device(device)
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.gt_scaffolder_graph_new_from_file(C.byref(h), fasta.encode(), min_ctg_len,
+                                                 dist.encode(), astat_is_annotated, err, 512)
+        if rc != 0:
+            raise EngineError(err.value.decode())
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gt_scaffolder_graph_delete(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, err=None):
+        if rc != 0:
+            msg = err.value.decode() if err is not None and err.value else \
+                self._L.gt_scaffolder_graph_last_error(self._h).decode()
+            raise EngineError(msg)
+
+    @property
+    def nv(self):
+        return int(self._L.gt_scaffolder_graph_nof_vertices(self._h))
+
+    @property
+    def ne(self):
+        return int(self._L.gt_scaffolder_graph_nof_edges(self._h))
+
+    def mark_repeats(self, astat_file, copy_num_cutoff=0.3, astat_cutoff=20.0):
+        err = C.create_string_buffer(512)
+        self._chk(self._L.gt_scaffolder_graph_mark_repeats(astat_file.encode(), self._h,
+                                                           copy_num_cutoff, astat_cutoff, err, 512), err)
+
+    def filter(self, pcutoff=0.01, cncutoff=1.5, ocutoff=400):
+        self._chk(self._L.gt_scaffolder_graph_filter(self._h, pcutoff, cncutoff, int(ocutoff)))
+
+    def removecycles(self):
+        self._chk(self._L.gt_scaffolder_removecycles(self._h))
+
+    def makescaffold(self):
+        self._chk(self._L.gt_scaffolder_makescaffold(self._h))
+
+    def print_dot(self, path):
+        err = C.create_string_buffer(512)
+        self._chk(self._L.gt_scaffolder_graph_print(self._h, path.encode(), err, 512), err)
+
+    def write_scaffold(self, path):
+        """iterate_scaffolds + write_scaffold; returns the scaffold lengths."""
+        sl = C.POINTER(C.c_uint64)()
+        r = C.c_void_p(self._L.gt_scaffolder_graph_iterate_scaffolds(self._h, C.byref(sl)))
+        if not r:
+            raise EngineError(self._L.gt_scaffolder_graph_last_error(self._h).decode())
+        n = int(self._L.gt_scaffolder_graph_records_size(r))
+        lens = np.array([sl[i] for i in range(n)], np.uint64)
+        C.CDLL(None).free(sl)
+        err = C.create_string_buffer(512)
+        rc = self._L.gt_scaffolder_graph_write_scaffold(r, path.encode(), err, 512)
+        self._L.gt_scaffolder_graph_records_delete(r)
+        self._chk(rc, err)
+        return lens
 
 
 def state_digest_host(vstates, estates):

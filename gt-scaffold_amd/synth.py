@@ -27,7 +27,7 @@ def _lognormal_int(gen, n, median, sigma, lo, hi, device):
 def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
                scaffold_median=20, scaffold_sigma=1.0, p_repeat=0.02, repeat_degree=24,
                p_bubble=0.02, p_chimeric=0.01, p_missing_astat=0.01, p_relist=0.01,
-               p_link=0.97, contig_median=900, dist_range_small=False):
+               p_link=0.97, contig_median=900, dist_range_small=False, scaffold_max=20000):
     """Returns a dict of tensors:
       seq_len[u64 as i64], astat[f32], copy_num[f32]          (per contig)
       root[i32], ctg[i32], dist[i64], std_dev[f32], num_pairs[i64], flags[u8]
@@ -45,10 +45,10 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
 
     # --- layout: positions 0..n-1 on concatenated true scaffolds -------
     n_sc = max(4, int(n / scaffold_median * 2.5) + 8)
-    sc_len = _lognormal_int(gen, n_sc, scaffold_median, scaffold_sigma, 1, 20000, dev)
+    sc_len = _lognormal_int(gen, n_sc, scaffold_median, scaffold_sigma, 1, scaffold_max, dev)
     sc_end = torch.cumsum(sc_len, 0)
     while int(sc_end[-1]) < n:  # pathological draw: extend
-        more = _lognormal_int(gen, n_sc, scaffold_median, scaffold_sigma, 1, 20000, dev)
+        more = _lognormal_int(gen, n_sc, scaffold_median, scaffold_sigma, 1, scaffold_max, dev)
         sc_end = torch.cat([sc_end, sc_end[-1] + torch.cumsum(more, 0)])
     pos = torch.arange(n, device=dev)
     sc_id = torch.searchsorted(sc_end, pos, right=True)
@@ -211,24 +211,33 @@ def write_files(g, prefix, fasta_order_seed=1):
                                                    repr(float(g["copy_num"][i])),
                                                    repr(float(g["astat"][i]))))
     with open(prefix + ".de", "w") as f:
+        # one line per root contig: sense records, ';', antisense records.  The
+        # reference reads lines into a 1024-byte buffer (parser.c:30), so long
+        # lists continue on a further line of the same root.
         root = g["root"]; m = len(root)
         k = 0
         seen = set()
         while k < m:
             r = int(root[k])
             parts = [header_of(r)]
+            length = len(parts[0])
             sense = True
             while k < m and int(root[k]) == r:
                 s = bool(g["flags"][k] & 1)
+                rec = "%s%s,%d,%d,%s" % (header_of(int(g["ctg"][k])),
+                                         "+" if g["flags"][k] & 2 else "-",
+                                         g["dist"][k], g["num_pairs"][k],
+                                         repr(float(g["std_dev"][k])))
+                if (not sense) and s:         # back to sense: needs a new line
+                    break
+                if length + len(rec) + 4 > 900:
+                    break
                 if sense and not s:
                     parts.append(";")
                     sense = False
-                elif (not sense) and s:       # would need a new line
-                    break
-                parts.append("%s%s,%d,%d,%s" % (header_of(int(g["ctg"][k])),
-                                                 "+" if g["flags"][k] & 2 else "-",
-                                                 g["dist"][k], g["num_pairs"][k],
-                                                 repr(float(g["std_dev"][k]))))
+                    length += 2
+                parts.append(rec)
+                length += len(rec) + 1
                 k += 1
             if sense:
                 parts.append(";")

@@ -1,0 +1,97 @@
+/*
+  gt_scaffolder_host.h -- C host layer of libgtscaffold_hip.so.
+
+  Same function names, argument meaning and error behaviour as the reference's
+  public API (src/gt_scaffolder_graph.h, src/gt_scaffolder_parser.h,
+  src/gt_scaffolder_algorithms.h), with GenomeTools' types replaced by plain C:
+      GtStr *      -> const char *
+      GtError *    -> char *err, size_t errlen   (message, may be NULL)
+      GtUword/GtWord -> uint64_t / int64_t
+      GtArray * of GtScaffolderGraphRecord * -> GtScaffolderGraphRecords *
+  Text parsing (.fa / .de / .astat), .dot / .scaf writing and the scaffold
+  record walk run on the host; graph construction and all algorithms run on
+  the GPU through gt_scaffold_hip.h.  Without a GPU every call that needs the
+  engine fails with an error message.
+*/
+#ifndef GT_SCAFFOLDER_HOST_H
+#define GT_SCAFFOLDER_HOST_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct GtScaffolderGraph GtScaffolderGraph;
+typedef struct GtScaffolderGraphRecords GtScaffolderGraphRecords;
+
+/* ref gt_scaffolder_graph.c:60 / :75 */
+GtScaffolderGraph *gt_scaffolder_graph_new(uint64_t max_nof_vertices,
+                                           uint64_t max_nof_edges);
+void gt_scaffolder_graph_delete(GtScaffolderGraph *graph);
+/* ref gt_scaffolder_graph.c:105, :137 (hand-built graphs live on the host and
+   can be printed; they return -1 when they exceed the announced capacity,
+   where the reference asserts) */
+int gt_scaffolder_graph_add_vertex(GtScaffolderGraph *graph, const char *header_seq,
+                                   uint64_t seq_len, float astat, float copy_num);
+int gt_scaffolder_graph_add_edge(GtScaffolderGraph *graph, uint64_t vstart,
+                                 uint64_t vend, int64_t dist, float std_dev,
+                                 uint64_t num_pairs, bool dir, bool same);
+/* ref gt_scaffolder_graph.c:346 */
+int gt_scaffolder_graph_new_from_file(GtScaffolderGraph **graph_par,
+                                      const char *ctg_filename,
+                                      uint64_t min_ctg_len,
+                                      const char *dist_filename,
+                                      bool astat_is_annotated, char *err,
+                                      size_t errlen);
+/* ref gt_scaffolder_graph.c:247 */
+int gt_scaffolder_graph_print(const GtScaffolderGraph *g, const char *filename,
+                              char *err, size_t errlen);
+/* ref gt_scaffolder_graph.c:421 */
+int gt_scaffolder_graph_test(uint64_t max_nof_vertices, uint64_t max_nof_edges,
+                             bool init_vertices, uint64_t nof_vertices,
+                             bool init_edges, uint64_t nof_edges,
+                             bool print_graph, char *err, size_t errlen);
+/* ref gt_scaffolder_parser.c:55 */
+int gt_scaffolder_parser_read_distances_test(const char *filename,
+                                             const char *output_filename,
+                                             char *err, size_t errlen);
+
+/* ref gt_scaffolder_algorithms.c:90 */
+int gt_scaffolder_graph_mark_repeats(const char *filename,
+                                     GtScaffolderGraph *graph,
+                                     float copy_num_cutoff, float astat_cutoff,
+                                     char *err, size_t errlen);
+/* ref gt_scaffolder_algorithms.c:261, :495, :767 (void in the reference; here
+   they return the engine's status, 0 = ok) */
+int gt_scaffolder_graph_filter(GtScaffolderGraph *graph, float pcutoff,
+                               float cncutoff, int64_t ocutoff);
+int gt_scaffolder_removecycles(GtScaffolderGraph *graph);
+int gt_scaffolder_makescaffold(GtScaffolderGraph *graph);
+
+/* ref gt_scaffolder_algorithms.c:901; scaf_seqlen (may be NULL) receives a
+   malloc'ed array of the lengths the reference hands to its assembly-stats
+   calculator, one per record */
+GtScaffolderGraphRecords *
+gt_scaffolder_graph_iterate_scaffolds(GtScaffolderGraph *graph,
+                                      uint64_t **scaf_seqlen);
+uint64_t gt_scaffolder_graph_records_size(const GtScaffolderGraphRecords *r);
+void gt_scaffolder_graph_records_delete(GtScaffolderGraphRecords *r);
+/* ref gt_scaffolder_algorithms.c:1000 */
+int gt_scaffolder_graph_write_scaffold(const GtScaffolderGraphRecords *records,
+                                       const char *file_name, char *err,
+                                       size_t errlen);
+
+/* accessors used by bindings and tests */
+uint64_t gt_scaffolder_graph_nof_vertices(const GtScaffolderGraph *g);
+uint64_t gt_scaffolder_graph_nof_edges(const GtScaffolderGraph *g);
+const char *gt_scaffolder_graph_last_error(const GtScaffolderGraph *g);
+/* which GPU new_from_file / the algorithms use (default 0) */
+void gt_scaffolder_set_device(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -154,3 +154,48 @@ def test_medium_graph_and_digest():
     eng, og = run_pipeline(g)
     assert eng.digest() == pkg.engine.state_digest_host(og.vertex_states(), og.edge_states())
     assert eng.stat("components") > 1000
+
+
+def test_file_api_reproduces_reference_dot_files(tmp_path, golden_dir):
+    """BASELINE configs[0]: testdata/primary-contigs.fa + libPE.de + libPE.astat
+    through the drop-in C API, bit-exact .dot against the reference's
+    *_expected.dot (ref testsuite/scaffolder_include.rb:88-121, src/test.c:130-157)."""
+    import filecmp
+    G = pkg.engine.ScaffolderGraph.from_files(golden_dir + "/primary-contigs.fa",
+                                              golden_dir + "/libPE.de", DEFAULTS["min_ctg_len"])
+    G.mark_repeats(golden_dir + "/libPE.astat", DEFAULTS["copy_num_cutoff"], DEFAULTS["astat_cutoff"])
+    stages = [("mark_repeats", None), ("filter", G.filter), ("removecycles", G.removecycles),
+              ("makescaffold", G.makescaffold)]
+    for name, fn in stages:
+        if fn:
+            fn()
+        out = str(tmp_path / (name + ".dot"))
+        G.print_dot(out)
+        assert filecmp.cmp(out, "%s/gt_scaffolder_algorithms_test_%s_expected.dot" % (golden_dir, name),
+                           shallow=False), name
+    # .scaf against the oracle's writer
+    og = OracleGraph.from_files(golden_dir + "/primary-contigs.fa", golden_dir + "/libPE.de")
+    og.mark_repeats_file(golden_dir + "/libPE.astat"); og.filter(); og.removecycles(); og.makescaffold(False)
+    og.write_scaffold(str(tmp_path / "oracle.scaf"))
+    G.write_scaffold(str(tmp_path / "engine.scaf"))
+    assert filecmp.cmp(tmp_path / "oracle.scaf", tmp_path / "engine.scaf", shallow=False)
+
+
+def test_file_api_on_synthetic_files(tmp_path):
+    """BASELINE configs[1] in miniature: synthetic .fa/.de/.astat written in the
+    reference's formats, parsed by both sides, identical .dot and .scaf."""
+    import filecmp
+    g = make_inputs(3000, 17, repeat_degree=12)
+    pkg.synth.write_files(g, str(tmp_path / "syn"))
+    fa, de, astat = [str(tmp_path / ("syn" + x)) for x in (".fa", ".de", ".astat")]
+    og = OracleGraph.from_files(fa, de)
+    G = pkg.engine.ScaffolderGraph.from_files(fa, de)
+    assert (G.nv, G.ne) == (og.nv, og.ne)
+    og.mark_repeats_file(astat); G.mark_repeats(astat)
+    og.filter(); G.filter(); og.makescaffold(True); G.makescaffold()
+    og.print_dot(str(tmp_path / "o.dot")); G.print_dot(str(tmp_path / "e.dot"))
+    assert filecmp.cmp(tmp_path / "o.dot", tmp_path / "e.dot", shallow=False)
+    og.write_scaffold(str(tmp_path / "o.scaf"))
+    lens = G.write_scaffold(str(tmp_path / "e.scaf"))
+    assert filecmp.cmp(tmp_path / "o.scaf", tmp_path / "e.scaf", shallow=False)
+    assert np.array_equal(lens, og.scaffolds()[3])

@@ -1,0 +1,85 @@
+"""Host layer of the product library (include/gt_scaffolder_host.h): the parts
+that need no GPU -- library loads with every declared symbol, hand-built
+graphs, .de normalisation, error behaviour of the parsers -- mirroring
+ref testsuite/scaffolder_include.rb."""
+import ctypes as C
+import filecmp
+import os
+import re
+
+import pytest
+
+from helpers import ROOT, pkg
+
+engine = pkg.engine
+
+
+def test_library_exports_every_declared_symbol():
+    L = engine.lib()
+    for hdr in ("gt_scaffold_hip.h", "gt_scaffolder_host.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names = set(re.findall(r"\b(gtsg_\w+|gt_scaffolder_\w+)\s*\(", text))
+        assert len(names) >= 15
+        for n in names:
+            assert hasattr(L, n), "%s declared in %s but not exported" % (n, hdr)
+
+
+def test_no_gpu_means_loud_failure(golden_dir):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(engine.EngineError):
+        engine.Engine(0)
+    with pytest.raises(engine.EngineError, match="no CPU path"):
+        engine.ScaffolderGraph.from_files(golden_dir + "/primary-contigs.fa", golden_dir + "/libPE.de")
+
+
+def test_graph_module_toy_graph(tmp_path, golden_dir):
+    # ref testsuite/scaffolder_include.rb:1-56 (exit status 2 = failed assertion)
+    L = engine.lib()
+    err = C.create_string_buffer(256)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert L.gt_scaffolder_graph_test(5, 8, False, 0, False, 0, False, err, 256) == 0
+        assert L.gt_scaffolder_graph_test(5, 8, True, 5, False, 0, False, err, 256) == 0
+        assert L.gt_scaffolder_graph_test(5, 8, True, 6, False, 0, False, err, 256) == 2
+        assert L.gt_scaffolder_graph_test(5, 8, True, 5, True, 8, False, err, 256) == 0
+        assert L.gt_scaffolder_graph_test(5, 8, True, 5, True, 9, False, err, 256) == 2
+        assert L.gt_scaffolder_graph_test(5, 8, True, 5, True, 8, True, err, 256) == 0
+        assert filecmp.cmp("gt_scaffolder_graph_test.dot",
+                           golden_dir + "/gt_scaffolder_graph_test_expected.dot", shallow=False)
+    finally:
+        os.chdir(cwd)
+
+
+def test_parser_module_roundtrip(tmp_path, golden_dir):
+    # ref testsuite/scaffolder_include.rb:58-80
+    L = engine.lib()
+    err = C.create_string_buffer(256)
+    out = str(tmp_path / "norm.de").encode()
+    for f in ("wrong_libPE_1.de", "wrong_libPE_2.de", "libPE.de"):
+        assert L.gt_scaffolder_parser_read_distances_test((golden_dir + "/" + f).encode(), out, err, 256) == 0
+    assert filecmp.cmp(tmp_path / "norm.de", golden_dir + "/libPE.de", shallow=False)
+
+
+@pytest.mark.parametrize("de", ["wrong_libPE_1.de", "wrong_libPE_2.de"])
+def test_erroneous_de_files_are_rejected(golden_dir, de):
+    with pytest.raises(engine.EngineError, match="Invalid record in dist file"):
+        engine.ScaffolderGraph.from_files(golden_dir + "/primary-contigs.fa", golden_dir + "/" + de)
+
+
+def test_missing_files_and_empty_de(tmp_path, golden_dir):
+    with pytest.raises(engine.EngineError, match="cannot open"):
+        engine.ScaffolderGraph.from_files(str(tmp_path / "nope.fa"), golden_dir + "/libPE.de")
+    with pytest.raises(engine.EngineError, match="can not read distance file"):
+        engine.ScaffolderGraph.from_files(golden_dir + "/primary-contigs.fa", str(tmp_path / "nope.de"))
+    empty = tmp_path / "only_unknown.de"
+    empty.write_text("contig-x contig-y+,1,2,3.0 ;\n")
+    with pytest.raises(engine.EngineError, match="is empty"):
+        engine.ScaffolderGraph.from_files(golden_dir + "/primary-contigs.fa", str(empty))
+    bad = tmp_path / "bad.fa"
+    bad.write_text("ACGT\n")
+    with pytest.raises(engine.EngineError, match="has to be '>'"):
+        engine.ScaffolderGraph.from_files(str(bad), golden_dir + "/libPE.de")
