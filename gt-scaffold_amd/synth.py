@@ -27,7 +27,8 @@ def _lognormal_int(gen, n, median, sigma, lo, hi, device):
 def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
                scaffold_median=20, scaffold_sigma=1.0, p_repeat=0.02, repeat_degree=24,
                p_bubble=0.02, p_chimeric=0.01, p_missing_astat=0.01, p_relist=0.01,
-               p_link=0.97, contig_median=900, dist_range_small=False, scaffold_max=20000):
+               p_link=0.97, contig_median=900, dist_range_small=False, scaffold_max=20000,
+               p_relist_flip=0.0):
     """Returns a dict of tensors:
       seq_len[u64 as i64], astat[f32], copy_num[f32]          (per contig)
       root[i32], ctg[i32], dist[i64], std_dev[f32], num_pairs[i64], flags[u8]
@@ -143,7 +144,11 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
     if n_re > 0:
         idx = randint(0, 2 * m, n_re)
         root = torch.cat([root, root[idx]]); ctg = torch.cat([ctg, ctg[idx]])
-        rsense = torch.cat([rsense, torch.where(rand(n_re) < 0.9, rsense[idx], ~rsense[idx])])
+        # a re-listed pair normally keeps its direction; p_relist_flip makes the two
+        # directed edges of a pair geometrically inconsistent (with a negative
+        # distance this is a negative 2-cycle on which the reference's walk
+        # search does not terminate, so it is off by default)
+        rsense = torch.cat([rsense, torch.where(rand(n_re) < 1.0 - p_relist_flip, rsense[idx], ~rsense[idx])])
         rsame = torch.cat([rsame, rsame[idx]])
         rdist = torch.cat([rdist, rdist[idx] + randint(-40, 41, n_re)])
         rsd = torch.cat([rsd, ((rsd[idx] + 0.6 * (rand(n_re) - 0.4)) * 10).round().clamp_(1, 500) / 10])

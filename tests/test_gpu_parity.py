@@ -69,7 +69,8 @@ def test_device_rounding_of_ambiguous_order():
 
 @pytest.mark.parametrize("seed", range(6))
 def test_small_graphs_stage_by_stage(seed):
-    g = make_inputs(400 + 211 * seed, seed, p_chimeric=0.03, p_bubble=0.05, p_repeat=0.03)
+    g = make_inputs(400 + 211 * seed, seed, p_chimeric=0.03, p_bubble=0.05, p_repeat=0.03,
+                    p_relist_flip=0.1)
     run_pipeline(g)
 
 

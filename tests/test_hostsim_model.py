@@ -32,7 +32,8 @@ def check(out):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_small_random_graphs(seed):
-    g = make_inputs(300 + 37 * seed, seed, p_chimeric=0.03, p_bubble=0.05, p_repeat=0.03)
+    g = make_inputs(300 + 37 * seed, seed, p_chimeric=0.03, p_bubble=0.05, p_repeat=0.03,
+                    p_relist_flip=0.1)
     out, _ = run_both(g)
     check(out)
 
