@@ -61,10 +61,13 @@ struct GtsCompView {
   uint8_t *st_dir;
   float *distmap;            /* all GTS_DIST_UNSET between walks */
   uint32_t *ccoff;           /* nslots + ncomp entries; comp c at comp_off[c]+c */
-  /* walk FIFO: ring per component, wq_off[c]..wq_off[c+1] */
-  const uint64_t *wq_off;    /* ncomp+1 */
+  /* walk FIFO of the reference search: a ring carved out of one pool the first
+     time a component needs it (few components do) */
   uint32_t *wq_edge;
   int64_t *wq_dist;
+  unsigned long long *wq_used;  /* pool entries handed out */
+  uint64_t wq_pool;          /* pool entries */
+  uint64_t wq_factor;        /* ring = factor * compact edges of the component + 64 */
   uint32_t *cerr;            /* ncomp: error code per component */
   uint64_t max_pops;         /* bound on queue pops of one walk */
   /* linear-time walk (create_walk_fast) */
@@ -331,7 +334,12 @@ struct GtsComponent {
     const uint32_t lane = W::lane();
     const uint32_t gv = C.slot_v[start];
     if (W::uni(C.G.row[gv + 1]) == W::uni(C.G.row[gv])) return true; /* :655 */
-    qbase = C.wq_off[c]; qcap = C.wq_off[c + 1] - qbase;
+    if (qcap == 0) {
+      const uint64_t need = C.wq_factor * (uint64_t)(W::uni(C.coff[s1]) - W::uni(C.coff[s0])) + 64;
+      const uint64_t off = W::alloc(C.wq_used, need);
+      if (off + need > C.wq_pool) { err = GTS_CERR_WALKQ_OVERFLOW; return false; }
+      qbase = off; qcap = need;
+    }
     qh = 0; qn = 0; ntouch = 0;
     uint32_t nwt = 0, popseq = 0;
     bool ok = true;
@@ -720,6 +728,8 @@ struct GtsWave1 {
   static GTS_HD int64_t uni64(int64_t v) { return v; }
   static GTS_HD void fence() {}
   static GTS_HD uint64_t clock() { return 0; }
+  static GTS_HD uint64_t alloc(unsigned long long *used, uint64_t n)
+  { const uint64_t o = *used; *used += n; return o; }
 };
 
 #endif

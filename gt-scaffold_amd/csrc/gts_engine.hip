@@ -60,7 +60,8 @@ struct GtsgEngine {
   size_t pool_cap = 0, pool_used = 0;
   uint32_t *d_scalars = nullptr;   /* 16 x u64 device scalars */
   /* options */
-  int64_t walk_queue_factor = 8, max_walk_pops = 1ll << 32, hub_degree = 32;
+  int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
+  int64_t walk_pool_entries = 1ll << 26;
   int64_t fast_walks = 1;
   bool profile = false;
   /* profiling */
@@ -596,14 +597,6 @@ __global__ void k_compact_fill(GtsGraphView G, const uint8_t *live,
       ++k;
     }
 }
-__global__ void k_walkq_sizes(const uint32_t *comp_off, const uint32_t *coff,
-                              uint64_t *sz, uint32_t ncomp, uint64_t factor)
-{
-  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < ncomp)
-    sz[c] = factor * (uint64_t)(coff[comp_off[c + 1]] - coff[comp_off[c]]) + 64;
-}
-
 /* gfx950 wave policy of gts_component.hpp */
 struct GtsWave64 {
   static const uint32_t WIDTH = 64;
@@ -631,6 +624,13 @@ struct GtsWave64 {
   { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
   /* constant 100 MHz counter (s_memrealtime) */
   static __device__ __forceinline__ uint64_t clock() { return wall_clock64(); }
+  /* lane 0 takes n entries from the pool, every lane gets the offset */
+  static __device__ __forceinline__ uint64_t alloc(unsigned long long *used, uint64_t n)
+  {
+    unsigned long long o = 0;
+    if (lane() == 0) o = atomicAdd(used, (unsigned long long)n);
+    return (uint64_t)uni64((int64_t)o);
+  }
 };
 
 /* one wavefront per component; `order` lists components largest first */
@@ -804,6 +804,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
 {
   if (!e || !name) return GTSG_EINVAL;
   if (!strcmp(name, "walk_queue_factor") && value >= 1) e->walk_queue_factor = value;
+  else if (!strcmp(name, "walk_pool_entries") && value >= 1) e->walk_pool_entries = value;
   else if (!strcmp(name, "max_walk_pops") && value >= 1) e->max_walk_pops = value;
   else if (!strcmp(name, "hub_degree") && value >= 1) e->hub_degree = value;
   else if (!strcmp(name, "fast_walks")) e->fast_walks = value != 0;
@@ -1050,7 +1051,7 @@ static int run_components(GtsgEngine *e, int mode)
   const uint32_t n = e->n, m = e->m;
   if (!n) return 0;
   int rc;
-  int64_t factor = e->walk_queue_factor;
+  int64_t factor = e->walk_queue_factor, pool_entries = e->walk_pool_entries;
   int64_t retries = 0;
   /* snapshot for the (rare) walk-queue retry */
   uint8_t *snap_v = nullptr, *snap_e = nullptr;
@@ -1062,7 +1063,7 @@ static int run_components(GtsgEngine *e, int mode)
                        (size_t)n + m + (16u << 20);
     /* upper bounds for phase B: slots <= n, compact edges <= m */
     const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64) + (size_t)m * (4 * 3 + 8 + 2) +
-                       ((size_t)m * factor + 64ull * n) * 12 + (size_t)n * 24 + (16u << 20);
+                       (size_t)pool_entries * 12 + (size_t)n * 24 + (16u << 20);
     if (!e->pool || e->pool_cap < wsA + wsB) {
       if ((rc = pool_reserve(e, wsA + wsB))) return rc;
     } else
@@ -1126,17 +1127,11 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemsetAsync(cmap, 0xFF, ((size_t)m + 1) * 4, e->st));
     LAUNCH("comp_compact_fill", k_compact_fill, nblk(nslots), GTS_BLOCK, G, live, slot_v,
            slot_of, coff, cstart, cend, cdist, cflags, cgpos, cstate, cmap, nslots);
-    /* walk queues */
-    PALLOC(wq_off, uint64_t, (size_t)ncomp + 1);
-    PALLOC(wtmp, uint64_t, gts_scan_tmp_elems(ncomp));
-    LAUNCH("comp_walkq_sizes", k_walkq_sizes, nblk(ncomp), GTS_BLOCK, comp_off, coff, wq_off,
-           ncomp, (uint64_t)factor);
-    gts_exscan<uint64_t, uint64_t>(wq_off, wq_off, ncomp, wtmp, (uint64_t *)(e->d_scalars + 8),
-                                   e->st);
-    uint64_t wq_total = 0;
-    if ((rc = read_u64(e, (uint64_t *)(e->d_scalars + 8), &wq_total))) return rc;
-    LAUNCH("fill", k_fill<uint64_t>, 1, 1, wq_off + ncomp, wq_total, (uint64_t)1);
-    PALLOC(wq_edge, uint32_t, wq_total + 1); PALLOC(wq_dist, int64_t, wq_total + 1);
+    /* walk queue pool of the reference search */
+    const uint64_t wq_pool = (uint64_t)pool_entries;
+    PALLOC(wq_edge, uint32_t, wq_pool + 1); PALLOC(wq_dist, int64_t, wq_pool + 1);
+    unsigned long long *wq_used = (unsigned long long *)(e->d_scalars + 48);
+    HIPCHK(hipMemsetAsync(wq_used, 0, 8, e->st));
     /* per-slot scratch */
     PALLOC(s_queue, uint32_t, nslots); PALLOC(s_term, uint32_t, nslots);
     PALLOC(s_visited, uint32_t, nslots); PALLOC(s_stv, uint32_t, nslots);
@@ -1174,7 +1169,8 @@ static int run_components(GtsgEngine *e, int mode)
     C.queue = s_queue; C.term = s_term; C.visited = s_visited; C.st_v = s_stv;
     C.st_par = s_stpar; C.st_cur = s_stcur; C.edgemap = s_edgemap; C.lastpop = s_lastpop;
     C.wterm = s_wterm; C.touched = s_touched; C.cc_best = s_ccbest; C.st_dir = s_stdir;
-    C.distmap = s_distmap; C.ccoff = s_ccoff; C.wq_off = wq_off; C.wq_edge = wq_edge;
+    C.distmap = s_distmap; C.ccoff = s_ccoff; C.wq_edge = wq_edge; C.wq_used = wq_used;
+    C.wq_pool = wq_pool; C.wq_factor = (uint64_t)factor;
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
     C.fast_walks = (int)e->fast_walks; C.nd = s_nd; C.plen = s_plen; C.tight = s_tight;
     C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat;
@@ -1217,7 +1213,7 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(e->vstate, snap_v, n, hipMemcpyDeviceToDevice, e->st));
     if (m) HIPCHK(hipMemcpyAsync(e->state, snap_e, m, hipMemcpyDeviceToDevice, e->st));
     HIPCHK(hipStreamSynchronize(e->st));
-    factor *= 4;
+    factor *= 4; pool_entries *= 4;
     if (++retries > 6) return fail(e, GTSG_EWALK, "walk queues keep overflowing");
   }
   e->stats["walk_retries"] = retries;

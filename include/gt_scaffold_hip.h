@@ -102,7 +102,11 @@ int gtsg_selftest_ambiguous(GtsgEngine *e, uint64_t n, const int64_t *d1,
 
 /* tuning */
 int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
-/*   "walk_queue_factor" (default 8), "max_walk_pops" (default 2^32),
+/*   "walk_queue_factor" (default 64: ring of a component's reference search =
+     factor x its live edges + 64 entries), "walk_pool_entries" (default 2^26,
+     the pool the rings are carved from; both are quadrupled and the call is
+     re-run from a snapshot if a ring or the pool overflows),
+     "max_walk_pops" (default 2^32),
      "hub_degree" (default 32), "profile" (0/1),
      "fast_walks" (default 1; 0 forces the reference's label-correcting search
      for every walk) */

@@ -195,20 +195,18 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
         cflags[k] = flags[p]; cstate[k] = state[p]; cgpos[k] = p; cmap[p] = k; k++;
       }
   }
-  std::vector<uint64_t> wq_off(ncomp + 1, 0);
   uint32_t maxcomp = 0;
-  for (uint32_t c = 0; c < ncomp; c++) {
-    uint64_t e = coff[comp_off[c + 1]] - coff[comp_off[c]];
-    wq_off[c + 1] = wq_off[c] + (uint64_t)wq_factor * e + 64;
+  for (uint32_t c = 0; c < ncomp; c++)
     if (comp_off[c + 1] - comp_off[c] > maxcomp) maxcomp = comp_off[c + 1] - comp_off[c];
-  }
+  const uint64_t wq_pool = (uint64_t)wq_factor * nce + 64ull * ncomp + 64;
+  unsigned long long wq_used = 0;
   const size_t S = nslots ? nslots : 1;
   std::vector<uint32_t> queue(S), term(S), visited(S), st_v(S), st_par(S), st_cur(S),
       edgemap(S), lastpop(S, 0), wterm(S), touchedl(S), cc_best(S), ccoff(S + ncomp + 1),
-      wq_edge(wq_off[ncomp] ? wq_off[ncomp] : 1), cerr(ncomp ? ncomp : 1, 0);
+      wq_edge(wq_pool), cerr(ncomp ? ncomp : 1, 0);
   std::vector<uint8_t> st_dir(S);
   std::vector<float> distmap(S, GTS_DIST_UNSET);
-  std::vector<int64_t> wq_dist(wq_off[ncomp] ? wq_off[ncomp] : 1);
+  std::vector<int64_t> wq_dist(wq_pool);
   GtsCompView C;
   C.G = G; C.cmap = cmap.data(); C.ncomp = ncomp; C.comp_off = comp_off.data();
   C.slot_v = slot_v.data(); C.cseq = cseq.data(); C.coff = coff.data();
@@ -219,7 +217,8 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   C.st_cur = st_cur.data(); C.edgemap = edgemap.data(); C.lastpop = lastpop.data();
   C.wterm = wterm.data(); C.touched = touchedl.data(); C.cc_best = cc_best.data();
   C.st_dir = st_dir.data(); C.distmap = distmap.data(); C.ccoff = ccoff.data();
-  C.wq_off = wq_off.data(); C.wq_edge = wq_edge.data(); C.wq_dist = wq_dist.data();
+  C.wq_edge = wq_edge.data(); C.wq_dist = wq_dist.data(); C.wq_used = &wq_used;
+  C.wq_pool = wq_pool; C.wq_factor = wq_factor;
   C.cerr = cerr.data(); C.max_pops = max_pops;
   std::vector<int64_t> nd(S); std::vector<uint64_t> plen(S); std::vector<uint8_t> tight(S, 0);
   std::vector<uint32_t> sf(ncomp ? ncomp : 1, 0), ss(ncomp ? ncomp : 1, 0);
