@@ -31,6 +31,13 @@
   live edges (unmarked when the component phase starts) are copied into a
   compact CSR in list order.  Marks set here (CYCLIC, SCAFFOLD) go to the
   global graph AND to the compact copy.
+
+  Everything the program touches is addressed with COMPONENT-LOCAL indices
+  (slot 0..nv-1, compact edge 0..ne-1) through GtsCompMem, a bundle of base
+  pointers.  The bases either point into the global arrays (any size) or into
+  the workgroup's LDS, where the launcher has staged the component's graph and
+  scratch (gts_engine.hip: one launch per LDS size class): the dependent
+  pointer chasing of BFS / DFS / walks then runs at LDS latency.
 */
 #ifndef GTS_COMPONENT_HPP
 #define GTS_COMPONENT_HPP
@@ -48,8 +55,8 @@ struct GtsCompView {
   const uint32_t *slot_v;    /* slot -> global vertex */
   const int64_t *cseq;       /* slot -> seq_len */
   const uint32_t *coff;      /* nslots+1: compact edge range of a slot */
-  const uint32_t *cstart;    /* compact edge -> start slot */
-  const uint32_t *cend;      /* compact edge -> end slot */
+  const uint32_t *cstart;    /* compact edge -> start slot, component-local */
+  const uint32_t *cend;      /* compact edge -> end slot, component-local */
   const int64_t *cdist;
   const uint8_t *cflags;
   const uint32_t *cgpos;     /* compact edge -> global position */
@@ -80,13 +87,48 @@ struct GtsCompView {
                                 outside walks, fast walks, reference walks */
 };
 
+/* base pointers of ONE component, component-local indices */
+struct GtsCompMem {
+  uint32_t nv, ne;           /* slots, compact edges of the component */
+  uint32_t e0;               /* value to subtract from coff[] entries */
+  const uint32_t *coff;      /* nv+1 */
+  const uint32_t *cstart, *cend;
+  const int64_t *cdist;
+  const uint8_t *cflags;
+  const int64_t *cseq;
+  uint8_t *cstate, *vst;
+  uint32_t *queue, *term, *visited, *st_v, *st_par, *st_cur, *edgemap,
+      *lastpop, *wterm, *touched, *cc_best, *ccoff;
+  uint8_t *st_dir, *tight;
+  float *distmap;
+  int64_t *nd;
+  uint64_t *plen;
+};
+
+/* LDS bytes needed to stage a component (every array 16-byte aligned) */
+GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
+{
+  const uint32_t a = 16;
+  uint32_t b = 0;
+  b += (((nv + 1) * 4 + a - 1) / a) * a * 2;          /* coff, ccoff */
+  b += ((nv * 4 + a - 1) / a) * a * 12;               /* queue..cc_best, distmap */
+  b += ((nv * 8 + a - 1) / a) * a * 3;                /* cseq, nd, plen */
+  b += ((nv + a - 1) / a) * a * 3;                    /* vst, st_dir, tight */
+  b += ((ne * 4 + a - 1) / a) * a * 2;                /* cstart, cend */
+  b += ((ne * 8 + a - 1) / a) * a;                    /* cdist */
+  b += ((ne + a - 1) / a) * a * 2;                    /* cflags, cstate */
+  return b;
+}
+
 /* (float)GT_WORD_MAX, ref algorithms.c:650 */
 #define GTS_DIST_UNSET 9223372036854775808.0f
 
 template <class W>
 struct GtsComponent {
   const GtsCompView &C;
-  uint32_t c, s0, s1;   /* component, slot range */
+  const GtsCompMem &M;
+  uint32_t c, s0, e0g;  /* component, its first slot and first compact edge */
+  uint32_t nv;
   uint32_t nterm, ncc;  /* filled by calc_cc */
   uint32_t err;
   /* walk-queue state of the walk in flight */
@@ -95,57 +137,76 @@ struct GtsComponent {
   uint32_t nfast, nslow;
   uint64_t tfast, tslow;
 
-  GTS_HD GtsComponent(const GtsCompView &cv, uint32_t comp)
-      : C(cv), c(comp), s0(cv.comp_off[comp]), s1(cv.comp_off[comp + 1]),
-        nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0), ntouch(0),
-        nfast(0), nslow(0), tfast(0), tslow(0) {}
+  GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMem &mem, uint32_t comp)
+      : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
+        nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0) {}
 
-  GTS_HD uint32_t *ccoffs() const { return C.ccoff + s0 + c; }
+  /* bases into the global arrays */
+  static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
+  {
+    GtsCompMem m;
+    const uint32_t s0 = C.comp_off[comp], s1 = C.comp_off[comp + 1];
+    const uint32_t e0 = C.coff[s0];
+    m.nv = s1 - s0; m.ne = C.coff[s1] - e0; m.e0 = e0;
+    m.coff = C.coff + s0; m.cstart = C.cstart + e0; m.cend = C.cend + e0;
+    m.cdist = C.cdist + e0; m.cflags = C.cflags + e0; m.cseq = C.cseq + s0;
+    m.cstate = C.cstate + e0; m.vst = C.vst + s0;
+    m.queue = C.queue + s0; m.term = C.term + s0; m.visited = C.visited + s0;
+    m.st_v = C.st_v + s0; m.st_par = C.st_par + s0; m.st_cur = C.st_cur + s0;
+    m.edgemap = C.edgemap + s0; m.lastpop = C.lastpop + s0; m.wterm = C.wterm + s0;
+    m.touched = C.touched + s0; m.cc_best = C.cc_best + s0;
+    m.ccoff = C.ccoff + s0 + comp; m.st_dir = C.st_dir + s0; m.tight = C.tight + s0;
+    m.distmap = C.distmap + s0; m.nd = C.nd + s0; m.plen = C.plen + s0;
+    return m;
+  }
+
+  GTS_HD uint32_t eoff(uint32_t ls) const { return W::uni(M.coff[ls]) - M.e0; }
 
   /* ---- ref algorithms.c:379-436 (with isterminal, :346-373, fused) ---- */
   GTS_HD void calc_cc()
   {
     const uint32_t lane = W::lane();
-    for (uint32_t s = s0 + lane; s < s1; s += W::WIDTH)
-      if (!gts_vertex_is_marked(C.vst[s])) C.vst[s] = GIS_UNVISITED;
+    for (uint32_t s = lane; s < nv; s += W::WIDTH)
+      if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
     W::fence();
-    uint32_t *ccoff = ccoffs();
+    uint32_t *ccoff = M.ccoff;
     nterm = 0; ncc = 0;
-    for (uint32_t s = s0; s < s1; ++s) {
-      const uint8_t st = (uint8_t)W::uni(C.vst[s]);
+    for (uint32_t s = 0; s < nv; ++s) {
+      const uint8_t st = (uint8_t)W::uni(M.vst[s]);
       if (gts_vertex_is_marked(st) || st == GIS_VISITED) continue;
-      C.vst[s] = GIS_PROCESSED;
-      C.queue[s0] = s;
+      M.vst[s] = GIS_PROCESSED;
+      M.queue[0] = s;
       ccoff[ncc++] = nterm;
       W::fence();
       uint32_t bh = 0, bn = 1;
       while (bh < bn) {
-        const uint32_t cur = W::uni(C.queue[s0 + bh]);
+        const uint32_t cur = W::uni(M.queue[bh]);
         ++bh;
-        const uint32_t eb = W::uni(C.coff[cur]), ee = W::uni(C.coff[cur + 1]);
+        const uint32_t eb = eoff(cur), ee = eoff(cur + 1);
         bool has_s = false, has_a = false;
         for (uint32_t base = eb; base < ee; base += W::WIDTH) {
           const uint32_t ce = base + lane;
           bool live = false, sense = false, unv = false;
           uint32_t nb = 0;
           if (ce < ee) {
-            live = !gts_edge_is_marked(C.cstate[ce]);
-            sense = (C.cflags[ce] & GTS_F_SENSE) != 0;
-            nb = C.cend[ce];
-            unv = live && C.vst[nb] == GIS_UNVISITED;
+            live = !gts_edge_is_marked(M.cstate[ce]);
+            sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+            nb = M.cend[ce];
+            unv = live && M.vst[nb] == GIS_UNVISITED;
           }
           has_s |= W::ballot(live && sense) != 0;
           has_a |= W::ballot(live && !sense) != 0;
           const uint64_t mask = W::ballot(unv);
           if (unv) {
-            C.queue[s0 + bn + W::popc_below(mask, lane)] = nb;
-            C.vst[nb] = GIS_PROCESSED;
+            M.queue[bn + W::popc_below(mask, lane)] = nb;
+            M.vst[nb] = GIS_PROCESSED;
           }
           bn += W::popc(mask);
           W::fence();
         }
-        if (!(has_s && has_a)) C.term[s0 + nterm++] = cur;
-        C.vst[cur] = GIS_VISITED;
+        if (!(has_s && has_a)) M.term[nterm++] = cur;
+        M.vst[cur] = GIS_VISITED;
         W::fence();
       }
     }
@@ -160,28 +221,28 @@ struct GtsComponent {
     const uint32_t lane = W::lane();
     uint32_t sp = 1;
     nvis = 0;
-    C.st_v[s0] = start; C.st_par[s0] = GTS_NONE; C.st_cur[s0] = C.coff[start];
-    C.st_dir[s0] = dir0 ? 1 : 0;
-    C.visited[s0 + nvis++] = start;
-    C.vst[start] = GIS_VISITED;
+    M.st_v[0] = start; M.st_par[0] = GTS_NONE; M.st_cur[0] = eoff(start);
+    M.st_dir[0] = dir0 ? 1 : 0;
+    M.visited[nvis++] = start;
+    M.vst[start] = GIS_VISITED;
     W::fence();
     while (sp > 0) {
-      const uint32_t f = s0 + sp - 1;
-      const uint32_t v = W::uni(C.st_v[f]), par = W::uni(C.st_par[f]);
-      const bool dir = W::uni((uint32_t)C.st_dir[f]) != 0;
-      uint32_t cur = W::uni(C.st_cur[f]);
-      const uint32_t ee = W::uni(C.coff[v + 1]);
+      const uint32_t f = sp - 1;
+      const uint32_t v = W::uni(M.st_v[f]), par = W::uni(M.st_par[f]);
+      const bool dir = W::uni((uint32_t)M.st_dir[f]) != 0;
+      uint32_t cur = W::uni(M.st_cur[f]);
+      const uint32_t ee = eoff(v + 1);
       bool descended = false;
       while (cur < ee) {
         const uint32_t ce = cur + lane;
         bool cand = false;
         uint32_t nb = 0, vs = 0, fl = 0;
         if (ce < ee) {
-          fl = C.cflags[ce];
-          nb = C.cend[ce];
+          fl = M.cflags[ce];
+          nb = M.cend[ce];
           if (((fl & GTS_F_SENSE) != 0) == dir &&
-              !gts_edge_is_marked(C.cstate[ce]) && nb != par) {
-            vs = C.vst[nb];
+              !gts_edge_is_marked(M.cstate[ce]) && nb != par) {
+            vs = M.vst[nb];
             cand = !gts_vertex_is_marked((uint8_t)vs) && vs != GIS_PROCESSED;
           }
         }
@@ -192,13 +253,13 @@ struct GtsComponent {
           const uint32_t fl_l = W::shfl(fl, l);
           if (vs_l == GIS_VISITED) return cur + l;      /* back edge */
           /* GIS_UNVISITED: descend */
-          C.st_cur[f] = cur + l + 1;
-          const uint32_t g = s0 + sp;
-          C.st_v[g] = nb_l; C.st_par[g] = v; C.st_cur[g] = C.coff[nb_l];
-          C.st_dir[g] = gts_next_dir((uint8_t)fl_l) ? 1 : 0;
+          M.st_cur[f] = cur + l + 1;
+          const uint32_t g = sp;
+          M.st_v[g] = nb_l; M.st_par[g] = v; M.st_cur[g] = eoff(nb_l);
+          M.st_dir[g] = gts_next_dir((uint8_t)fl_l) ? 1 : 0;
           ++sp;
-          C.visited[s0 + nvis++] = nb_l;
-          C.vst[nb_l] = GIS_VISITED;
+          M.visited[nvis++] = nb_l;
+          M.vst[nb_l] = GIS_VISITED;
           W::fence();
           descended = true;
           break;
@@ -206,7 +267,7 @@ struct GtsComponent {
         cur += W::WIDTH;
       }
       if (!descended) {
-        C.vst[v] = GIS_PROCESSED;
+        M.vst[v] = GIS_PROCESSED;
         --sp;
         W::fence();
       }
@@ -218,8 +279,8 @@ struct GtsComponent {
   GTS_HD void mark_vertex_cyclic(uint32_t s)
   {
     const uint32_t lane = W::lane();
-    const uint32_t v = C.slot_v[s];
-    C.vst[s] = GIS_CYCLIC;
+    const uint32_t v = C.slot_v[s0 + s];
+    M.vst[s] = GIS_CYCLIC;
     C.G.vstate[v] = GIS_CYCLIC;
     const uint32_t b = C.G.row[v], e = C.G.row[v + 1];
     for (uint32_t p = b + lane; p < e; p += W::WIDTH) {
@@ -227,8 +288,8 @@ struct GtsComponent {
       C.G.state[p] = GIS_CYCLIC;
       C.G.state[t] = GIS_CYCLIC;
       const uint32_t cp = C.cmap[p], ct = C.cmap[t];
-      if (cp != GTS_NONE) C.cstate[cp] = GIS_CYCLIC;
-      if (ct != GTS_NONE) C.cstate[ct] = GIS_CYCLIC;
+      if (cp != GTS_NONE) M.cstate[cp - e0g] = GIS_CYCLIC;
+      if (ct != GTS_NONE) M.cstate[ct - e0g] = GIS_CYCLIC;
     }
     W::fence();
   }
@@ -241,22 +302,22 @@ struct GtsComponent {
     while (found) {
       found = false;
       calc_cc();
-      for (uint32_t s = s0 + lane; s < s1; s += W::WIDTH)
-        if (!gts_vertex_is_marked(C.vst[s])) C.vst[s] = GIS_UNVISITED;
+      for (uint32_t s = lane; s < nv; s += W::WIDTH)
+        if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
       W::fence();
       /* the ccs are visited in order; their boundaries do not matter here */
       for (uint32_t j = 0; j < nterm; ++j) {
-        const uint32_t start = W::uni(C.term[s0 + j]);
+        const uint32_t start = W::uni(M.term[j]);
         /* direction of the LAST unmarked edge, algorithms.c:533-538 */
-        const uint32_t eb = W::uni(C.coff[start]), ee = W::uni(C.coff[start + 1]);
+        const uint32_t eb = eoff(start), ee = eoff(start + 1);
         bool set_dir = false, dir = true;
         for (uint32_t base = eb; base < ee; base += W::WIDTH) {
           const uint32_t ce = base + lane;
           bool live = false;
           uint32_t fl = 0;
           if (ce < ee) {
-            live = !gts_edge_is_marked(C.cstate[ce]);
-            fl = C.cflags[ce];
+            live = !gts_edge_is_marked(M.cstate[ce]);
+            fl = M.cflags[ce];
           }
           const uint64_t mask = W::ballot(live);
           if (mask) {
@@ -265,15 +326,15 @@ struct GtsComponent {
           }
         }
         if (!set_dir) continue;
-        if (gts_vertex_is_marked((uint8_t)W::uni(C.vst[start]))) continue;
+        if (gts_vertex_is_marked((uint8_t)W::uni(M.vst[start]))) continue;
         uint32_t nvis = 0;
         const uint32_t back = detect_cycle(start, dir, nvis);
         for (uint32_t k = lane; k < nvis; k += W::WIDTH)
-          C.vst[C.visited[s0 + k]] = GIS_UNVISITED;
+          M.vst[M.visited[k]] = GIS_UNVISITED;
         W::fence();
         if (back != GTS_NONE) {
           found = true;
-          const uint32_t a = W::uni(C.cstart[back]), b = W::uni(C.cend[back]);
+          const uint32_t a = W::uni(M.cstart[back]), b = W::uni(M.cend[back]);
           mark_vertex_cyclic(a);
           mark_vertex_cyclic(b);
         }
@@ -289,20 +350,20 @@ struct GtsComponent {
   {
     const uint32_t lane = W::lane();
     float old = 0.0f;
-    if (q) old = C.distmap[nb];
+    if (q) old = M.distmap[nb];
     const bool imp = q && (unconditional || old == GTS_DIST_UNSET || old > distance);
     const bool fresh = imp && old == GTS_DIST_UNSET;
     const uint64_t im = W::ballot(imp), fm = W::ballot(fresh);
     const uint32_t ni = W::popc(im);
     if (qn + ni - qh > qcap) { err = GTS_CERR_WALKQ_OVERFLOW; return false; }
     if (imp) {
-      C.distmap[nb] = distance;
-      C.edgemap[nb] = ce;
+      M.distmap[nb] = distance;
+      M.edgemap[nb] = ce;
       const uint64_t slot = qbase + (qn + W::popc_below(im, lane)) % qcap;
       C.wq_edge[slot] = ce;
       C.wq_dist[slot] = pushd;
     }
-    if (fresh) C.touched[s0 + ntouch + W::popc_below(fm, lane)] = nb;
+    if (fresh) M.touched[ntouch + W::popc_below(fm, lane)] = nb;
     qn += ni;
     ntouch += W::popc(fm);
     W::fence();
@@ -332,10 +393,8 @@ struct GtsComponent {
   GTS_HD bool create_walk_reference(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t lane = W::lane();
-    const uint32_t gv = C.slot_v[start];
-    if (W::uni(C.G.row[gv + 1]) == W::uni(C.G.row[gv])) return true; /* :655 */
     if (qcap == 0) {
-      const uint64_t need = C.wq_factor * (uint64_t)(W::uni(C.coff[s1]) - W::uni(C.coff[s0])) + 64;
+      const uint64_t need = C.wq_factor * (uint64_t)M.ne + 64;
       const uint64_t off = W::alloc(C.wq_used, need);
       if (off + need > C.wq_pool) { err = GTS_CERR_WALKQ_OVERFLOW; return false; }
       qbase = off; qcap = need;
@@ -345,16 +404,16 @@ struct GtsComponent {
     bool ok = true;
     /* seed with the start's live edges, algorithms.c:661-679 */
     {
-      const uint32_t eb = W::uni(C.coff[start]), ee = W::uni(C.coff[start + 1]);
+      const uint32_t eb = eoff(start), ee = eoff(start + 1);
       for (uint32_t base = eb; base < ee && ok; base += W::WIDTH) {
         const uint32_t ce = base + lane;
         bool live = false;
         uint32_t nb = 0;
         int64_t d = 0;
         if (ce < ee) {
-          live = !gts_edge_is_marked(C.cstate[ce]);
-          nb = C.cend[ce];
-          d = C.cdist[ce];
+          live = !gts_edge_is_marked(M.cstate[ce]);
+          nb = M.cend[ce];
+          d = M.cdist[ce];
         }
         if (W::popc(W::ballot(live && nb == start)) >= 2)
           ok = relax_ordered(live, nb, ce, (float)d, d, true);
@@ -369,9 +428,9 @@ struct GtsComponent {
       const int64_t nd = W::uni64(C.wq_dist[slot]);
       ++qh;
       if (++pops > C.max_pops) { err = GTS_CERR_WALK_LOOP; ok = false; break; }
-      const uint32_t endv = W::uni(C.cend[pe]), from = W::uni(C.cstart[pe]);
-      const bool dir = gts_next_dir((uint8_t)W::uni((uint32_t)C.cflags[pe]));
-      const uint32_t eb = W::uni(C.coff[endv]), ee = W::uni(C.coff[endv + 1]);
+      const uint32_t endv = W::uni(M.cend[pe]), from = W::uni(M.cstart[pe]);
+      const bool dir = gts_next_dir((uint8_t)W::uni((uint32_t)M.cflags[pe]));
+      const uint32_t eb = eoff(endv), ee = eoff(endv + 1);
       bool has_s = false, has_a = false;
       for (uint32_t base = eb; base < ee && ok; base += W::WIDTH) {
         const uint32_t ce = base + lane;
@@ -379,14 +438,14 @@ struct GtsComponent {
         uint32_t nb = 0;
         float distance = 0.0f;
         if (ce < ee) {
-          live = !gts_edge_is_marked(C.cstate[ce]);
-          sense = (C.cflags[ce] & GTS_F_SENSE) != 0;
-          nb = C.cend[ce];
+          live = !gts_edge_is_marked(M.cstate[ce]);
+          sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+          nb = M.cend[ce];
           /* is_twin(edge, nextedge), algorithms.c:702: nextedge ends where
              edge started */
           q = live && sense == dir && nb != from &&
-              !gts_vertex_is_marked(C.vst[nb]);
-          distance = (float)(nd + C.cdist[ce]);
+              !gts_vertex_is_marked(M.vst[nb]);
+          distance = (float)(nd + M.cdist[ce]);
         }
         has_s |= W::ballot(live && sense) != 0;
         has_a |= W::ballot(live && !sense) != 0;
@@ -397,8 +456,8 @@ struct GtsComponent {
       }
       /* terminal bookkeeping, algorithms.c:694-695: remember the LAST pop */
       if (!(has_s && has_a)) {
-        if (W::uni(C.lastpop[endv]) == 0) C.wterm[s0 + nwt++] = endv;
-        C.lastpop[endv] = ++popseq;
+        if (W::uni(M.lastpop[endv]) == 0) M.wterm[nwt++] = endv;
+        M.lastpop[endv] = ++popseq;
         W::fence();
       }
     }
@@ -409,19 +468,19 @@ struct GtsComponent {
     uint64_t best_len = 0;
     uint32_t best_pop = 0, best_t = GTS_NONE;
     if (ok) {
-      const uint32_t limit = s1 - s0 + 1;
+      const uint32_t limit = nv + 1;
       bool loop_err = false;
       for (uint32_t k = lane; k < nwt; k += W::WIDTH) {
-        const uint32_t t = C.wterm[s0 + k];
-        uint64_t len = (uint64_t)C.cseq[start];
+        const uint32_t t = M.wterm[k];
+        uint64_t len = (uint64_t)M.cseq[start];
         uint32_t cv = t, steps = 0;
         while (cv != start) {
-          const uint32_t re = C.edgemap[cv];
-          len += (uint64_t)C.cseq[cv];
-          cv = C.cstart[re];
+          const uint32_t re = M.edgemap[cv];
+          len += (uint64_t)M.cseq[cv];
+          cv = M.cstart[re];
           if (++steps > limit) { loop_err = true; break; }
         }
-        const uint32_t lp = C.lastpop[t];
+        const uint32_t lp = M.lastpop[t];
         if (len > best_len || (len == best_len && len > 0 && lp > best_pop)) {
           best_len = len; best_pop = lp; best_t = t;
         }
@@ -443,9 +502,9 @@ struct GtsComponent {
     if (ok && best_t != GTS_NONE && best_len > cc_len) {
       uint32_t cv = best_t, n = 0;
       while (cv != start) {
-        const uint32_t re = W::uni(C.edgemap[cv]);
-        C.cc_best[s0 + n++] = re;
-        cv = W::uni(C.cstart[re]);
+        const uint32_t re = W::uni(M.edgemap[cv]);
+        M.cc_best[n++] = re;
+        cv = W::uni(M.cstart[re]);
       }
       cc_len = best_len;
       cc_n = n;
@@ -453,9 +512,9 @@ struct GtsComponent {
     }
     /* leave the maps clean for the next walk */
     for (uint32_t k = lane; k < ntouch; k += W::WIDTH)
-      C.distmap[C.touched[s0 + k]] = GTS_DIST_UNSET;
+      M.distmap[M.touched[k]] = GTS_DIST_UNSET;
     for (uint32_t k = lane; k < nwt; k += W::WIDTH)
-      C.lastpop[C.wterm[s0 + k]] = 0;
+      M.lastpop[M.wterm[k]] = 0;
     W::fence();
     return ok;
   }
@@ -482,18 +541,18 @@ struct GtsComponent {
   GTS_HD bool create_walk_fast(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t lane = W::lane();
-    uint32_t *R = C.queue, *TQ = C.visited, *indeg = C.st_v;
-    uint8_t *orient = C.st_dir;
+    uint32_t *R = M.queue, *TQ = M.visited, *indeg = M.st_v;
+    uint8_t *orient = M.st_dir;
     /* all live edges of the start must leave in one direction */
     bool has_s = false, has_a = false;
     {
-      const uint32_t eb = W::uni(C.coff[start]), ee = W::uni(C.coff[start + 1]);
+      const uint32_t eb = eoff(start), ee = eoff(start + 1);
       for (uint32_t base = eb; base < ee; base += W::WIDTH) {
         const uint32_t ce = base + lane;
         bool live = false, sense = false;
         if (ce < ee) {
-          live = !gts_edge_is_marked(C.cstate[ce]);
-          sense = (C.cflags[ce] & GTS_F_SENSE) != 0;
+          live = !gts_edge_is_marked(M.cstate[ce]);
+          sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
         }
         has_s |= W::ballot(live && sense) != 0;
         has_a |= W::ballot(live && !sense) != 0;
@@ -504,27 +563,27 @@ struct GtsComponent {
     /* pass 1: reachable states, in-degrees */
     uint32_t nr = 1, rh = 0;
     bool bad = false;
-    R[s0] = start;
+    R[0] = start;
     orient[start] = has_s ? 2 : 1;              /* direction + 1 */
     indeg[start] = 0;
     W::fence();
     while (rh < nr && !bad) {
-      const uint32_t u = W::uni(R[s0 + rh]);
+      const uint32_t u = W::uni(R[rh]);
       ++rh;
       const bool du = W::uni((uint32_t)orient[u]) == 2;
-      const uint32_t eb = W::uni(C.coff[u]), ee = W::uni(C.coff[u + 1]);
+      const uint32_t eb = eoff(u), ee = eoff(u + 1);
       for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
         const uint32_t ce = base + lane;
         bool arc = false, fresh = false, clash = false;
         uint32_t v = 0, od = 0;
         if (ce < ee) {
-          const uint32_t fl = C.cflags[ce];
-          arc = !gts_edge_is_marked(C.cstate[ce]) && ((fl & GTS_F_SENSE) != 0) == du;
+          const uint32_t fl = M.cflags[ce];
+          arc = !gts_edge_is_marked(M.cstate[ce]) && ((fl & GTS_F_SENSE) != 0) == du;
           if (arc) {
-            v = C.cend[ce];
+            v = M.cend[ce];
             od = gts_next_dir((uint8_t)fl) ? 2u : 1u;
             const uint32_t ov = orient[v];
-            clash = v == u || v == start || gts_vertex_is_marked(C.vst[v]) ||
+            clash = v == u || v == start || gts_vertex_is_marked(M.vst[v]) ||
                     (ov != 0 && ov != od);
             fresh = ov == 0;
           }
@@ -535,7 +594,7 @@ struct GtsComponent {
           if (fresh) {
             orient[v] = (uint8_t)od;
             indeg[v] = 1;
-            R[s0 + nr + W::popc_below(fm, lane)] = v;
+            R[nr + W::popc_below(fm, lane)] = v;
           } else
             indeg[v] = indeg[v] + 1;
         }
@@ -547,40 +606,40 @@ struct GtsComponent {
     uint32_t nq = 1, qh2 = 0, processed = 0, nbest = 0, best_t = GTS_NONE;
     uint64_t best_len = 0;
     if (!bad) {
-      TQ[s0] = start;
-      C.plen[start] = (uint64_t)C.cseq[start];
+      TQ[0] = start;
+      M.plen[start] = (uint64_t)M.cseq[start];
       W::fence();
       while (qh2 < nq && !bad) {
-        const uint32_t u = W::uni(TQ[s0 + qh2]);
+        const uint32_t u = W::uni(TQ[qh2]);
         ++qh2; ++processed;
         const bool du = W::uni((uint32_t)orient[u]) == 2;
-        const int64_t ndu = u == start ? 0 : W::uni64(C.nd[u]);
-        const uint64_t plu = (uint64_t)W::uni64((int64_t)C.plen[u]);
-        if (u != start && W::uni((uint32_t)C.tight[u]) != 1) { bad = true; break; }
-        const uint32_t eb = W::uni(C.coff[u]), ee = W::uni(C.coff[u + 1]);
+        const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
+        const uint64_t plu = (uint64_t)W::uni64((int64_t)M.plen[u]);
+        if (u != start && W::uni((uint32_t)M.tight[u]) != 1) { bad = true; break; }
+        const uint32_t eb = eoff(u), ee = eoff(u + 1);
         bool us = false, ua = false;
         for (uint32_t base = eb; base < ee; base += W::WIDTH) {
           const uint32_t ce = base + lane;
           bool live = false, sense = false, arc = false, ready = false;
           uint32_t v = 0;
           if (ce < ee) {
-            live = !gts_edge_is_marked(C.cstate[ce]);
-            sense = (C.cflags[ce] & GTS_F_SENSE) != 0;
+            live = !gts_edge_is_marked(M.cstate[ce]);
+            sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
             arc = live && sense == du;
             if (arc) {
-              v = C.cend[ce];
-              const int64_t w = C.cdist[ce];
+              v = M.cend[ce];
+              const int64_t w = M.cdist[ce];
               const float cand = u == start ? (float)w : (float)(ndu + w);
-              const float old = C.distmap[v];
+              const float old = M.distmap[v];
               if (old == GTS_DIST_UNSET || old > cand) {
-                C.distmap[v] = cand;
-                C.edgemap[v] = ce;
-                C.nd[v] = u == start ? w : (int64_t)cand;
-                C.plen[v] = plu + (uint64_t)C.cseq[v];
-                C.tight[v] = 1;
+                M.distmap[v] = cand;
+                M.edgemap[v] = ce;
+                M.nd[v] = u == start ? w : (int64_t)cand;
+                M.plen[v] = plu + (uint64_t)M.cseq[v];
+                M.tight[v] = 1;
               } else if (old == cand) {
-                const uint8_t t = C.tight[v];
-                if (t < 255) C.tight[v] = t + 1;
+                const uint8_t t = M.tight[v];
+                if (t < 255) M.tight[v] = t + 1;
               }
               const uint32_t d = indeg[v] - 1;
               indeg[v] = d;
@@ -590,7 +649,7 @@ struct GtsComponent {
           us |= W::ballot(live && sense) != 0;
           ua |= W::ballot(live && !sense) != 0;
           const uint64_t rm = W::ballot(ready);
-          if (ready) TQ[s0 + nq + W::popc_below(rm, lane)] = v;
+          if (ready) TQ[nq + W::popc_below(rm, lane)] = v;
           nq += W::popc(rm);
           W::fence();
         }
@@ -606,19 +665,19 @@ struct GtsComponent {
     if (!bad && best_t != GTS_NONE && best_len > cc_len) {
       uint32_t cv = best_t, n = 0;
       while (cv != start) {
-        const uint32_t re = W::uni(C.edgemap[cv]);
-        C.cc_best[s0 + n++] = re;
-        cv = W::uni(C.cstart[re]);
+        const uint32_t re = W::uni(M.edgemap[cv]);
+        M.cc_best[n++] = re;
+        cv = W::uni(M.cstart[re]);
       }
       cc_len = best_len;
       cc_n = n;
     }
     /* restore the scratch */
     for (uint32_t k = lane; k < nr; k += W::WIDTH) {
-      const uint32_t v = R[s0 + k];
+      const uint32_t v = R[k];
       orient[v] = 0;
-      C.distmap[v] = GTS_DIST_UNSET;
-      C.tight[v] = 0;
+      M.distmap[v] = GTS_DIST_UNSET;
+      M.tight[v] = 0;
     }
     W::fence();
     return !bad;
@@ -626,7 +685,7 @@ struct GtsComponent {
 
   GTS_HD bool create_walk(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
-    const uint32_t gv = C.slot_v[start];
+    const uint32_t gv = C.slot_v[s0 + start];
     if (W::uni(C.G.row[gv + 1]) == W::uni(C.G.row[gv])) return true; /* :655 */
     const uint64_t t0 = W::clock();
     if (C.fast_walks && create_walk_fast(start, cc_len, cc_n)) {
@@ -645,42 +704,42 @@ struct GtsComponent {
   {
     const uint32_t lane = W::lane();
     calc_cc();
-    for (uint32_t s = s0 + lane; s < s1; s += W::WIDTH) { C.st_dir[s] = 0; C.tight[s] = 0; }
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }
     W::fence();
-    const uint32_t *ccoff = ccoffs();
+    const uint32_t *ccoff = M.ccoff;
     for (uint32_t i = 0; i < ncc && !err; ++i) {
       const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
       if (te - tb == 1) {                    /* algorithms.c:790-807 */
-        const uint32_t v = W::uni(C.term[s0 + tb]);
-        const uint32_t eb = W::uni(C.coff[v]), ee = W::uni(C.coff[v + 1]);
+        const uint32_t v = W::uni(M.term[tb]);
+        const uint32_t eb = eoff(v), ee = eoff(v + 1);
         bool any_live = false;
         for (uint32_t base = eb; base < ee; base += W::WIDTH) {
           const uint32_t ce = base + lane;
-          const bool live = ce < ee && !gts_edge_is_marked(C.cstate[ce]);
+          const bool live = ce < ee && !gts_edge_is_marked(M.cstate[ce]);
           any_live |= W::ballot(live) != 0;
         }
-        if (!any_live) C.vst[v] = GIS_SCAFFOLD;
+        if (!any_live) M.vst[v] = GIS_SCAFFOLD;
         W::fence();
       }
       if (te - tb > 1) {
         uint64_t cc_len = 0;
         uint32_t cc_n = 0;
         for (uint32_t j = tb; j < te; ++j)
-          if (!create_walk(W::uni(C.term[s0 + j]), cc_len, cc_n)) break;
+          if (!create_walk(W::uni(M.term[j]), cc_len, cc_n)) break;
         if (err) break;
         /* mark the best walk, algorithms.c:835-848 (a walk without edges is
            undefined behaviour there and is left unmarked here) */
         if (cc_n > 0) {
           for (uint32_t k = lane; k < cc_n; k += W::WIDTH) {
-            const uint32_t ce = C.cc_best[s0 + k];
-            const uint32_t p = C.cgpos[ce], t = C.G.twin[p];
-            C.cstate[ce] = GIS_SCAFFOLD;
+            const uint32_t ce = M.cc_best[k];
+            const uint32_t p = C.cgpos[e0g + ce], t = C.G.twin[p];
+            M.cstate[ce] = GIS_SCAFFOLD;
             C.G.state[p] = GIS_SCAFFOLD;
             C.G.state[t] = GIS_SCAFFOLD;
             const uint32_t ct = C.cmap[t];
-            if (ct != GTS_NONE) C.cstate[ct] = GIS_SCAFFOLD;
-            C.vst[C.cend[ce]] = GIS_SCAFFOLD;
-            C.vst[C.cstart[ce]] = GIS_SCAFFOLD;
+            if (ct != GTS_NONE) M.cstate[ct - e0g] = GIS_SCAFFOLD;
+            M.vst[M.cend[ce]] = GIS_SCAFFOLD;
+            M.vst[M.cstart[ce]] = GIS_SCAFFOLD;
           }
           W::fence();
         }
@@ -696,11 +755,11 @@ struct GtsComponent {
     const uint64_t t1 = W::clock();
     if (mode == GTS_MODE_MAKESCAFFOLD) makescaffold();
     const uint64_t t2 = W::clock();
-    for (uint32_t s = s0 + lane; s < s1; s += W::WIDTH) {
-      const uint8_t st = C.vst[s];
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) {
+      const uint8_t st = M.vst[s];
       /* removecycles leaves every unmarked vertex UNVISITED (algorithms.c:
          513-517, 550-553); makescaffold leaves VISITED or SCAFFOLD */
-      C.G.vstate[C.slot_v[s]] = st;
+      C.G.vstate[C.slot_v[s0 + s]] = st;
     }
     if (lane == 0) {
       C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow;

@@ -33,6 +33,8 @@
 #include "gts_filter.hpp"
 #include "gts_prims.hpp"
 
+#define GTS_NKLASS 4
+
 /* ------------------------------------------------------------------ */
 /* engine object                                                       */
 
@@ -62,7 +64,7 @@ struct GtsgEngine {
   /* options */
   int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
   int64_t walk_pool_entries = 1ll << 26;
-  int64_t fast_walks = 1;
+  int64_t fast_walks = 1, lds_components = 1;
   bool profile = false;
   /* profiling */
   struct Pending { const char *name; hipEvent_t a, b; };
@@ -564,6 +566,14 @@ __global__ void k_slot_finish(const uint32_t *labels, const uint32_t *cidx,
   cseq[s] = seq_len[v];
   vst[s] = vstate[v];
 }
+/* first slot of the component of every slot */
+__global__ void k_slot_bases(const uint32_t *head, const uint32_t *cidx,
+                             const uint32_t *comp_off, uint32_t *slot_base,
+                             uint32_t nslots)
+{
+  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nslots) slot_base[s] = comp_off[cidx[s] + head[s] - 1];
+}
 /* an edge enters the compact graph if it or its twin is live: marking a walk
    edge's twin SCAFFOLD (algorithms.c:842-845) revives a marked twin */
 __global__ void k_compact_count(GtsGraphView G, const uint8_t *live,
@@ -580,6 +590,7 @@ __global__ void k_compact_count(GtsGraphView G, const uint8_t *live,
 }
 __global__ void k_compact_fill(GtsGraphView G, const uint8_t *live,
                                const uint32_t *slot_v, const uint32_t *slot_of,
+                               const uint32_t *slot_base,
                                const uint32_t *coff, uint32_t *cstart,
                                uint32_t *cend, int64_t *cdist, uint8_t *cflags,
                                uint32_t *cgpos, uint8_t *cstate, uint32_t *cmap,
@@ -591,7 +602,7 @@ __global__ void k_compact_fill(GtsGraphView G, const uint8_t *live,
   uint32_t k = coff[s];
   for (uint32_t p = G.row[v]; p < G.row[v + 1]; ++p)
     if (live[p] || live[G.twin[p]]) {
-      cstart[k] = (uint32_t)s; cend[k] = slot_of[G.end[p]];
+      cstart[k] = (uint32_t)s - slot_base[s]; cend[k] = slot_of[G.end[p]] - slot_base[s];
       cdist[k] = G.dist[p]; cflags[k] = G.flags[p]; cgpos[k] = p;
       cstate[k] = G.state[p]; cmap[p] = k;
       ++k;
@@ -633,23 +644,90 @@ struct GtsWave64 {
   }
 };
 
-/* one wavefront per component; `order` lists components largest first */
+/* one wavefront per component; `order` lists the components by decreasing
+   LDS footprint, [first, first + count) is the slice of this launch.
+   Global-memory variant: any component size. */
 __global__ void __launch_bounds__(GTS_WAVE)
-k_components(GtsCompView C, const uint32_t *order, int mode)
+k_components(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode)
 {
-  const uint32_t i = blockIdx.x;
-  if (i >= C.ncomp) return;
-  const uint32_t c = order ? order[i] : i;
-  GtsComponent<GtsWave64> prog(C, c);
+  if (blockIdx.x >= count) return;
+  const uint32_t c = order[first + blockIdx.x];
+  const GtsCompMem M = GtsComponent<GtsWave64>::global_mem(C, c);
+  GtsComponent<GtsWave64> prog(C, M, c);
   prog.run(mode);
 }
-__global__ void k_comp_size_keys(const uint32_t *comp_off, uint32_t *keys,
-                                 uint32_t *vals, uint32_t ncomp)
+
+/* LDS-resident variant: the launcher guarantees gts_comp_lds_bytes(nv, ne) <=
+   the dynamic LDS size of the launch.  The wavefront stages the component's
+   compact graph and vertex states with coalesced loads, initialises the
+   scratch in LDS and runs the same program on LDS base pointers; marks still
+   go to the global graph as they are set, vertex states are written back by
+   run(). */
+template <typename T>
+__device__ __forceinline__ T *lds_carve(char *&p, uint32_t count)
+{
+  T *r = (T *)p;
+  p += ((count * (uint32_t)sizeof(T) + 15u) / 16u) * 16u;
+  return r;
+}
+__global__ void __launch_bounds__(GTS_WAVE)
+k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x >= count) return;
+  const uint32_t c = order[first + blockIdx.x];
+  const GtsCompMem G0 = GtsComponent<GtsWave64>::global_mem(C, c);
+  const uint32_t nv = G0.nv, ne = G0.ne, lane = threadIdx.x;
+  char *p = smem;
+  GtsCompMem M;
+  M.nv = nv; M.ne = ne; M.e0 = 0;
+  uint32_t *coff = lds_carve<uint32_t>(p, nv + 1);
+  M.ccoff = lds_carve<uint32_t>(p, nv + 1);
+  M.queue = lds_carve<uint32_t>(p, nv); M.term = lds_carve<uint32_t>(p, nv);
+  M.visited = lds_carve<uint32_t>(p, nv); M.st_v = lds_carve<uint32_t>(p, nv);
+  M.st_par = lds_carve<uint32_t>(p, nv); M.st_cur = lds_carve<uint32_t>(p, nv);
+  M.edgemap = lds_carve<uint32_t>(p, nv); M.lastpop = lds_carve<uint32_t>(p, nv);
+  M.wterm = lds_carve<uint32_t>(p, nv); M.touched = lds_carve<uint32_t>(p, nv);
+  M.cc_best = lds_carve<uint32_t>(p, nv); M.distmap = lds_carve<float>(p, nv);
+  int64_t *cseq = lds_carve<int64_t>(p, nv);
+  M.nd = lds_carve<int64_t>(p, nv); M.plen = lds_carve<uint64_t>(p, nv);
+  M.vst = lds_carve<uint8_t>(p, nv); M.st_dir = lds_carve<uint8_t>(p, nv);
+  M.tight = lds_carve<uint8_t>(p, nv);
+  uint32_t *cstart = lds_carve<uint32_t>(p, ne), *cend = lds_carve<uint32_t>(p, ne);
+  int64_t *cdist = lds_carve<int64_t>(p, ne);
+  uint8_t *cflags = lds_carve<uint8_t>(p, ne);
+  M.cstate = lds_carve<uint8_t>(p, ne);
+  for (uint32_t i = lane; i <= nv; i += GTS_WAVE) coff[i] = G0.coff[i] - G0.e0;
+  for (uint32_t i = lane; i < nv; i += GTS_WAVE) {
+    cseq[i] = G0.cseq[i]; M.vst[i] = G0.vst[i];
+    M.lastpop[i] = 0; M.distmap[i] = GTS_DIST_UNSET; M.st_dir[i] = 0; M.tight[i] = 0;
+  }
+  for (uint32_t i = lane; i < ne; i += GTS_WAVE) {
+    cstart[i] = G0.cstart[i]; cend[i] = G0.cend[i]; cdist[i] = G0.cdist[i];
+    cflags[i] = G0.cflags[i]; M.cstate[i] = G0.cstate[i];
+  }
+  M.coff = coff; M.cseq = cseq; M.cstart = cstart; M.cend = cend; M.cdist = cdist;
+  M.cflags = cflags;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  GtsComponent<GtsWave64> prog(C, M, c);
+  prog.run(mode);
+}
+/* LDS footprint of every component as a descending sort key, and how many
+   components fit each size class */
+__global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
+                                uint32_t *keys, uint32_t *vals, uint32_t ncomp,
+                                const uint32_t *klass, uint32_t nklass,
+                                uint32_t *klass_count)
 {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncomp) return;
-  keys[c] = ~(comp_off[c + 1] - comp_off[c]);   /* ascending sort = largest first */
+  const uint32_t s0 = comp_off[c], s1 = comp_off[c + 1];
+  const uint32_t need = gts_comp_lds_bytes(s1 - s0, coff[s1] - coff[s0]);
+  keys[c] = ~need;   /* ascending sort = largest first */
   vals[c] = (uint32_t)c;
+  uint32_t k = 0;
+  while (k < nklass && need > klass[k]) ++k;   /* klass ascending; nklass = global */
+  atomicAdd(&klass_count[k], 1u);
 }
 __global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
                                uint32_t *out /* [0]=overflow, [1]=loop */)
@@ -770,6 +848,11 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
     e->own_stream = true;
   }
   if (hipMalloc((void **)&e->d_scalars, 1024) != hipSuccess) { delete e; return GTSG_ENOMEM; }
+  if (hipFuncSetAttribute((const void *)k_components_lds,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
+    fprintf(stderr, "gtsg_create: cannot raise the dynamic LDS limit to 160 KiB\n");
+    delete e; return GTSG_EHIP;
+  }
   *out = e;
   return 0;
 }
@@ -808,6 +891,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "max_walk_pops") && value >= 1) e->max_walk_pops = value;
   else if (!strcmp(name, "hub_degree") && value >= 1) e->hub_degree = value;
   else if (!strcmp(name, "fast_walks")) e->fast_walks = value != 0;
+  else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "profile")) e->profile = value != 0;
   else return fail(e, GTSG_EINVAL, "unknown option %s", name);
   return 0;
@@ -1113,6 +1197,9 @@ static int run_components(GtsgEngine *e, int mode)
     LAUNCH("comp_slot_finish", k_slot_finish, nblk(nslots), GTS_BLOCK, labels, cidx, slot_v,
            e->seq_len, e->vstate, comp_off, slot_of, cseq, vst, nslots);
     LAUNCH("fill", k_fill<uint32_t>, 1, 1, comp_off + ncomp, nslots, (uint64_t)1);
+    PALLOC(slot_base, uint32_t, nslots);
+    LAUNCH("comp_slot_bases", k_slot_bases, nblk(nslots), GTS_BLOCK, head, cidx, comp_off,
+           slot_base, nslots);
     PALLOC(coff, uint32_t, (size_t)nslots + 1);
     LAUNCH("comp_compact_count", k_compact_count, nblk(nslots), GTS_BLOCK, G, live, slot_v,
            coff, nslots);
@@ -1126,7 +1213,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cmap, uint32_t, (size_t)m + 1);
     HIPCHK(hipMemsetAsync(cmap, 0xFF, ((size_t)m + 1) * 4, e->st));
     LAUNCH("comp_compact_fill", k_compact_fill, nblk(nslots), GTS_BLOCK, G, live, slot_v,
-           slot_of, coff, cstart, cend, cdist, cflags, cgpos, cstate, cmap, nslots);
+           slot_of, slot_base, coff, cstart, cend, cdist, cflags, cgpos, cstate, cmap, nslots);
     /* walk queue pool of the reference search */
     const uint64_t wq_pool = (uint64_t)pool_entries;
     PALLOC(wq_edge, uint32_t, wq_pool + 1); PALLOC(wq_dist, int64_t, wq_pool + 1);
@@ -1151,14 +1238,22 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemsetAsync(cerr, 0, (size_t)ncomp * 4, e->st));
     LAUNCH("fill", k_fill<float>, nblk(nslots), GTS_BLOCK, s_distmap, GTS_DIST_UNSET,
            (uint64_t)nslots);
-    /* largest components first */
-    LAUNCH("comp_size_keys", k_comp_size_keys, nblk(ncomp), GTS_BLOCK, comp_off, ok0, ov0, ncomp);
+    /* components by decreasing LDS footprint; size classes of the LDS launches */
+    static const uint32_t klass_h[GTS_NKLASS] = {4096, 16384, 65536, 163840};
+    uint32_t *klass_d = e->d_scalars + 64, *klass_count = e->d_scalars + 72;
+    HIPCHK(hipMemcpyAsync(klass_d, klass_h, sizeof klass_h, hipMemcpyHostToDevice, e->st));
+    HIPCHK(hipMemsetAsync(klass_count, 0, (GTS_NKLASS + 1) * 4, e->st));
+    LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
+           ncomp, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count);
     const uint32_t *order;
     {
       int shifts[4] = {0, 8, 16, 24};
       const int where = gts_radix_sort<uint32_t>(ok0, ov0, ok1, ov1, ncomp, shifts, 4, otmp, e->st);
       order = where ? ov1 : ov0;
     }
+    uint32_t kcount[GTS_NKLASS + 1];
+    HIPCHK(hipMemcpyAsync(kcount, klass_count, sizeof kcount, hipMemcpyDeviceToHost, e->st));
+    if ((rc = sync_stream(e))) return rc;
     HIPCHK(hipMemsetAsync(e->d_scalars + 12, 0, 16, e->st));
     LAUNCH("comp_max_size", k_max_u32_diff, nblk(ncomp), GTS_BLOCK, comp_off, ncomp,
            e->d_scalars + 14);
@@ -1174,8 +1269,35 @@ static int run_components(GtsgEngine *e, int mode)
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
     C.fast_walks = (int)e->fast_walks; C.nd = s_nd; C.plen = s_plen; C.tight = s_tight;
     C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat;
-    LAUNCH(mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold" : "components_removecycles",
-           k_components, ncomp, GTS_WAVE, C, order, mode);
+    {
+      /* order[] is sorted by decreasing footprint: the global-memory class
+         (larger than every LDS class, or all if LDS is disabled) comes first,
+         then the LDS classes from the largest to the smallest */
+      const char *kname = mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold"
+                                                        : "components_removecycles";
+      uint32_t first = 0;
+      const uint32_t nk = e->lds_components ? GTS_NKLASS : 0;
+      if (kcount[nk]) {
+        LAUNCH(kname, k_components, kcount[nk], GTS_WAVE, C, order, first, kcount[nk], mode);
+        first += kcount[nk];
+      }
+      for (int k = (int)nk - 1; k >= 0; --k) {
+        if (!kcount[k]) continue;
+        hipEvent_t _a = nullptr, _b = nullptr;
+        if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, e->st); }
+        k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], e->st>>>(C, order, first, kcount[k], mode);
+        static const char *const kn[2][GTS_NKLASS] = {
+            {"components_removecycles_lds4k", "components_removecycles_lds16k",
+             "components_removecycles_lds64k", "components_removecycles_lds160k"},
+            {"components_makescaffold_lds4k", "components_makescaffold_lds16k",
+             "components_makescaffold_lds64k", "components_makescaffold_lds160k"}};
+        if (e->profile) { hipEventRecord(_b, e->st);
+                          e->pending.push_back({kn[mode == GTS_MODE_MAKESCAFFOLD][k], _a, _b}); }
+        e->stats[std::string("components_lds_class") + char('0' + k)] = kcount[k];
+        first += kcount[k];
+      }
+      e->stats["components_global_mem"] = kcount[nk];
+    }
     LAUNCH("comp_count_errors", k_count_errors, nblk(ncomp), GTS_BLOCK, cerr, ncomp,
            e->d_scalars + 12);
     HIPCHK(hipMemsetAsync(e->d_scalars + 16, 0, 16, e->st));

@@ -109,7 +109,8 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      "max_walk_pops" (default 2^32),
      "hub_degree" (default 32), "profile" (0/1),
      "fast_walks" (default 1; 0 forces the reference's label-correcting search
-     for every walk) */
+     for every walk), "lds_components" (default 1; 0 runs every component
+     from global memory) */
 
 /* per-kernel timing collected with hipEvents on the engine's stream while
    option "profile" is 1.  Fills up to cap entries, returns the number of

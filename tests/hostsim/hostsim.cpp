@@ -191,7 +191,8 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
     cseq[s] = seq_len[v]; vst[s] = vstate[v];
     for (uint32_t p = row[v]; p < row[v + 1]; p++)
       if (incl(p)) {
-        cstart[k] = s; cend[k] = slot_of[end[p]]; cdist[k] = dist[p];
+        cstart[k] = s - lab_first[label[v]]; cend[k] = slot_of[end[p]] - lab_first[label[v]];
+        cdist[k] = dist[p];
         cflags[k] = flags[p]; cstate[k] = state[p]; cgpos[k] = p; cmap[p] = k; k++;
       }
   }
@@ -227,7 +228,8 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   C.stat_fast = sf.data(); C.stat_slow = ss.data(); C.tstat = tstat.data();
   uint32_t nerr = 0;
   for (uint32_t c = 0; c < ncomp; c++) {
-    GtsComponent<GtsWave1> prog(C, c);
+    GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
+    GtsComponent<GtsWave1> prog(C, mem, c);
     prog.run(mode);
     if (cerr[c]) nerr++;
   }

@@ -111,6 +111,15 @@ def test_reference_search_for_every_walk(seed):
     assert eng.stat("fast_walks") == 0 and eng.stat("slow_walks") > 0
 
 
+def test_global_memory_components_match_lds_components():
+    g = make_inputs(30000, 8, p_chimeric=0.02)
+    eng, _ = run_pipeline(g, lds_components=0)
+    assert eng.stat("components_global_mem") == eng.stat("components")
+    eng2, _ = run_pipeline(g)
+    assert eng2.stat("components_global_mem") < eng2.stat("components")
+    assert eng.digest() == eng2.digest()
+
+
 def test_fast_walks_fall_back_on_ties():
     g = make_inputs(3000, 21, dist_range_small=True, contig_median=300)
     eng, _ = run_pipeline(g)
