@@ -422,10 +422,25 @@ struct GtsComponent {
       }
     }
     uint64_t pops = 0;
+    /* the FIFO is read in batches: every lane fetches one of the next (up to
+       WIDTH) queued nodes with one coalesced load, the nodes are then handed
+       out by cross-lane reads.  Entries pushed meanwhile lie behind the batch. */
+    uint64_t bbase = 0, bend = 0;
+    uint32_t b_edge = 0;
+    int64_t b_dist = 0;
     while (ok && qh < qn) {
-      const uint64_t slot = qbase + qh % qcap;
-      const uint32_t pe = W::uni(C.wq_edge[slot]);
-      const int64_t nd = W::uni64(C.wq_dist[slot]);
+      if (qh == bend) {
+        const uint64_t cnt = qn - qh < W::WIDTH ? qn - qh : W::WIDTH;
+        if (lane < cnt) {
+          const uint64_t slot = qbase + (qh + lane) % qcap;
+          b_edge = C.wq_edge[slot];
+          b_dist = C.wq_dist[slot];
+        }
+        bbase = qh; bend = qh + cnt;
+      }
+      const uint32_t bl = (uint32_t)(qh - bbase);
+      const uint32_t pe = W::shfl(b_edge, bl);
+      const int64_t nd = (int64_t)W::shfl64((uint64_t)b_dist, bl);
       ++qh;
       if (++pops > C.max_pops) { err = GTS_CERR_WALK_LOOP; ok = false; break; }
       const uint32_t endv = W::uni(M.cend[pe]), from = W::uni(M.cstart[pe]);

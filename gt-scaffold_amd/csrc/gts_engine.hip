@@ -26,14 +26,14 @@
 #include <string>
 #include <vector>
 
+#define GTS_NKLASS 4
+
 #include "../../include/gt_scaffold_hip.h"
 #include "gts_amb_host.h"
 #include "gts_component.hpp"
 #include "gts_defs.h"
 #include "gts_filter.hpp"
 #include "gts_prims.hpp"
-
-#define GTS_NKLASS 4
 
 /* ------------------------------------------------------------------ */
 /* engine object                                                       */
@@ -42,6 +42,8 @@ struct GtsgEngine {
   int device = 0;
   hipStream_t st = nullptr;
   bool own_stream = false;
+  hipStream_t side[GTS_NKLASS] = {nullptr, nullptr, nullptr, nullptr};  /* class launches */
+  hipEvent_t ev_fork = nullptr, ev_join[GTS_NKLASS] = {nullptr, nullptr, nullptr, nullptr};
   std::string err;
   /* vertices */
   uint32_t n = 0;
@@ -848,6 +850,12 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
     e->own_stream = true;
   }
   if (hipMalloc((void **)&e->d_scalars, 1024) != hipSuccess) { delete e; return GTSG_ENOMEM; }
+  for (int k = 0; k < GTS_NKLASS; ++k)
+    if (hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming) != hipSuccess) {
+      delete e; return GTSG_EHIP;
+    }
+  if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { delete e; return GTSG_EHIP; }
   if (hipFuncSetAttribute((const void *)k_components_lds,
                           hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
     fprintf(stderr, "gtsg_create: cannot raise the dynamic LDS limit to 160 KiB\n");
@@ -877,6 +885,11 @@ void gtsg_destroy(GtsgEngine *e)
   void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->pool, e->d_scalars};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto ev : e->free_events) hipEventDestroy(ev);
+  for (int k = 0; k < GTS_NKLASS; ++k) {
+    if (e->side[k]) hipStreamDestroy(e->side[k]);
+    if (e->ev_join[k]) hipEventDestroy(e->ev_join[k]);
+  }
+  if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->own_stream) hipStreamDestroy(e->st);
   delete e;
 }
@@ -1277,22 +1290,29 @@ static int run_components(GtsgEngine *e, int mode)
                                                         : "components_removecycles";
       uint32_t first = 0;
       const uint32_t nk = e->lds_components ? GTS_NKLASS : 0;
+      HIPCHK(hipEventRecord(e->ev_fork, e->st));
       if (kcount[nk]) {
         LAUNCH(kname, k_components, kcount[nk], GTS_WAVE, C, order, first, kcount[nk], mode);
         first += kcount[nk];
       }
+      /* the size classes are independent: fork them onto side streams so the
+         launches overlap (each has its own tail), join before the statistics */
       for (int k = (int)nk - 1; k >= 0; --k) {
         if (!kcount[k]) continue;
-        hipEvent_t _a = nullptr, _b = nullptr;
-        if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, e->st); }
-        k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], e->st>>>(C, order, first, kcount[k], mode);
         static const char *const kn[2][GTS_NKLASS] = {
             {"components_removecycles_lds4k", "components_removecycles_lds16k",
              "components_removecycles_lds64k", "components_removecycles_lds160k"},
             {"components_makescaffold_lds4k", "components_makescaffold_lds16k",
              "components_makescaffold_lds64k", "components_makescaffold_lds160k"}};
-        if (e->profile) { hipEventRecord(_b, e->st);
+        hipStream_t ss = e->side[k];
+        HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
+        hipEvent_t _a = nullptr, _b = nullptr;
+        if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
+        k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode);
+        if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({kn[mode == GTS_MODE_MAKESCAFFOLD][k], _a, _b}); }
+        HIPCHK(hipEventRecord(e->ev_join[k], ss));
+        HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
         e->stats[std::string("components_lds_class") + char('0' + k)] = kcount[k];
         first += kcount[k];
       }
