@@ -179,7 +179,10 @@ def main():
                        **{k: eng.stat(k) for k in
                           ("us_sum_removecycles", "us_max_removecycles", "us_sum_makescaffold_other",
                            "us_max_makescaffold_other", "us_sum_walks_fast", "us_max_walks_fast",
-                           "us_sum_walks_reference", "us_max_walks_reference")}),
+                           "us_sum_walks_reference", "us_max_walks_reference")},
+                       slowest_reference_components=[
+                           {k: eng.stat("top%d_%s" % (r, k)) for k in ("size", "ref_walks", "ref_us", "ref_pops")}
+                           for r in range(3)]),
                    kernels_ms_per_step={k: round(v[1] / args.steps, 3) for k, v in
                                         sorted(kt.items(), key=lambda kv: -kv[1][1])[:12]})
         if not args.no_cpu_baseline:

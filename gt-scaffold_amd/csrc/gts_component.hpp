@@ -83,8 +83,9 @@ struct GtsCompView {
   uint64_t *plen;            /* slot -> contig length of the tree path */
   uint8_t *tight;            /* slot -> number of tight in-arcs (saturating) */
   uint32_t *stat_fast, *stat_slow;  /* per component: walks by path taken */
-  uint64_t *tstat;           /* per component x4: ticks in removecycles, makescaffold
-                                outside walks, fast walks, reference walks */
+  uint64_t *tstat;           /* per component x5: ticks in removecycles, makescaffold
+                                outside walks, fast walks, reference walks; pops of
+                                the reference walks */
 };
 
 /* base pointers of ONE component, component-local indices */
@@ -135,12 +136,12 @@ struct GtsComponent {
   uint64_t qbase, qcap, qh, qn;
   uint32_t ntouch;
   uint32_t nfast, nslow;
-  uint64_t tfast, tslow;
+  uint64_t tfast, tslow, npops;
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMem &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -400,7 +401,7 @@ struct GtsComponent {
       qbase = off; qcap = need;
     }
     qh = 0; qn = 0; ntouch = 0;
-    uint32_t nwt = 0, popseq = 0;
+    uint32_t nwt = 0;
     bool ok = true;
     /* seed with the start's live edges, algorithms.c:661-679 */
     {
@@ -421,61 +422,147 @@ struct GtsComponent {
           ok = relax_distinct(live, nb, ce, (float)d, d, true);
       }
     }
+    /* Main loop, algorithms.c:681-728, vectorised without changing its
+       sequential meaning.  The FIFO is consumed in order; the out-arcs of
+       consecutive queued nodes are laid out across the lanes (node after node,
+       arc after arc: exactly the order in which the reference relaxes them).
+       A candidate succeeds iff it beats the label its target had before the
+       step AND every earlier candidate of the step for the same target (a
+       per-target prefix minimum over the lanes holding that target); every
+       success pushes a node, in lane order, and the last success per target
+       leaves label and edgemap.  Nodes pushed during a step lie behind the
+       nodes it consumes, as in the reference. */
     uint64_t pops = 0;
-    /* the FIFO is read in batches: every lane fetches one of the next (up to
-       WIDTH) queued nodes with one coalesced load, the nodes are then handed
-       out by cross-lane reads.  Entries pushed meanwhile lie behind the batch. */
-    uint64_t bbase = 0, bend = 0;
-    uint32_t b_edge = 0;
-    int64_t b_dist = 0;
+    uint64_t wbase = 0, wend = 0;      /* queue window held in registers */
+    uint32_t w_edge = 0;
+    int64_t w_dist = 0;
+    uint32_t cur_off = 0;              /* arcs of node qh already relaxed */
+    bool carry_s = false, carry_a = false;
+    const uint32_t tbits = 32u - W::clz32(nv > 1 ? nv - 1 : 1);
     while (ok && qh < qn) {
-      if (qh == bend) {
+      if (qh == wend || (wend - qh < W::WIDTH / 4 && qn > wend)) {
         const uint64_t cnt = qn - qh < W::WIDTH ? qn - qh : W::WIDTH;
         if (lane < cnt) {
           const uint64_t slot = qbase + (qh + lane) % qcap;
-          b_edge = C.wq_edge[slot];
-          b_dist = C.wq_dist[slot];
+          w_edge = C.wq_edge[slot];
+          w_dist = C.wq_dist[slot];
         }
-        bbase = qh; bend = qh + cnt;
+        wbase = qh; wend = qh + cnt;
       }
-      const uint32_t bl = (uint32_t)(qh - bbase);
-      const uint32_t pe = W::shfl(b_edge, bl);
-      const int64_t nd = (int64_t)W::shfl64((uint64_t)b_dist, bl);
-      ++qh;
-      if (++pops > C.max_pops) { err = GTS_CERR_WALK_LOOP; ok = false; break; }
-      const uint32_t endv = W::uni(M.cend[pe]), from = W::uni(M.cstart[pe]);
-      const bool dir = gts_next_dir((uint8_t)W::uni((uint32_t)M.cflags[pe]));
-      const uint32_t eb = eoff(endv), ee = eoff(endv + 1);
-      bool has_s = false, has_a = false;
-      for (uint32_t base = eb; base < ee && ok; base += W::WIDTH) {
-        const uint32_t ce = base + lane;
-        bool live = false, sense = false, q = false;
-        uint32_t nb = 0;
-        float distance = 0.0f;
-        if (ce < ee) {
-          live = !gts_edge_is_marked(M.cstate[ce]);
-          sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
-          nb = M.cend[ce];
-          /* is_twin(edge, nextedge), algorithms.c:702: nextedge ends where
-             edge started */
-          q = live && sense == dir && nb != from &&
-              !gts_vertex_is_marked(M.vst[nb]);
-          distance = (float)(nd + M.cdist[ce]);
+      /* node l of this step = queue entry qh + l */
+      const uint32_t shift = (uint32_t)(qh - wbase);
+      const uint32_t navail = (uint32_t)(wend - qh);
+      const uint32_t src = (lane + shift) & (W::WIDTH - 1);
+      const uint32_t pe = W::shfl(w_edge, src);
+      const int64_t nd = (int64_t)W::shfl64((uint64_t)w_dist, src);
+      uint32_t endv = 0, from = 0, eb = 0, deg = 0;
+      bool dir = false;
+      if (lane < navail) {
+        endv = M.cend[pe]; from = M.cstart[pe];
+        dir = gts_next_dir(M.cflags[pe]);
+        eb = M.coff[endv] - M.e0;
+        const uint32_t ee = M.coff[endv + 1] - M.e0;
+        if (lane == 0) eb += cur_off;
+        deg = ee - eb;
+      }
+      const uint32_t incl = W::scan_incl(deg), excl = incl - deg;
+      const uint32_t total = W::shfl(incl, W::WIDTH - 1);
+      const uint32_t take = total < W::WIDTH ? total : W::WIDTH;
+      /* arc lane a -> node r = number of nodes that end at or before a */
+      uint32_t r = 0;
+      for (uint32_t st = W::WIDTH / 2; st > 0; st >>= 1)
+        if (W::shfl(incl, r + st - 1) <= lane) r += st;
+      const bool act = lane < take;
+      const uint32_t rr = act ? r : 0;
+      const uint32_t r_eb = W::shfl(eb, rr), r_excl = W::shfl(excl, rr);
+      const uint32_t r_from = W::shfl(from, rr);
+      const bool r_dir = W::shfl((uint32_t)dir, rr) != 0;
+      const int64_t r_nd = (int64_t)W::shfl64((uint64_t)nd, rr);
+      bool live = false, sense = false, q = false;
+      uint32_t nb = 0, ce = 0;
+      float distance = 0.0f, old = 0.0f;
+      if (act) {
+        ce = r_eb + (lane - r_excl);
+        live = !gts_edge_is_marked(M.cstate[ce]);
+        sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+        nb = M.cend[ce];
+        q = live && sense == r_dir && nb != r_from && !gts_vertex_is_marked(M.vst[nb]);
+        distance = (float)(r_nd + M.cdist[ce]);
+        if (q) old = M.distmap[nb];
+      }
+      const uint64_t bs = W::ballot(act && live && sense);
+      const uint64_t ba = W::ballot(act && live && !sense);
+      /* same-target lanes */
+      uint64_t peers = W::ballot(q);
+      for (uint32_t bit = 0; bit < tbits; ++bit) {
+        const bool one = (nb >> bit) & 1u;
+        const uint64_t bm = W::ballot(q && one);
+        peers &= one ? bm : ~bm;
+      }
+      const uint64_t lt = W::lanemask_lt(lane);
+      float minprev = GTS_DIST_UNSET;
+      {
+        uint64_t lower = q ? (peers & lt) : 0;
+        /* every lane walks its own (short) list of earlier same-target lanes;
+           the shuffles are executed by all lanes */
+        uint64_t any = W::ballot(lower != 0);
+        while (any) {
+          const uint32_t m = lower ? W::ctz(lower) : 0;
+          const float cm = W::shflf(distance, m);
+          if (lower) { if (cm < minprev) minprev = cm; lower &= lower - 1; }
+          any = W::ballot(lower != 0);
         }
-        has_s |= W::ballot(live && sense) != 0;
-        has_a |= W::ballot(live && !sense) != 0;
-        if (W::popc(W::ballot(q && nb == endv)) >= 2)
-          ok = relax_ordered(q, nb, ce, distance, (int64_t)distance, false);
-        else
-          ok = relax_distinct(q, nb, ce, distance, (int64_t)distance, false);
       }
-      /* terminal bookkeeping, algorithms.c:694-695: remember the LAST pop */
-      if (!(has_s && has_a)) {
-        if (W::uni(M.lastpop[endv]) == 0) M.wterm[nwt++] = endv;
-        M.lastpop[endv] = ++popseq;
-        W::fence();
+      const bool imp = q && (old == GTS_DIST_UNSET || old > distance) && distance < minprev;
+      const uint64_t im = W::ballot(imp);
+      const uint32_t ni = W::popc(im);
+      if (qn + ni - qh > qcap) { err = GTS_CERR_WALKQ_OVERFLOW; ok = false; break; }
+      const bool last = imp && (peers & im & ~lt & ~(1ull << lane)) == 0;
+      const bool fresh = imp && old == GTS_DIST_UNSET && (peers & im & lt) == 0;
+      const uint64_t fm = W::ballot(fresh);
+      if (imp) {
+        const uint64_t slot = qbase + (qn + W::popc_below(im, lane)) % qcap;
+        C.wq_edge[slot] = ce;
+        C.wq_dist[slot] = (int64_t)distance;
       }
+      if (last) { M.distmap[nb] = distance; M.edgemap[nb] = ce; }
+      if (fresh) M.touched[ntouch + W::popc_below(fm, lane)] = nb;
+      qn += ni;
+      ntouch += W::popc(fm);
+      /* nodes whose arcs were all relaxed in this step are popped now */
+      const bool done = lane < navail && incl <= take;
+      const uint32_t ndone = W::popc(W::ballot(done));
+      bool term = false;
+      if (done) {
+        const uint64_t mine = W::range_mask(excl, incl);
+        const bool hs = (bs & mine) != 0 || (lane == 0 && carry_s);
+        const bool ha = (ba & mine) != 0 || (lane == 0 && carry_a);
+        term = !(hs && ha);          /* algorithms.c:694 */
+      }
+      uint32_t prev = 1;
+      if (term)                      /* remember the LAST pop of a terminal */
+        prev = W::atomic_max(&M.lastpop[endv], (uint32_t)(pops + lane + 1));
+      const uint64_t nm = W::ballot(term && prev == 0);
+      if (term && prev == 0) M.wterm[nwt + W::popc_below(nm, lane)] = endv;
+      nwt += W::popc(nm);
+      if (ndone < navail && take > W::shfl(excl, ndone < W::WIDTH ? ndone : 0)) {
+        /* the next node is partly relaxed: keep its terminal flags and cursor */
+        const uint32_t pex = W::shfl(excl, ndone);
+        const uint64_t part = W::range_mask(pex, take);
+        const bool first = ndone == 0;
+        carry_s = (bs & part) != 0 || (first && carry_s);
+        carry_a = (ba & part) != 0 || (first && carry_a);
+        cur_off = (first ? cur_off : 0) + (take - pex);
+      } else {
+        carry_s = carry_a = false;
+        cur_off = 0;
+      }
+      qh += ndone;
+      pops += ndone;
+      if (pops > C.max_pops) { err = GTS_CERR_WALK_LOOP; ok = false; break; }
+      W::fence();
     }
+    npops += pops;
     /* evaluate the reached terminals, algorithms.c:732-756: the reference pops
        them from the back and keeps a strictly longer walk, i.e. it returns the
        longest walk and, among equals, the terminal popped last.  Each lane
@@ -778,10 +865,11 @@ struct GtsComponent {
     }
     if (lane == 0) {
       C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow;
-      C.tstat[4 * (uint64_t)c] = t1 - t0;
-      C.tstat[4 * (uint64_t)c + 1] = t2 - t1 - tfast - tslow;
-      C.tstat[4 * (uint64_t)c + 2] = tfast;
-      C.tstat[4 * (uint64_t)c + 3] = tslow;
+      C.tstat[5 * (uint64_t)c] = t1 - t0;
+      C.tstat[5 * (uint64_t)c + 1] = t2 - t1 - tfast - tslow;
+      C.tstat[5 * (uint64_t)c + 2] = tfast;
+      C.tstat[5 * (uint64_t)c + 3] = tslow;
+      C.tstat[5 * (uint64_t)c + 4] = npops;
     }
     W::fence();
   }
@@ -804,6 +892,13 @@ struct GtsWave1 {
   static GTS_HD uint64_t clock() { return 0; }
   static GTS_HD uint64_t alloc(unsigned long long *used, uint64_t n)
   { const uint64_t o = *used; *used += n; return o; }
+  static GTS_HD uint32_t clz32(uint32_t v) { uint32_t n = 0; while (n < 32 && !(v & (0x80000000u >> n))) ++n; return n; }
+  static GTS_HD uint32_t scan_incl(uint32_t v) { return v; }
+  static GTS_HD float shflf(float v, uint32_t) { return v; }
+  static GTS_HD uint64_t lanemask_lt(uint32_t) { return 0; }
+  static GTS_HD uint64_t range_mask(uint32_t lo, uint32_t hi) { return lo < hi ? 1u : 0u; }
+  static GTS_HD uint32_t atomic_max(uint32_t *p, uint32_t v)
+  { const uint32_t o = *p; if (v > o) *p = v; return o; }
 };
 
 #endif

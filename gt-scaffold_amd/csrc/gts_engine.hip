@@ -637,6 +637,27 @@ struct GtsWave64 {
   { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
   /* constant 100 MHz counter (s_memrealtime) */
   static __device__ __forceinline__ uint64_t clock() { return wall_clock64(); }
+  static __device__ __forceinline__ uint32_t clz32(uint32_t v) { return (uint32_t)__clz((int)v); }
+  static __device__ __forceinline__ uint32_t scan_incl(uint32_t v)
+  {
+    const uint32_t l = lane();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)v, off);
+      if (l >= (uint32_t)off) v += o;
+    }
+    return v;
+  }
+  static __device__ __forceinline__ float shflf(float v, uint32_t l) { return __shfl(v, (int)l); }
+  static __device__ __forceinline__ uint64_t lanemask_lt(uint32_t l) { return (1ull << l) - 1ull; }
+  static __device__ __forceinline__ uint64_t range_mask(uint32_t lo, uint32_t hi)
+  {
+    const uint64_t h = hi >= 64 ? ~0ull : (1ull << hi) - 1ull;
+    const uint64_t l = lo >= 64 ? ~0ull : (1ull << lo) - 1ull;
+    return h & ~l;
+  }
+  static __device__ __forceinline__ uint32_t atomic_max(uint32_t *p, uint32_t v)
+  { return atomicMax(p, v); }
   /* lane 0 takes n entries from the pool, every lane gets the offset */
   static __device__ __forceinline__ uint64_t alloc(unsigned long long *used, uint64_t n)
   {
@@ -745,7 +766,7 @@ __global__ void k_tstat_reduce(const uint64_t *t, uint32_t ncomp, unsigned long 
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncomp) return;
   for (int k = 0; k < 4; ++k) {
-    const unsigned long long v = t[4 * c + k];
+    const unsigned long long v = t[5 * c + k];
     if (v) { atomicAdd(&out[k], v); atomicMax(&out[4 + k], v); }
   }
 }
@@ -1243,7 +1264,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cerr, uint32_t, ncomp);
     PALLOC(s_nd, int64_t, nslots); PALLOC(s_plen, uint64_t, nslots); PALLOC(s_tight, uint8_t, nslots);
     PALLOC(stat_fast, uint32_t, ncomp); PALLOC(stat_slow, uint32_t, ncomp);
-    PALLOC(tstat, uint64_t, 4 * (size_t)ncomp);
+    PALLOC(tstat, uint64_t, 5 * (size_t)ncomp);
     PALLOC(ok0, uint32_t, ncomp); PALLOC(ok1, uint32_t, ncomp);
     PALLOC(ov0, uint32_t, ncomp); PALLOC(ov1, uint32_t, ncomp);
     PALLOC(otmp, uint32_t, gts_sort_tmp_elems(ncomp));
@@ -1340,6 +1361,23 @@ static int run_components(GtsgEngine *e, int mode)
       for (int k = 0; k < 4; ++k) {   /* 100 MHz ticks -> microseconds */
         e->stats[std::string("us_sum_") + nm[k]] = (int64_t)(ts[k] / 100);
         e->stats[std::string("us_max_") + nm[k]] = (int64_t)(ts[4 + k] / 100);
+      }
+    }
+    if (e->profile) {   /* the three components with the longest reference walks */
+      std::vector<uint64_t> ht(5 * (size_t)ncomp);
+      std::vector<uint32_t> hs(ncomp), ho((size_t)ncomp + 1);
+      HIPCHK(hipMemcpy(ht.data(), tstat, ht.size() * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hs.data(), stat_slow, (size_t)ncomp * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(ho.data(), comp_off, ((size_t)ncomp + 1) * 4, hipMemcpyDeviceToHost));
+      for (int r = 0; r < 3; ++r) {
+        uint32_t best = 0;
+        for (uint32_t c2 = 1; c2 < ncomp; ++c2) if (ht[5 * (size_t)c2 + 3] > ht[5 * (size_t)best + 3]) best = c2;
+        const std::string pre = std::string("top") + char('0' + r) + "_";
+        e->stats[pre + "size"] = ho[best + 1] - ho[best];
+        e->stats[pre + "ref_walks"] = hs[best];
+        e->stats[pre + "ref_us"] = (int64_t)(ht[5 * (size_t)best + 3] / 100);
+        e->stats[pre + "ref_pops"] = (int64_t)ht[5 * (size_t)best + 4];
+        ht[5 * (size_t)best + 3] = 0;
       }
     }
     e->stats["fast_walks"] = (int64_t)wstat[0];

@@ -224,7 +224,7 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   std::vector<int64_t> nd(S); std::vector<uint64_t> plen(S); std::vector<uint8_t> tight(S, 0);
   std::vector<uint32_t> sf(ncomp ? ncomp : 1, 0), ss(ncomp ? ncomp : 1, 0);
   C.fast_walks = fast_walks; C.nd = nd.data(); C.plen = plen.data(); C.tight = tight.data();
-  std::vector<uint64_t> tstat(4 * (size_t)(ncomp ? ncomp : 1), 0);
+  std::vector<uint64_t> tstat(5 * (size_t)(ncomp ? ncomp : 1), 0);
   C.stat_fast = sf.data(); C.stat_slow = ss.data(); C.tstat = tstat.data();
   uint32_t nerr = 0;
   for (uint32_t c = 0; c < ncomp; c++) {
