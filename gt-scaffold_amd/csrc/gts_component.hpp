@@ -250,8 +250,8 @@ struct GtsComponent {
         const uint64_t mask = W::ballot(cand);
         if (mask) {
           const uint32_t l = W::ctz(mask);
-          const uint32_t nb_l = W::shfl(nb, l), vs_l = W::shfl(vs, l);
-          const uint32_t fl_l = W::shfl(fl, l);
+          const uint32_t nb_l = W::bcast(nb, l), vs_l = W::bcast(vs, l);
+          const uint32_t fl_l = W::bcast(fl, l);
           if (vs_l == GIS_VISITED) return cur + l;      /* back edge */
           /* GIS_UNVISITED: descend */
           M.st_cur[f] = cur + l + 1;
@@ -322,7 +322,7 @@ struct GtsComponent {
           }
           const uint64_t mask = W::ballot(live);
           if (mask) {
-            dir = (W::shfl(fl, W::msb(mask)) & GTS_F_SENSE) != 0;
+            dir = (W::bcast(fl, W::msb(mask)) & GTS_F_SENSE) != 0;
             set_dir = true;
           }
         }
@@ -465,13 +465,18 @@ struct GtsComponent {
         if (lane == 0) eb += cur_off;
         deg = ee - eb;
       }
-      const uint32_t incl = W::scan_incl(deg), excl = incl - deg;
-      const uint32_t total = W::shfl(incl, W::WIDTH - 1);
+      /* prefix sums of the arc counts.  A step takes at most WIDTH arcs, so
+         counts are clamped to WIDTH + 1 (keeps "does not fit" visible) and the
+         sum is built from one ballot per bit */
+      const uint32_t degc = deg > W::WIDTH ? W::WIDTH + 1 : deg;
+      const uint32_t incl = W::scan_incl_small(degc), excl = incl - degc;
+      const uint32_t total = W::bcast(incl, W::WIDTH - 1);
       const uint32_t take = total < W::WIDTH ? total : W::WIDTH;
-      /* arc lane a -> node r = number of nodes that end at or before a */
+      /* arc lane a -> node r: the last node that starts at or before a */
+      const uint32_t nstart = W::popc(W::ballot(lane < navail && excl < take));
       uint32_t r = 0;
-      for (uint32_t st = W::WIDTH / 2; st > 0; st >>= 1)
-        if (W::shfl(incl, r + st - 1) <= lane) r += st;
+      for (uint32_t k = 1; k < nstart; ++k)
+        if (lane >= W::bcast(excl, k)) r = k;
       const bool act = lane < take;
       const uint32_t rr = act ? r : 0;
       const uint32_t r_eb = W::shfl(eb, rr), r_excl = W::shfl(excl, rr);
@@ -530,7 +535,7 @@ struct GtsComponent {
       qn += ni;
       ntouch += W::popc(fm);
       /* nodes whose arcs were all relaxed in this step are popped now */
-      const bool done = lane < navail && incl <= take;
+      const bool done = lane < navail && incl <= take && deg == degc;
       const uint32_t ndone = W::popc(W::ballot(done));
       bool term = false;
       if (done) {
@@ -545,9 +550,9 @@ struct GtsComponent {
       const uint64_t nm = W::ballot(term && prev == 0);
       if (term && prev == 0) M.wterm[nwt + W::popc_below(nm, lane)] = endv;
       nwt += W::popc(nm);
-      if (ndone < navail && take > W::shfl(excl, ndone < W::WIDTH ? ndone : 0)) {
+      if (ndone < navail && take > W::bcast(excl, ndone < W::WIDTH ? ndone : 0)) {
         /* the next node is partly relaxed: keep its terminal flags and cursor */
-        const uint32_t pex = W::shfl(excl, ndone);
+        const uint32_t pex = W::bcast(excl, ndone);
         const uint64_t part = W::range_mask(pex, take);
         const bool first = ndone == 0;
         carry_s = (bs & part) != 0 || (first && carry_s);
@@ -893,7 +898,8 @@ struct GtsWave1 {
   static GTS_HD uint64_t alloc(unsigned long long *used, uint64_t n)
   { const uint64_t o = *used; *used += n; return o; }
   static GTS_HD uint32_t clz32(uint32_t v) { uint32_t n = 0; while (n < 32 && !(v & (0x80000000u >> n))) ++n; return n; }
-  static GTS_HD uint32_t scan_incl(uint32_t v) { return v; }
+  static GTS_HD uint32_t scan_incl_small(uint32_t v) { return v; }
+  static GTS_HD uint32_t bcast(uint32_t v, uint32_t) { return v; }
   static GTS_HD float shflf(float v, uint32_t) { return v; }
   static GTS_HD uint64_t lanemask_lt(uint32_t) { return 0; }
   static GTS_HD uint64_t range_mask(uint32_t lo, uint32_t hi) { return lo < hi ? 1u : 0u; }

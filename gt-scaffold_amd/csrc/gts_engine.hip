@@ -638,16 +638,21 @@ struct GtsWave64 {
   /* constant 100 MHz counter (s_memrealtime) */
   static __device__ __forceinline__ uint64_t clock() { return wall_clock64(); }
   static __device__ __forceinline__ uint32_t clz32(uint32_t v) { return (uint32_t)__clz((int)v); }
-  static __device__ __forceinline__ uint32_t scan_incl(uint32_t v)
+  /* inclusive prefix sum of values < 128: one ballot per bit, the lower-lane
+     population count of each ballot weighted by the bit */
+  static __device__ __forceinline__ uint32_t scan_incl_small(uint32_t v)
   {
     const uint32_t l = lane();
+    const uint64_t le = l == 63 ? ~0ull : (2ull << l) - 1ull;
+    uint32_t s = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)v, off);
-      if (l >= (uint32_t)off) v += o;
-    }
-    return v;
+    for (int b = 0; b < 7; ++b)
+      s += (uint32_t)__popcll(__ballot((v >> b) & 1u) & le) << b;
+    return s;
   }
+  /* value of lane l, l wave-uniform: v_readlane instead of ds_bpermute */
+  static __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t l)
+  { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
   static __device__ __forceinline__ float shflf(float v, uint32_t l) { return __shfl(v, (int)l); }
   static __device__ __forceinline__ uint64_t lanemask_lt(uint32_t l) { return (1ull << l) - 1ull; }
   static __device__ __forceinline__ uint64_t range_mask(uint32_t lo, uint32_t hi)
