@@ -88,23 +88,51 @@ struct GtsCompView {
                                 the reference walks */
 };
 
+/* Pointer type of the component's working set: generic pointers into the
+   global arrays, or address-space-3 pointers when the component is staged in
+   LDS.  LDS pointers matter: accesses become ds_read / ds_write (lgkmcnt only);
+   through generic pointers they would be flat_* instructions, whose results
+   also wait for every outstanding global store (the walk-queue pushes). */
+template <class T, bool LDS> struct GtsPtrSel { typedef T *type; };
+#if defined(__HIPCC__)
+template <class T> struct GtsPtrSel<T, true> {
+  typedef T __attribute__((address_space(3))) *type;
+};
+#endif
+#define GTS_P(T) typename GtsPtrSel<T, LDS>::type
+
 /* base pointers of ONE component, component-local indices */
-struct GtsCompMem {
+template <bool LDS>
+struct GtsCompMemT {
   uint32_t nv, ne;           /* slots, compact edges of the component */
   uint32_t e0;               /* value to subtract from coff[] entries */
-  const uint32_t *coff;      /* nv+1 */
-  const uint32_t *cstart, *cend;
-  const int64_t *cdist;
-  const uint8_t *cflags;
-  const int64_t *cseq;
-  uint8_t *cstate, *vst;
-  uint32_t *queue, *term, *visited, *st_v, *st_par, *st_cur, *edgemap,
-      *lastpop, *wterm, *touched, *cc_best, *ccoff;
-  uint8_t *st_dir, *tight;
-  float *distmap;
-  int64_t *nd;
-  uint64_t *plen;
+  GTS_P(const uint32_t) coff;      /* nv+1 */
+  GTS_P(const uint32_t) cstart;
+  GTS_P(const uint32_t) cend;
+  GTS_P(const int64_t) cdist;
+  GTS_P(const uint8_t) cflags;
+  GTS_P(const int64_t) cseq;
+  GTS_P(uint8_t) cstate;
+  GTS_P(uint8_t) vst;
+  GTS_P(uint32_t) queue;
+  GTS_P(uint32_t) term;
+  GTS_P(uint32_t) visited;
+  GTS_P(uint32_t) st_v;
+  GTS_P(uint32_t) st_par;
+  GTS_P(uint32_t) st_cur;
+  GTS_P(uint32_t) edgemap;
+  GTS_P(uint32_t) lastpop;
+  GTS_P(uint32_t) wterm;
+  GTS_P(uint32_t) touched;
+  GTS_P(uint32_t) cc_best;
+  GTS_P(uint32_t) ccoff;
+  GTS_P(uint8_t) st_dir;
+  GTS_P(uint8_t) tight;
+  GTS_P(float) distmap;
+  GTS_P(int64_t) nd;
+  GTS_P(uint64_t) plen;
 };
+typedef GtsCompMemT<false> GtsCompMem;
 
 /* LDS bytes needed to stage a component (every array 16-byte aligned) */
 GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
@@ -124,10 +152,10 @@ GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
 /* (float)GT_WORD_MAX, ref algorithms.c:650 */
 #define GTS_DIST_UNSET 9223372036854775808.0f
 
-template <class W>
+template <class W, bool LDS = false>
 struct GtsComponent {
   const GtsCompView &C;
-  const GtsCompMem &M;
+  const GtsCompMemT<LDS> &M;
   uint32_t c, s0, e0g;  /* component, its first slot and first compact edge */
   uint32_t nv;
   uint32_t nterm, ncc;  /* filled by calc_cc */
@@ -138,7 +166,7 @@ struct GtsComponent {
   uint32_t nfast, nslow;
   uint64_t tfast, tslow, npops;
 
-  GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMem &mem, uint32_t comp)
+  GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
         ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0) {}
@@ -171,7 +199,7 @@ struct GtsComponent {
     for (uint32_t s = lane; s < nv; s += W::WIDTH)
       if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
     W::fence();
-    uint32_t *ccoff = M.ccoff;
+    auto ccoff = M.ccoff;
     nterm = 0; ncc = 0;
     for (uint32_t s = 0; s < nv; ++s) {
       const uint8_t st = (uint8_t)W::uni(M.vst[s]);
@@ -648,8 +676,10 @@ struct GtsComponent {
   GTS_HD bool create_walk_fast(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t lane = W::lane();
-    uint32_t *R = M.queue, *TQ = M.visited, *indeg = M.st_v;
-    uint8_t *orient = M.st_dir;
+    auto R = M.queue;
+    auto TQ = M.visited;
+    auto indeg = M.st_v;
+    auto orient = M.st_dir;
     /* all live edges of the start must leave in one direction */
     bool has_s = false, has_a = false;
     {
@@ -813,7 +843,7 @@ struct GtsComponent {
     calc_cc();
     for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }
     W::fence();
-    const uint32_t *ccoff = M.ccoff;
+    auto ccoff = M.ccoff;
     for (uint32_t i = 0; i < ncc && !err; ++i) {
       const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
       if (te - tb == 1) {                    /* algorithms.c:790-807 */
@@ -903,7 +933,7 @@ struct GtsWave1 {
   static GTS_HD float shflf(float v, uint32_t) { return v; }
   static GTS_HD uint64_t lanemask_lt(uint32_t) { return 0; }
   static GTS_HD uint64_t range_mask(uint32_t lo, uint32_t hi) { return lo < hi ? 1u : 0u; }
-  static GTS_HD uint32_t atomic_max(uint32_t *p, uint32_t v)
+  template <class P> static GTS_HD uint32_t atomic_max(P p, uint32_t v)
   { const uint32_t o = *p; if (v > o) *p = v; return o; }
 };
 

@@ -661,8 +661,8 @@ struct GtsWave64 {
     const uint64_t l = lo >= 64 ? ~0ull : (1ull << lo) - 1ull;
     return h & ~l;
   }
-  static __device__ __forceinline__ uint32_t atomic_max(uint32_t *p, uint32_t v)
-  { return atomicMax(p, v); }
+  template <class P> static __device__ __forceinline__ uint32_t atomic_max(P p, uint32_t v)
+  { return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   /* lane 0 takes n entries from the pool, every lane gets the offset */
   static __device__ __forceinline__ uint64_t alloc(unsigned long long *used, uint64_t n)
   {
@@ -691,10 +691,11 @@ k_components(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t coun
    scratch in LDS and runs the same program on LDS base pointers; marks still
    go to the global graph as they are set, vertex states are written back by
    run(). */
+typedef char __attribute__((address_space(3))) *gts_lds_cursor;
 template <typename T>
-__device__ __forceinline__ T *lds_carve(char *&p, uint32_t count)
+__device__ __forceinline__ T __attribute__((address_space(3))) *lds_carve(gts_lds_cursor &p, uint32_t count)
 {
-  T *r = (T *)p;
+  T __attribute__((address_space(3))) *r = (T __attribute__((address_space(3))) *)p;
   p += ((count * (uint32_t)sizeof(T) + 15u) / 16u) * 16u;
   return r;
 }
@@ -706,10 +707,10 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
   const uint32_t c = order[first + blockIdx.x];
   const GtsCompMem G0 = GtsComponent<GtsWave64>::global_mem(C, c);
   const uint32_t nv = G0.nv, ne = G0.ne, lane = threadIdx.x;
-  char *p = smem;
-  GtsCompMem M;
+  gts_lds_cursor p = (gts_lds_cursor)smem;
+  GtsCompMemT<true> M;
   M.nv = nv; M.ne = ne; M.e0 = 0;
-  uint32_t *coff = lds_carve<uint32_t>(p, nv + 1);
+  auto coff = lds_carve<uint32_t>(p, nv + 1);
   M.ccoff = lds_carve<uint32_t>(p, nv + 1);
   M.queue = lds_carve<uint32_t>(p, nv); M.term = lds_carve<uint32_t>(p, nv);
   M.visited = lds_carve<uint32_t>(p, nv); M.st_v = lds_carve<uint32_t>(p, nv);
@@ -717,13 +718,14 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
   M.edgemap = lds_carve<uint32_t>(p, nv); M.lastpop = lds_carve<uint32_t>(p, nv);
   M.wterm = lds_carve<uint32_t>(p, nv); M.touched = lds_carve<uint32_t>(p, nv);
   M.cc_best = lds_carve<uint32_t>(p, nv); M.distmap = lds_carve<float>(p, nv);
-  int64_t *cseq = lds_carve<int64_t>(p, nv);
+  auto cseq = lds_carve<int64_t>(p, nv);
   M.nd = lds_carve<int64_t>(p, nv); M.plen = lds_carve<uint64_t>(p, nv);
   M.vst = lds_carve<uint8_t>(p, nv); M.st_dir = lds_carve<uint8_t>(p, nv);
   M.tight = lds_carve<uint8_t>(p, nv);
-  uint32_t *cstart = lds_carve<uint32_t>(p, ne), *cend = lds_carve<uint32_t>(p, ne);
-  int64_t *cdist = lds_carve<int64_t>(p, ne);
-  uint8_t *cflags = lds_carve<uint8_t>(p, ne);
+  auto cstart = lds_carve<uint32_t>(p, ne);
+  auto cend = lds_carve<uint32_t>(p, ne);
+  auto cdist = lds_carve<int64_t>(p, ne);
+  auto cflags = lds_carve<uint8_t>(p, ne);
   M.cstate = lds_carve<uint8_t>(p, ne);
   for (uint32_t i = lane; i <= nv; i += GTS_WAVE) coff[i] = G0.coff[i] - G0.e0;
   for (uint32_t i = lane; i < nv; i += GTS_WAVE) {
@@ -737,7 +739,7 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
   M.coff = coff; M.cseq = cseq; M.cstart = cstart; M.cend = cend; M.cdist = cdist;
   M.cflags = cflags;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  GtsComponent<GtsWave64> prog(C, M, c);
+  GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.run(mode);
 }
 /* LDS footprint of every component as a descending sort key, and how many
