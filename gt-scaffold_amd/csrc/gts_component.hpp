@@ -388,7 +388,7 @@ struct GtsComponent {
     if (imp) {
       M.distmap[nb] = distance;
       M.edgemap[nb] = ce;
-      const uint64_t slot = qbase + (qn + W::popc_below(im, lane)) % qcap;
+      const uint64_t slot = qbase + ((qn + W::popc_below(im, lane)) & (qcap - 1));
       C.wq_edge[slot] = ce;
       C.wq_dist[slot] = pushd;
     }
@@ -423,7 +423,8 @@ struct GtsComponent {
   {
     const uint32_t lane = W::lane();
     if (qcap == 0) {
-      const uint64_t need = C.wq_factor * (uint64_t)M.ne + 64;
+      uint64_t need = 64;   /* power of two: ring positions are masked, not divided */
+      while (need < C.wq_factor * (uint64_t)M.ne + 64) need <<= 1;
       const uint64_t off = W::alloc(C.wq_used, need);
       if (off + need > C.wq_pool) { err = GTS_CERR_WALKQ_OVERFLOW; return false; }
       qbase = off; qcap = need;
@@ -471,7 +472,7 @@ struct GtsComponent {
       if (qh == wend || (wend - qh < W::WIDTH / 4 && qn > wend)) {
         const uint64_t cnt = qn - qh < W::WIDTH ? qn - qh : W::WIDTH;
         if (lane < cnt) {
-          const uint64_t slot = qbase + (qh + lane) % qcap;
+          const uint64_t slot = qbase + ((qh + lane) & (qcap - 1));
           w_edge = C.wq_edge[slot];
           w_dist = C.wq_dist[slot];
         }
@@ -554,7 +555,7 @@ struct GtsComponent {
       const bool fresh = imp && old == GTS_DIST_UNSET && (peers & im & lt) == 0;
       const uint64_t fm = W::ballot(fresh);
       if (imp) {
-        const uint64_t slot = qbase + (qn + W::popc_below(im, lane)) % qcap;
+        const uint64_t slot = qbase + ((qn + W::popc_below(im, lane)) & (qcap - 1));
         C.wq_edge[slot] = ce;
         C.wq_dist[slot] = (int64_t)distance;
       }

@@ -28,7 +28,7 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
                scaffold_median=20, scaffold_sigma=1.0, p_repeat=0.02, repeat_degree=24,
                p_bubble=0.02, p_chimeric=0.01, p_missing_astat=0.01, p_relist=0.01,
                p_link=0.97, contig_median=900, dist_range_small=False, scaffold_max=20000,
-               p_relist_flip=0.0):
+               p_relist_flip=0.0, min_dist=-99):
     """Returns a dict of tensors:
       seq_len[u64 as i64], astat[f32], copy_num[f32]          (per contig)
       root[i32], ctg[i32], dist[i64], std_dev[f32], num_pairs[i64], flags[u8]
@@ -89,7 +89,8 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
         a = pos[: n - k]
         b = a + k
         d = cs[b] - (cs[a] + clen[a])
-        ok = (sc_id[a] == sc_id[b]) & (d <= reach) & (rand(n - k) < p_link)
+        # DistanceEst does not report estimates below -99 (ref src/test.c:49 MIN_DIST)
+        ok = (sc_id[a] == sc_id[b]) & (d <= reach) & (d >= min_dist) & (rand(n - k) < p_link)
         ok &= ~(is_rep[a] | is_rep[b])
         if k == 1:
             ok &= ~bub[a]
@@ -130,7 +131,7 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
     sd = (sigma_lib / npairs.float().sqrt() * (0.8 + 0.4 * rand(m)))
     sd = (sd * 10).round() / 10                           # .de files carry %.1f
     noise = (torch.empty(m, device=dev).normal_(0, 1, generator=gen) * sd).round().long()
-    dist = D + noise
+    dist = (D + noise).clamp_(min=min_dist)
     if dist_range_small:                                  # provoke ties in walks
         dist = dist.clamp_(-99, 99)
 
