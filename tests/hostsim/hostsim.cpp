@@ -199,7 +199,7 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   uint32_t maxcomp = 0;
   for (uint32_t c = 0; c < ncomp; c++)
     if (comp_off[c + 1] - comp_off[c] > maxcomp) maxcomp = comp_off[c + 1] - comp_off[c];
-  const uint64_t wq_pool = (uint64_t)wq_factor * nce + 64ull * ncomp + 64;
+  const uint64_t wq_pool = 2 * ((uint64_t)wq_factor * nce + 64ull * ncomp) + 64;  /* rings are powers of two */
   unsigned long long wq_used = 0;
   const size_t S = nslots ? nslots : 1;
   std::vector<uint32_t> queue(S), term(S), visited(S), st_v(S), st_par(S), st_cur(S),
