@@ -30,7 +30,7 @@ from __graft_entry__ import load_package  # noqa: E402
 # north_star's 10M-contig / 100M-edge graph; it fits one GPU)
 WORKLOAD = dict(name="synthetic 10M-contig / 100M-edge scaffold graph",
                 n_contigs=10_000_000,
-                gen=dict(links_per_side=5, p_repeat=0.03, repeat_degree=43))
+                gen=dict(links_per_side=5, p_repeat=0.03, repeat_degree=43, p_inversion=0.0))
 CUTS = dict(copy_num_cutoff=0.3, astat_cutoff=20.0, pcutoff=0.01, cncutoff=1.5, ocutoff=400)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 
@@ -104,6 +104,9 @@ def main():
                     help="contigs per GPU (default: the BASELINE configuration)")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inversions", type=float, default=None,
+                    help="fraction of the chimeric links that are inversions (default 0: the "
+                         "reference's walk search is exponential on components holding one)")
     ap.add_argument("--verify", action="store_true",
                     help="also run the oracle on the FULL workload and compare digests (slow)")
     args = ap.parse_args()
@@ -122,6 +125,8 @@ def main():
     pkg = load_package()
     dev = "cuda:%d" % local_rank
 
+    if args.inversions is not None:
+        WORKLOAD["gen"]["p_inversion"] = args.inversions
     g = make_inputs(pkg, args.contigs, 1234 + rank, dev, WORKLOAD["gen"])
     g["num_pairs"] = g["num_pairs"].to(torch.int64)
     nrec = g["root"].numel()

@@ -28,7 +28,7 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
                scaffold_median=20, scaffold_sigma=1.0, p_repeat=0.02, repeat_degree=24,
                p_bubble=0.02, p_chimeric=0.01, p_missing_astat=0.01, p_relist=0.01,
                p_link=0.97, contig_median=900, dist_range_small=False, scaffold_max=20000,
-               p_relist_flip=0.0, min_dist=-99):
+               p_relist_flip=0.0, min_dist=-99, p_inversion=1.0):
     """Returns a dict of tensors:
       seq_len[u64 as i64], astat[f32], copy_num[f32]          (per contig)
       root[i32], ctg[i32], dist[i64], std_dev[f32], num_pairs[i64], flags[u8]
@@ -120,8 +120,17 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
     # geometry flags.  true links follow the layout; others are random.
     sense_a = ~orient[A]                      # B lies downstream of A
     same = orient[A] == orient[B]
+    # false links: repeat links always get random geometry; a chimeric link gets
+    # random geometry (an inversion: it joins the two strands of the layout)
+    # with probability p_inversion, else the geometry of the layout with a
+    # wrong position / distance (a plain misjoin).  Inversions put a vertex on
+    # walks in both directions; the reference's label-correcting walk search
+    # (algorithms.c:681-728) then degenerates (millions of queue pops for a
+    # few hundred contigs).
     rnd = torch.ones(m, dtype=torch.bool, device=dev)
     rnd[:n_true] = False
+    n_c = ca.numel()
+    rnd[n_true:n_true + n_c] = rand(n_c) < p_inversion
     sense_a = torch.where(rnd, rand(m) < 0.5, sense_a)
     same = torch.where(rnd, rand(m) < 0.5, same)
     sense_b = torch.where(same, ~sense_a, sense_a)  # ref parser.c:369-372 twin_dir
