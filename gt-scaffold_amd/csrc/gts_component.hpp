@@ -664,16 +664,38 @@ struct GtsComponent {
        (a) the (vertex, leaving direction) states reachable from the start form
            a DAG in which every vertex occurs with ONE direction (then the twin
            exclusion of algorithms.c:702 never applies either),
-       (b) every reached vertex has exactly ONE in-arc that attains its final
-           label (edgemap keeps the FIRST arc that sets the final value; with a
-           single candidate the order does not matter),
-       (c) one reached terminal has the strictly longest tree path (the
-           reference breaks length ties by pop order).
+       (b) ties -- several in-arcs attaining a vertex' final label (edgemap
+           keeps the FIRST arc that sets it), several reached terminals with
+           the longest tree path (the reference keeps the one popped last) --
+           are resolved by the FIFO's push order of final nodes, which is
+           known in closed form (pushed_after) as long as every label stays
+           below 2^24 in magnitude, where the float sums are exact.
      The final label is min over paths of the nested float roundings
      fl(int(label) + dist); fl is monotone, so a relaxation in topological
      order computes it with the very same operations.  Any violated condition
      returns false with the scratch restored, and the caller runs the
      reference's search instead. */
+  /* Order in which the reference pushes the FINAL queue nodes of two reached
+     vertices a != b (exact arithmetic, labels final, tree = first-arrival
+     tree given by edgemap/depth): the FIFO handles whole generations one after
+     the other, a final node's generation is its tree depth, and inside a
+     generation nodes keep the order of their parents and, under one parent,
+     the order of the parent's adjacency list.  Returns true if a's final node
+     is pushed (hence popped) after b's. */
+  GTS_HD bool pushed_after(uint32_t a, uint32_t b, uint32_t start) const
+  {
+    const uint32_t da = a == start ? 0 : W::uni(M.st_par[a]);
+    const uint32_t db = b == start ? 0 : W::uni(M.st_par[b]);
+    if (da != db) return da > db;
+    uint32_t ea = W::uni(M.edgemap[a]), eb = W::uni(M.edgemap[b]);
+    uint32_t pa = W::uni(M.cstart[ea]), pb = W::uni(M.cstart[eb]);
+    while (pa != pb) {
+      ea = W::uni(M.edgemap[pa]); eb = W::uni(M.edgemap[pb]);
+      pa = W::uni(M.cstart[ea]); pb = W::uni(M.cstart[eb]);
+    }
+    return ea > eb;
+  }
+
   GTS_HD bool create_walk_fast(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t lane = W::lane();
@@ -681,6 +703,7 @@ struct GtsComponent {
     auto TQ = M.visited;
     auto indeg = M.st_v;
     auto orient = M.st_dir;
+    auto depth = M.st_par;
     /* all live edges of the start must leave in one direction */
     bool has_s = false, has_a = false;
     {
@@ -741,8 +764,9 @@ struct GtsComponent {
       }
     }
     /* pass 2: relaxation in topological order */
-    uint32_t nq = 1, qh2 = 0, processed = 0, nbest = 0, best_t = GTS_NONE;
+    uint32_t nq = 1, qh2 = 0, processed = 0, best_t = GTS_NONE;
     uint64_t best_len = 0;
+    bool inexact = false;     /* a label left the range where floats are exact */
     if (!bad) {
       TQ[0] = start;
       M.plen[start] = (uint64_t)M.cseq[start];
@@ -753,12 +777,12 @@ struct GtsComponent {
         const bool du = W::uni((uint32_t)orient[u]) == 2;
         const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
         const uint64_t plu = (uint64_t)W::uni64((int64_t)M.plen[u]);
-        if (u != start && W::uni((uint32_t)M.tight[u]) != 1) { bad = true; break; }
+        const uint32_t dpu = u == start ? 0 : W::uni(depth[u]);
         const uint32_t eb = eoff(u), ee = eoff(u + 1);
         bool us = false, ua = false;
-        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+        for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
           const uint32_t ce = base + lane;
-          bool live = false, sense = false, arc = false, ready = false;
+          bool live = false, sense = false, arc = false, ready = false, tie = false;
           uint32_t v = 0;
           if (ce < ee) {
             live = !gts_edge_is_marked(M.cstate[ce]);
@@ -769,16 +793,15 @@ struct GtsComponent {
               const int64_t w = M.cdist[ce];
               const float cand = u == start ? (float)w : (float)(ndu + w);
               const float old = M.distmap[v];
+              if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
               if (old == GTS_DIST_UNSET || old > cand) {
                 M.distmap[v] = cand;
                 M.edgemap[v] = ce;
                 M.nd[v] = u == start ? w : (int64_t)cand;
                 M.plen[v] = plu + (uint64_t)M.cseq[v];
-                M.tight[v] = 1;
-              } else if (old == cand) {
-                const uint8_t t = M.tight[v];
-                if (t < 255) M.tight[v] = t + 1;
-              }
+                depth[v] = dpu + 1;
+              } else if (old == cand)
+                tie = true;
               const uint32_t d = indeg[v] - 1;
               indeg[v] = d;
               ready = d == 0;
@@ -786,19 +809,41 @@ struct GtsComponent {
           }
           us |= W::ballot(live && sense) != 0;
           ua |= W::ballot(live && !sense) != 0;
+          inexact = W::ballot(inexact) != 0;
+          /* two in-arcs attain the label of v: edgemap keeps the one whose
+             value arrived first (algorithms.c:711-717), i.e. the arc whose
+             source's final node is pushed first */
+          uint64_t tm = W::ballot(tie);
+          if (tm && inexact) { bad = true; break; }
+          while (tm) {
+            const uint32_t l = W::ctz(tm);
+            tm &= tm - 1;
+            const uint32_t tv = W::bcast(v, l), tce = W::bcast(ce, l);
+            const uint32_t up = W::uni(M.cstart[W::uni(M.edgemap[tv])]);
+            if (pushed_after(up, u, start)) {       /* u's value came first */
+              M.edgemap[tv] = tce;
+              M.plen[tv] = plu + (uint64_t)W::uni64(M.cseq[tv]);
+              depth[tv] = dpu + 1;
+              W::fence();
+            }
+          }
           const uint64_t rm = W::ballot(ready);
           if (ready) TQ[nq + W::popc_below(rm, lane)] = v;
           nq += W::popc(rm);
           W::fence();
         }
-        /* reached terminal (algorithms.c:694): candidate end of the walk */
-        if (u != start && !(us && ua)) {
-          if (plu > best_len) { best_len = plu; best_t = u; nbest = 1; }
-          else if (plu == best_len) ++nbest;
+        /* reached terminal (algorithms.c:694): candidate end of the walk; among
+           equally long walks the reference keeps the terminal popped last
+           (algorithms.c:732-756), whose last pop is its final node */
+        if (!bad && u != start && !(us && ua)) {
+          if (plu > best_len) { best_len = plu; best_t = u; }
+          else if (plu == best_len && best_t != GTS_NONE) {
+            if (inexact) bad = true;
+            else if (pushed_after(u, best_t, start)) best_t = u;
+          }
         }
       }
       if (processed != nr) bad = true;                    /* cycle */
-      if (best_t != GTS_NONE && nbest != 1) bad = true;   /* length tie */
     }
     if (!bad && best_t != GTS_NONE && best_len > cc_len) {
       uint32_t cv = best_t, n = 0;
@@ -815,7 +860,6 @@ struct GtsComponent {
       const uint32_t v = R[k];
       orient[v] = 0;
       M.distmap[v] = GTS_DIST_UNSET;
-      M.tight[v] = 0;
     }
     W::fence();
     return !bad;

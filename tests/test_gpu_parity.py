@@ -120,10 +120,10 @@ def test_global_memory_components_match_lds_components():
     assert eng.digest() == eng2.digest()
 
 
-def test_fast_walks_fall_back_on_ties():
+def test_fast_walks_resolve_ties():
     g = make_inputs(3000, 21, dist_range_small=True, contig_median=300)
     eng, _ = run_pipeline(g)
-    assert eng.stat("fast_walks") > 0 and eng.stat("slow_walks") > 0
+    assert eng.stat("fast_walks") > 0
 
 
 def test_empty_and_ragged_inputs():

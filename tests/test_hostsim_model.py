@@ -91,3 +91,19 @@ def test_walk_paths_agree(fast):
             assert hs.fast_walks > 0
         else:
             assert hs.fast_walks == 0 and hs.slow_walks > 0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_ties_are_resolved_in_the_linear_walk(seed):
+    # equal distances / equal walk lengths everywhere: the closed-form push order
+    # (pushed_after) must reproduce the reference's tie-breaks without falling back
+    g = make_inputs(800, 500 + seed, dist_range_small=True, contig_median=250, p_inversion=0.0,
+                    links_per_side=4)
+    og = oracle_from_inputs(g)
+    hs = HostSimGraph(csr_from_oracle(og))
+    og.mark_repeats(); hs.mark_repeats(); og.filter(); hs.filter()
+    og.makescaffold(True)
+    assert hs.makescaffold(fast_walks=1) == 0
+    assert np.array_equal(og.vertex_states(), hs.vertex_states())
+    assert np.array_equal(og.edge_states(), hs.edge_states())
+    assert hs.slow_walks <= hs.fast_walks // 50
