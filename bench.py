@@ -30,7 +30,8 @@ from __graft_entry__ import load_package  # noqa: E402
 # north_star's 10M-contig / 100M-edge graph; it fits one GPU)
 WORKLOAD = dict(name="synthetic 10M-contig / 100M-edge scaffold graph",
                 n_contigs=10_000_000,
-                gen=dict(links_per_side=5, p_repeat=0.03, repeat_degree=43, p_inversion=0.0))
+                gen=dict(links_per_side=5, p_repeat=0.03, repeat_degree=43, p_inversion=0.0,
+                         unique_pairs=True))
 CUTS = dict(copy_num_cutoff=0.3, astat_cutoff=20.0, pcutoff=0.01, cncutoff=1.5, ocutoff=400)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 

@@ -28,7 +28,7 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
                scaffold_median=20, scaffold_sigma=1.0, p_repeat=0.02, repeat_degree=24,
                p_bubble=0.02, p_chimeric=0.01, p_missing_astat=0.01, p_relist=0.01,
                p_link=0.97, contig_median=900, dist_range_small=False, scaffold_max=20000,
-               p_relist_flip=0.0, min_dist=-99, p_inversion=1.0):
+               p_relist_flip=0.0, min_dist=-99, p_inversion=1.0, unique_pairs=False):
     """Returns a dict of tensors:
       seq_len[u64 as i64], astat[f32], copy_num[f32]          (per contig)
       root[i32], ctg[i32], dist[i64], std_dev[f32], num_pairs[i64], flags[u8]
@@ -104,6 +104,23 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
     cb = torch.where(near, (ca + randint(-30, 31, n_chi)).clamp_(0, n - 1), randint(0, n, n_chi))
     keep = ca != cb
     ca, cb = ca[keep], cb[keep]
+    if unique_pairs:
+        # one estimate per contig pair, as in a real DistEst file: drop a false
+        # link that repeats a pair (it would give the pair's two directed edges
+        # contradicting geometry)
+        tkey = torch.minimum(pa, pb) * n + torch.maximum(pa, pb)
+        ckey = torch.minimum(ca, cb) * n + torch.maximum(ca, cb)
+        keep = ~torch.isin(ckey, tkey)
+        ca, cb, ckey = ca[keep], cb[keep], ckey[keep]
+        _, first = torch.unique(ckey, return_inverse=True)
+        seen = torch.zeros(int(first.max().item()) + 1 if first.numel() else 1, dtype=torch.bool,
+                           device=dev)
+        order_c = torch.arange(ckey.numel(), device=dev)
+        firstpos = torch.full_like(seen, 0, dtype=torch.int64).scatter_reduce(
+            0, first, order_c, reduce="amin", include_self=False) if first.numel() else None
+        if first.numel():
+            keep = firstpos[first] == order_c
+            ca, cb = ca[keep], cb[keep]
     cd = randint(-90, reach, ca.numel())
     # repeat links
     rep_pos = pos[is_rep]
