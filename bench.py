@@ -186,6 +186,11 @@ def main():
                           ("us_sum_removecycles", "us_max_removecycles", "us_sum_makescaffold_other",
                            "us_max_makescaffold_other", "us_sum_walks_fast", "us_max_walks_fast",
                            "us_sum_walks_reference", "us_max_walks_reference")},
+                       left_linear_walk_because={k[4:]: eng.stat(k) for k in
+                                                 ("why_mixed_start", "why_self_arc", "why_back_at_start",
+                                                  "why_marked_end", "why_two_directions",
+                                                  "why_inexact_tie", "why_cycle",
+                                                  "why_inexact_length_tie")},
                        slowest_reference_components=[
                            {k: eng.stat("top%d_%s" % (r, k)) for k in ("size", "ref_walks", "ref_us", "ref_pops")}
                            for r in range(3)]),

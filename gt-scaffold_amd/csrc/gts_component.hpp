@@ -83,6 +83,9 @@ struct GtsCompView {
   uint64_t *plen;            /* slot -> contig length of the tree path */
   uint8_t *tight;            /* slot -> number of tight in-arcs (saturating) */
   uint32_t *stat_fast, *stat_slow;  /* per component: walks by path taken */
+  unsigned long long *why;   /* [8] why walks left the linear path: mixed start,
+                                self arc, back at start, marked end, two
+                                directions, inexact tie, cycle, inexact length tie */
   uint64_t *tstat;           /* per component x5: ticks in removecycles, makescaffold
                                 outside walks, fast walks, reference walks; pops of
                                 the reference walks */
@@ -696,6 +699,116 @@ struct GtsComponent {
     return ea > eb;
   }
 
+
+  /* Reachable states with a cycle (single direction per vertex, no u-turn
+     arcs, start not re-entered: checked by pass 1 of create_walk_fast).
+     In exact arithmetic the reference's search ends with the shortest-path
+     labels whatever the order, only a value equal to the final label of v --
+     it can only come from a node carrying the final label of its source --
+     can fix edgemap[v], and the final node of v is pushed when the final node
+     of its first tight source is popped.  Hence edgemap and the pop order of
+     the final nodes are those of a FIFO search over the tight arcs, adjacency
+     lists in list order.  Labels: queue relaxation with an in-queue flag
+     (bounded pops, gives up on negative cycles). */
+  GTS_HD bool walk_cyclic(uint32_t start, uint32_t nr, uint64_t &best_len, uint32_t &best_t)
+  {
+    const uint32_t lane = W::lane();
+    auto R = M.queue;
+    auto TQ = M.visited;
+    auto BQ = M.wterm;
+    auto orient = M.st_dir;
+    auto inq = M.tight;
+    for (uint32_t k = lane; k < nr; k += W::WIDTH) {
+      const uint32_t v = R[k];
+      M.distmap[v] = GTS_DIST_UNSET;
+      inq[v] = 0;
+    }
+    W::fence();
+    bool inexact = false, bad = false;
+    uint64_t qh2 = 0, qt = 1, pops = 0;
+    const uint64_t max_pops = 64ull * nr + 64;
+    TQ[0] = start;
+    W::fence();
+    while (qh2 < qt && !bad) {
+      const uint32_t u = W::uni(TQ[qh2 % nv]);
+      ++qh2;
+      if (++pops > max_pops) { bad = true; break; }
+      inq[u] = 0;
+      const bool du = (W::uni((uint32_t)orient[u]) & 3u) == 2;
+      const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
+      const uint32_t eb = eoff(u), ee = eoff(u + 1);
+      for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool push = false;
+        uint32_t v = 0;
+        if (ce < ee && !gts_edge_is_marked(M.cstate[ce]) &&
+            ((M.cflags[ce] & GTS_F_SENSE) != 0) == du) {
+          v = M.cend[ce];
+          const int64_t w = M.cdist[ce];
+          const float cand = u == start ? (float)w : (float)(ndu + w);
+          const float old = M.distmap[v];
+          if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
+          if (old == GTS_DIST_UNSET || old > cand) {
+            M.distmap[v] = cand;
+            M.nd[v] = u == start ? w : (int64_t)cand;
+            push = inq[v] == 0;
+            if (push) inq[v] = 1;
+          }
+        }
+        const uint64_t pm = W::ballot(push);
+        if (push) TQ[(qt + W::popc_below(pm, lane)) % nv] = v;
+        qt += W::popc(pm);
+        W::fence();
+      }
+    }
+    if (W::ballot(inexact)) bad = true;
+    if (bad) return false;
+    /* FIFO search over the tight arcs */
+    uint32_t bh = 0, bt = 1;
+    best_len = 0; best_t = GTS_NONE;
+    BQ[0] = start;
+    M.plen[start] = (uint64_t)M.cseq[start];
+    W::fence();
+    while (bh < bt) {
+      const uint32_t u = W::uni(BQ[bh]);
+      ++bh;
+      const bool du = (W::uni((uint32_t)orient[u]) & 3u) == 2;
+      const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
+      const uint64_t plu = (uint64_t)W::uni64((int64_t)M.plen[u]);
+      const uint32_t eb = eoff(u), ee = eoff(u + 1);
+      bool us = false, ua = false;
+      for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool live = false, sense = false, take = false;
+        uint32_t v = 0;
+        if (ce < ee) {
+          live = !gts_edge_is_marked(M.cstate[ce]);
+          sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+          if (live && sense == du) {
+            v = M.cend[ce];
+            const int64_t w = M.cdist[ce];
+            const float cand = u == start ? (float)w : (float)(ndu + w);
+            take = cand == M.distmap[v] && !(orient[v] & 4u);
+          }
+        }
+        us |= W::ballot(live && sense) != 0;
+        ua |= W::ballot(live && !sense) != 0;
+        const uint64_t tm = W::ballot(take);
+        if (take) {
+          orient[v] = (uint8_t)(orient[v] | 4u);
+          M.edgemap[v] = ce;
+          M.plen[v] = plu + (uint64_t)M.cseq[v];
+          BQ[bt + W::popc_below(tm, lane)] = v;
+        }
+        bt += W::popc(tm);
+        W::fence();
+      }
+      /* later final node = later pop: on equal length the later terminal wins */
+      if (u != start && !(us && ua) && plu >= best_len && plu > 0) { best_len = plu; best_t = u; }
+    }
+    return bt == nr;
+  }
+
   GTS_HD bool create_walk_fast(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t lane = W::lane();
@@ -719,7 +832,7 @@ struct GtsComponent {
         has_a |= W::ballot(live && !sense) != 0;
       }
     }
-    if (has_s && has_a) return false;
+    if (has_s && has_a) { W::count(C.why + 0); return false; }
     if (!has_s && !has_a) return true;          /* nothing reachable: empty walk */
     /* pass 1: reachable states, in-degrees */
     uint32_t nr = 1, rh = 0;
@@ -745,11 +858,18 @@ struct GtsComponent {
             od = gts_next_dir((uint8_t)fl) ? 2u : 1u;
             const uint32_t ov = orient[v];
             clash = v == u || v == start || gts_vertex_is_marked(M.vst[v]) ||
-                    (ov != 0 && ov != od);
+                    (ov != 0 && ov != od) || (fl & GTS_F_UTURN);
             fresh = ov == 0;
           }
         }
-        if (W::ballot(clash)) { bad = true; break; }
+        const uint64_t cm = W::ballot(clash);
+        if (cm) {
+          const uint32_t l = W::ctz(cm), cv = W::bcast(v, l);
+          const bool ut = (W::bcast((uint32_t)(ce < ee ? M.cflags[ce] : 0), l) & GTS_F_UTURN) != 0;
+          W::count(C.why + (cv == u || ut ? 1 : cv == start ? 2
+                            : gts_vertex_is_marked((uint8_t)W::uni(M.vst[cv])) ? 3 : 4));
+          bad = true; break;
+        }
         const uint64_t fm = W::ballot(arc && fresh);
         if (arc) {
           if (fresh) {
@@ -814,7 +934,7 @@ struct GtsComponent {
              value arrived first (algorithms.c:711-717), i.e. the arc whose
              source's final node is pushed first */
           uint64_t tm = W::ballot(tie);
-          if (tm && inexact) { bad = true; break; }
+          if (tm && inexact) { W::count(C.why + 5); bad = true; break; }
           while (tm) {
             const uint32_t l = W::ctz(tm);
             tm &= tm - 1;
@@ -838,12 +958,16 @@ struct GtsComponent {
         if (!bad && u != start && !(us && ua)) {
           if (plu > best_len) { best_len = plu; best_t = u; }
           else if (plu == best_len && best_t != GTS_NONE) {
-            if (inexact) bad = true;
+            if (inexact) { W::count(C.why + 7); bad = true; }
             else if (pushed_after(u, best_t, start)) best_t = u;
           }
         }
       }
-      if (processed != nr) bad = true;                    /* cycle */
+      if (!bad && processed != nr) {
+        /* the reachable states hold a cycle: labels by a queue-based
+           relaxation, tie-breaks by a FIFO search over the tight arcs */
+        if (!walk_cyclic(start, nr, best_len, best_t)) { W::count(C.why + 6); bad = true; }
+      }
     }
     if (!bad && best_t != GTS_NONE && best_len > cc_len) {
       uint32_t cv = best_t, n = 0;
@@ -860,6 +984,7 @@ struct GtsComponent {
       const uint32_t v = R[k];
       orient[v] = 0;
       M.distmap[v] = GTS_DIST_UNSET;
+      M.tight[v] = 0;
     }
     W::fence();
     return !bad;
@@ -970,6 +1095,7 @@ struct GtsWave1 {
   static GTS_HD int64_t uni64(int64_t v) { return v; }
   static GTS_HD void fence() {}
   static GTS_HD uint64_t clock() { return 0; }
+  static GTS_HD void count(unsigned long long *p) { ++*p; }
   static GTS_HD uint64_t alloc(unsigned long long *used, uint64_t n)
   { const uint64_t o = *used; *used += n; return o; }
   static GTS_HD uint32_t clz32(uint32_t v) { uint32_t n = 0; while (n < 32 && !(v & (0x80000000u >> n))) ++n; return n; }

@@ -28,6 +28,11 @@ enum : uint8_t {
 #define GTS_NONE 0xFFFFFFFFu
 #define GTS_F_SENSE 1u   /* edge flag bit0: sense, bit1: same (graph.h:63-69) */
 #define GTS_F_SAME 2u
+/* compact edges only: the twin would be followed right after this edge (its
+   sense equals the direction in which this edge leaves its end vertex), i.e.
+   the pair is geometrically inconsistent and the reference's twin exclusion
+   (algorithms.c:702) becomes path dependent */
+#define GTS_F_UTURN 4u
 
 /* ref gt_scaffolder_algorithms.c:38-47 */
 GTS_HD bool gts_vertex_is_marked(uint8_t s)

@@ -605,7 +605,9 @@ __global__ void k_compact_fill(GtsGraphView G, const uint8_t *live,
   for (uint32_t p = G.row[v]; p < G.row[v + 1]; ++p)
     if (live[p] || live[G.twin[p]]) {
       cstart[k] = (uint32_t)s - slot_base[s]; cend[k] = slot_of[G.end[p]] - slot_base[s];
-      cdist[k] = G.dist[p]; cflags[k] = G.flags[p]; cgpos[k] = p;
+      const uint8_t f = G.flags[p], ft = G.flags[G.twin[p]];
+      const bool uturn = ((ft & GTS_F_SENSE) != 0) == gts_next_dir(f);
+      cdist[k] = G.dist[p]; cflags[k] = (uint8_t)((f & 3u) | (uturn ? GTS_F_UTURN : 0u)); cgpos[k] = p;
       cstate[k] = G.state[p]; cmap[p] = k;
       ++k;
     }
@@ -637,6 +639,8 @@ struct GtsWave64 {
   { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
   /* constant 100 MHz counter (s_memrealtime) */
   static __device__ __forceinline__ uint64_t clock() { return wall_clock64(); }
+  static __device__ __forceinline__ void count(unsigned long long *p)
+  { if (lane() == 0) atomicAdd(p, 1ull); }
   static __device__ __forceinline__ uint32_t clz32(uint32_t v) { return (uint32_t)__clz((int)v); }
   /* inclusive prefix sum of values < 128: one ballot per bit, the lower-lane
      population count of each ballot weighted by the bit */
@@ -1310,6 +1314,8 @@ static int run_components(GtsgEngine *e, int mode)
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
     C.fast_walks = (int)e->fast_walks; C.nd = s_nd; C.plen = s_plen; C.tight = s_tight;
     C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat;
+    C.why = (unsigned long long *)(e->d_scalars + 96);
+    HIPCHK(hipMemsetAsync(C.why, 0, 64, e->st));
     {
       /* order[] is sorted by decreasing footprint: the global-memory class
          (larger than every LDS class, or all if LDS is disabled) comes first,
@@ -1358,6 +1364,8 @@ static int run_components(GtsgEngine *e, int mode)
            (unsigned long long *)(e->d_scalars + 32));
     uint64_t ts[8];
     HIPCHK(hipMemcpyAsync(ts, e->d_scalars + 32, 64, hipMemcpyDeviceToHost, e->st));
+    uint64_t why[8];
+    HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 64, hipMemcpyDeviceToHost, e->st));
     uint32_t res[3] = {0, 0, 0};
     uint64_t wstat[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 12, hipMemcpyDeviceToHost, e->st));
@@ -1386,6 +1394,12 @@ static int run_components(GtsgEngine *e, int mode)
         e->stats[pre + "ref_pops"] = (int64_t)ht[5 * (size_t)best + 4];
         ht[5 * (size_t)best + 3] = 0;
       }
+    }
+    {
+      static const char *wn[8] = {"why_mixed_start", "why_self_arc", "why_back_at_start",
+                                  "why_marked_end", "why_two_directions", "why_inexact_tie",
+                                  "why_cycle", "why_inexact_length_tie"};
+      for (int k = 0; k < 8; ++k) e->stats[wn[k]] = (int64_t)why[k];
     }
     e->stats["fast_walks"] = (int64_t)wstat[0];
     e->stats["slow_walks"] = (int64_t)wstat[1];

@@ -193,7 +193,9 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
       if (incl(p)) {
         cstart[k] = s - lab_first[label[v]]; cend[k] = slot_of[end[p]] - lab_first[label[v]];
         cdist[k] = dist[p];
-        cflags[k] = flags[p]; cstate[k] = state[p]; cgpos[k] = p; cmap[p] = k; k++;
+        const bool uturn = ((flags[twin[p]] & GTS_F_SENSE) != 0) == gts_next_dir(flags[p]);
+        cflags[k] = (uint8_t)((flags[p] & 3u) | (uturn ? GTS_F_UTURN : 0u));
+        cstate[k] = state[p]; cgpos[k] = p; cmap[p] = k; k++;
       }
   }
   uint32_t maxcomp = 0;
@@ -225,7 +227,8 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   std::vector<uint32_t> sf(ncomp ? ncomp : 1, 0), ss(ncomp ? ncomp : 1, 0);
   C.fast_walks = fast_walks; C.nd = nd.data(); C.plen = plen.data(); C.tight = tight.data();
   std::vector<uint64_t> tstat(5 * (size_t)(ncomp ? ncomp : 1), 0);
-  C.stat_fast = sf.data(); C.stat_slow = ss.data(); C.tstat = tstat.data();
+  unsigned long long why[8] = {0};
+  C.stat_fast = sf.data(); C.stat_slow = ss.data(); C.tstat = tstat.data(); C.why = why;
   uint32_t nerr = 0;
   for (uint32_t c = 0; c < ncomp; c++) {
     GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);

@@ -120,6 +120,14 @@ def test_global_memory_components_match_lds_components():
     assert eng.digest() == eng2.digest()
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_misjoin_heavy_graphs_need_no_reference_search(seed):
+    g = make_inputs(6000, 900 + seed, p_chimeric=0.15, p_inversion=0.0, p_bubble=0.05,
+                    links_per_side=4, p_relist=0.05)
+    eng, _ = run_pipeline(g)
+    assert eng.stat("slow_walks") == 0 and eng.stat("fast_walks") > 0
+
+
 def test_fast_walks_resolve_ties():
     g = make_inputs(3000, 21, dist_range_small=True, contig_median=300)
     eng, _ = run_pipeline(g)

@@ -107,3 +107,20 @@ def test_ties_are_resolved_in_the_linear_walk(seed):
     assert np.array_equal(og.vertex_states(), hs.vertex_states())
     assert np.array_equal(og.edge_states(), hs.edge_states())
     assert hs.slow_walks <= hs.fast_walks // 50
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cyclic_state_graphs_take_the_queue_relaxation_path(seed):
+    # many plain misjoins: cycles that the reference's DFS does not remove (twins
+    # revived by SCAFFOLD marks, asymmetric edge states) reach the walks; the
+    # linear walk then uses queue relaxation + FIFO search over tight arcs
+    g = make_inputs(1500, 900 + seed, p_chimeric=0.15, p_inversion=0.0, p_bubble=0.05,
+                    links_per_side=4, p_relist=0.05)
+    og = oracle_from_inputs(g)
+    hs = HostSimGraph(csr_from_oracle(og))
+    og.mark_repeats(); hs.mark_repeats(); og.filter(); hs.filter()
+    og.makescaffold(True)
+    assert hs.makescaffold(fast_walks=1) == 0
+    assert np.array_equal(og.vertex_states(), hs.vertex_states())
+    assert np.array_equal(og.edge_states(), hs.edge_states())
+    assert hs.slow_walks == 0
