@@ -26,7 +26,7 @@
 #include <string>
 #include <vector>
 
-#define GTS_NKLASS 4
+#define GTS_NKLASS 6
 
 #include "../../include/gt_scaffold_hip.h"
 #include "gts_amb_host.h"
@@ -42,8 +42,8 @@ struct GtsgEngine {
   int device = 0;
   hipStream_t st = nullptr;
   bool own_stream = false;
-  hipStream_t side[GTS_NKLASS] = {nullptr, nullptr, nullptr, nullptr};  /* class launches */
-  hipEvent_t ev_fork = nullptr, ev_join[GTS_NKLASS] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t side[GTS_NKLASS] = {};  /* class launches */
+  hipEvent_t ev_fork = nullptr, ev_join[GTS_NKLASS] = {};
   std::string err;
   /* vertices */
   uint32_t n = 0;
@@ -59,6 +59,7 @@ struct GtsgEngine {
   uint8_t *flags = nullptr, *state = nullptr;
   uint32_t nhub = 0;
   uint32_t *hubs = nullptr;
+  bool built = false;
   /* workspace */
   char *pool = nullptr;
   size_t pool_cap = 0, pool_used = 0;
@@ -74,6 +75,7 @@ struct GtsgEngine {
   std::vector<hipEvent_t> free_events;
   std::map<std::string, std::pair<uint64_t, double>> ktimes;
   std::map<std::string, int64_t> stats;
+  std::map<void *, size_t> alloc_bytes;
 };
 
 static int fail(GtsgEngine *e, int code, const char *fmt, ...)
@@ -182,14 +184,19 @@ static T *pool_alloc(GtsgEngine *e, size_t count)
   T *var = pool_alloc<T>(e, (count));                                         \
   if (!var) return GTSG_ENOMEM
 
+/* persistent arrays keep their allocation between calls when it is large
+   enough (hipFree/hipMalloc of multi-GB arrays costs milliseconds) */
 template <typename T>
 static int dev_alloc(GtsgEngine *e, T **p, size_t count)
 {
-  if (*p) { hipFree(*p); *p = nullptr; }
-  hipError_t r = hipMalloc((void **)p, (count ? count : 1) * sizeof(T));
+  const size_t bytes = (count ? count : 1) * sizeof(T);
+  auto it = e->alloc_bytes.find((void *)*p);
+  if (*p && it != e->alloc_bytes.end() && it->second >= bytes) return 0;
+  if (*p) { e->alloc_bytes.erase((void *)*p); hipFree(*p); *p = nullptr; }
+  hipError_t r = hipMalloc((void **)p, bytes + bytes / 16);
   if (r != hipSuccess)
-    return fail(e, GTSG_ENOMEM, "hipMalloc(%zu): %s", count * sizeof(T),
-                hipGetErrorString(r));
+    return fail(e, GTSG_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(r));
+  e->alloc_bytes[(void *)*p] = bytes + bytes / 16;
   return 0;
 }
 
@@ -897,14 +904,16 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
   return 0;
 }
 
-static void free_graph(GtsgEngine *e)
+static void free_graph(GtsgEngine *e, bool release)
 {
-  void *ptrs[] = {e->row, e->estart, e->eend, e->twin, e->eid, e->pos_of_eid,
-                  e->dist, e->npairs, e->sd, e->flags, e->state, e->hubs};
-  for (void *p : ptrs) if (p) hipFree(p);
-  e->row = e->estart = e->eend = e->twin = e->eid = e->pos_of_eid = e->hubs = nullptr;
-  e->dist = e->npairs = nullptr; e->sd = nullptr; e->flags = e->state = nullptr;
-  e->m = 0; e->nhub = 0;
+  if (release) {
+    void *ptrs[] = {e->row, e->estart, e->eend, e->twin, e->eid, e->pos_of_eid,
+                    e->dist, e->npairs, e->sd, e->flags, e->state, e->hubs};
+    for (void *p : ptrs) if (p) { e->alloc_bytes.erase(p); hipFree(p); }
+    e->row = e->estart = e->eend = e->twin = e->eid = e->pos_of_eid = e->hubs = nullptr;
+    e->dist = e->npairs = nullptr; e->sd = nullptr; e->flags = e->state = nullptr;
+  }
+  e->m = 0; e->nhub = 0; e->built = false;
 }
 
 void gtsg_destroy(GtsgEngine *e)
@@ -913,7 +922,7 @@ void gtsg_destroy(GtsgEngine *e)
   hipSetDevice(e->device);
   hipStreamSynchronize(e->st);
   collect_times(e);
-  free_graph(e);
+  free_graph(e, true);
   void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->pool, e->d_scalars};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto ev : e->free_events) hipEventDestroy(ev);
@@ -948,7 +957,7 @@ int gtsg_set_contigs(GtsgEngine *e, uint64_t n, const int64_t *seq_len,
   if (!e || (n && !seq_len)) return GTSG_EINVAL;
   if (n >= (1ull << 31)) return fail(e, GTSG_ELIMIT, "more than 2^31-1 contigs");
   HIPCHK(hipSetDevice(e->device));
-  free_graph(e);
+  free_graph(e, false);
   e->n = (uint32_t)n;
   int rc;
   if ((rc = dev_alloc(e, &e->seq_len, n))) return rc;
@@ -983,7 +992,7 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
   if (!e || (nrec && (!root || !ctg || !dist || !std_dev || !flags))) return GTSG_EINVAL;
   if (nrec >= (1ull << 31) - 1) return fail(e, GTSG_ELIMIT, "too many records");
   HIPCHK(hipSetDevice(e->device));
-  free_graph(e);
+  free_graph(e, false);
   const uint32_t n = e->n;
   int rc;
   /* workspace estimate (bytes per record / edge, generous) */
@@ -1093,13 +1102,14 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
     if (nh) LAUNCH("build_hub_list", k_compact_ids, nblk(n), GTS_BLOCK, hflag, hidx, e->hubs, n);
   }
   e->stats["hubs"] = e->nhub;
+  e->built = true;
   return sync_stream(e);
 }
 
 int gtsg_mark_repeats(GtsgEngine *e, int have_file, float copy_num_cutoff,
                       float astat_cutoff)
 {
-  if (!e || !e->row) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
+  if (!e || !e->built) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
   HIPCHK(hipSetDevice(e->device));
   if (e->n)
     LAUNCH("repeat_vertices", k_repeat_vertices, nblk(e->n), GTS_BLOCK, e->astat,
@@ -1112,7 +1122,7 @@ int gtsg_mark_repeats(GtsgEngine *e, int have_file, float copy_num_cutoff,
 
 int gtsg_filter(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff)
 {
-  if (!e || !e->row) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
+  if (!e || !e->built) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
   HIPCHK(hipSetDevice(e->device));
   const uint32_t n = e->n, m = e->m;
   if (!n) return 0;
@@ -1175,7 +1185,7 @@ int gtsg_filter(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff)
 
 static int run_components(GtsgEngine *e, int mode)
 {
-  if (!e || !e->row) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
+  if (!e || !e->built) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
   HIPCHK(hipSetDevice(e->device));
   const uint32_t n = e->n, m = e->m;
   if (!n) return 0;
@@ -1284,7 +1294,7 @@ static int run_components(GtsgEngine *e, int mode)
     LAUNCH("fill", k_fill<float>, nblk(nslots), GTS_BLOCK, s_distmap, GTS_DIST_UNSET,
            (uint64_t)nslots);
     /* components by decreasing LDS footprint; size classes of the LDS launches */
-    static const uint32_t klass_h[GTS_NKLASS] = {4096, 16384, 65536, 163840};
+    static const uint32_t klass_h[GTS_NKLASS] = {4096, 8192, 16384, 32768, 65536, 163840};
     uint32_t *klass_d = e->d_scalars + 64, *klass_count = e->d_scalars + 72;
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, sizeof klass_h, hipMemcpyHostToDevice, e->st));
     HIPCHK(hipMemsetAsync(klass_count, 0, (GTS_NKLASS + 1) * 4, e->st));
@@ -1334,9 +1344,11 @@ static int run_components(GtsgEngine *e, int mode)
       for (int k = (int)nk - 1; k >= 0; --k) {
         if (!kcount[k]) continue;
         static const char *const kn[2][GTS_NKLASS] = {
-            {"components_removecycles_lds4k", "components_removecycles_lds16k",
+            {"components_removecycles_lds4k", "components_removecycles_lds8k",
+             "components_removecycles_lds16k", "components_removecycles_lds32k",
              "components_removecycles_lds64k", "components_removecycles_lds160k"},
-            {"components_makescaffold_lds4k", "components_makescaffold_lds16k",
+            {"components_makescaffold_lds4k", "components_makescaffold_lds8k",
+             "components_makescaffold_lds16k", "components_makescaffold_lds32k",
              "components_makescaffold_lds64k", "components_makescaffold_lds160k"}};
         hipStream_t ss = e->side[k];
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
