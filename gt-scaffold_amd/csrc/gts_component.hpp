@@ -334,10 +334,8 @@ struct GtsComponent {
     while (found) {
       found = false;
       calc_cc();
-      for (uint32_t s = lane; s < nv; s += W::WIDTH) {
+      for (uint32_t s = lane; s < nv; s += W::WIDTH)
         if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
-        M.st_dir[s] = 0;
-      }
       W::fence();
       /* the ccs are visited in order; their boundaries do not matter here */
       for (uint32_t j = 0; j < nterm; ++j) {
@@ -361,11 +359,8 @@ struct GtsComponent {
         }
         if (!set_dir) continue;
         if (gts_vertex_is_marked((uint8_t)W::uni(M.vst[start]))) continue;
-        if (C.fast_walks && dfs_is_futile(start, dir)) continue;
         uint32_t nvis = 0;
         const uint32_t back = detect_cycle(start, dir, nvis);
-        /* st_dir doubles as the per-vertex direction map of dfs_is_futile */
-        for (uint32_t k = lane; k < nvis; k += W::WIDTH) M.st_dir[k] = 0;
         for (uint32_t k = lane; k < nvis; k += W::WIDTH)
           M.vst[M.visited[k]] = GIS_UNVISITED;
         W::fence();
@@ -814,182 +809,6 @@ struct GtsComponent {
     return bt == nr;
   }
 
-  /* ---- batched frontier steps -------------------------------------------
-     Both passes of the linear walk consume a queue of vertices whose order
-     does not influence the result (see create_walk_fast), so one step lays the
-     adjacency lists of as many queue vertices as fit across the 64 lanes
-     instead of one list per step.  Returns the number of queue vertices
-     covered; 0 if the first one alone has more than WIDTH compact edges (the
-     caller then walks it in chunks).  Lane l < return value holds vertex qu,
-     lane a < take holds arc ace of vertex au. */
-  template <class Q>
-  GTS_HD uint32_t lay_out_arcs(Q q, uint32_t qh, uint32_t qt, uint32_t &qu,
-                               uint32_t &excl, uint32_t &incl, uint32_t &take,
-                               uint32_t &au, uint32_t &ace, bool &act)
-  {
-    const uint32_t lane = W::lane();
-    const uint32_t navail = qt - qh < W::WIDTH ? qt - qh : W::WIDTH;
-    uint32_t eb = 0, deg = 0;
-    qu = 0;
-    if (lane < navail) {
-      qu = q[qh + lane];
-      eb = M.coff[qu] - M.e0;
-      deg = M.coff[qu + 1] - M.e0 - eb;
-    }
-    const uint32_t degc = deg > W::WIDTH ? W::WIDTH + 1 : deg;
-    incl = W::scan_incl_small(degc);
-    excl = incl - degc;
-    const uint32_t nfit = W::popc(W::ballot(lane < navail && incl <= W::WIDTH));
-    if (nfit == 0) { take = 0; act = false; au = 0; ace = 0; return 0; }
-    take = W::bcast(incl, nfit - 1);
-    uint32_t r = 0;
-    for (uint32_t k = 1; k < nfit; ++k)
-      if (lane >= W::bcast(excl, k)) r = k;
-    act = lane < take;
-    const uint32_t rr = act ? r : 0;
-    au = W::shfl(qu, rr);
-    ace = W::shfl(eb, rr) + (lane - W::shfl(excl, rr));
-    return nfit;
-  }
-
-  /* lanes holding the same key among the lanes with q set */
-  GTS_HD uint64_t same_key_lanes(bool q, uint32_t key, uint32_t bits) const
-  {
-    uint64_t peers = W::ballot(q);
-    for (uint32_t bit = 0; bit < bits; ++bit) {
-      const bool one = (key >> bit) & 1u;
-      const uint64_t bm = W::ballot(q && one);
-      peers &= one ? bm : ~bm;
-    }
-    return q ? peers : 0;
-  }
-
-  /* pass 1 of the linear walk: the (vertex, direction) states reachable from
-     (start, dir): direction + 1 in orient[], number of in-arcs in indeg[], the
-     reached vertices in R[0..nr).  False if the states are not usable: a
-     vertex in both directions, the start re-entered, a u-turn arc. */
-  GTS_HD bool reach_pass(uint32_t start, bool dir_sense, uint32_t &nr)
-  {
-    const uint32_t lane = W::lane();
-    auto R = M.queue;
-    auto indeg = M.st_v;
-    auto orient = M.st_dir;
-    const uint32_t tbits = 32u - W::clz32(nv > 1 ? nv - 1 : 1);
-    uint32_t rh = 0;
-    bool bad = false;
-    nr = 1;
-    R[0] = start;
-    orient[start] = dir_sense ? 2 : 1;
-    indeg[start] = 0;
-    W::fence();
-    while (rh < nr && !bad) {
-      uint32_t qu, excl, incl, take, au, ace;
-      bool act;
-      const uint32_t nn = lay_out_arcs(R, rh, nr, qu, excl, incl, take, au, ace, act);
-      const bool single = nn == 0;
-      const uint32_t u1 = W::uni(R[rh]);
-      const uint32_t cb = single ? eoff(u1) : 0, cee = single ? eoff(u1 + 1) : 0;
-      for (uint32_t base = cb; single ? base < cee : base == 0; base += W::WIDTH) {
-        if (single) { au = u1; ace = base + lane; act = ace < cee; }
-        bool arc = false, clash = false;
-        uint32_t v = 0, od = 0, why = 4;
-        if (act) {
-          const uint32_t fl = M.cflags[ace];
-          const bool du = orient[au] == 2;
-          arc = !gts_edge_is_marked(M.cstate[ace]) && ((fl & GTS_F_SENSE) != 0) == du;
-          if (arc) {
-            v = M.cend[ace];
-            od = gts_next_dir((uint8_t)fl) ? 2u : 1u;
-            const uint32_t ov = orient[v];
-            if (v == au || (fl & GTS_F_UTURN)) { clash = true; why = 1; }
-            else if (v == start) { clash = true; why = 2; }
-            else if (gts_vertex_is_marked(M.vst[v])) { clash = true; why = 3; }
-            else if (ov != 0 && ov != od) clash = true;
-          }
-        }
-        const uint64_t peers = same_key_lanes(arc && !clash, v, tbits);
-        const uint64_t lt = W::lanemask_lt(lane);
-        const bool lead = arc && !clash && (peers & lt) == 0;
-        const bool fresh = lead && orient[v] == 0;
-        W::fence();
-        if (fresh) { orient[v] = (uint8_t)od; indeg[v] = 0; }
-        W::fence();
-        /* lanes that reach v in another direction than the one just recorded */
-        if (arc && !clash && orient[v] != od) clash = true;
-        const uint64_t cm = W::ballot(clash);
-        if (cm) { W::count(C.why + W::bcast(why, W::ctz(cm))); bad = true; break; }
-        if (lead) indeg[v] = indeg[v] + W::popc(peers);
-        const uint64_t fm = W::ballot(fresh);
-        if (fresh) R[nr + W::popc_below(fm, lane)] = v;
-        nr += W::popc(fm);
-        W::fence();
-      }
-      rh += single ? 1 : nn;
-    }
-    return !bad;
-  }
-
-  /* no cycle among the reached states: peel vertices without unprocessed
-     in-arcs (indeg[] from reach_pass is consumed) */
-  GTS_HD bool peel_pass(uint32_t start, uint32_t nr)
-  {
-    const uint32_t lane = W::lane();
-    auto TQ = M.visited;
-    auto indeg = M.st_v;
-    auto orient = M.st_dir;
-    const uint32_t tbits = 32u - W::clz32(nv > 1 ? nv - 1 : 1);
-    uint32_t qh2 = 0, nq = 1;
-    TQ[0] = start;
-    W::fence();
-    while (qh2 < nq) {
-      uint32_t qu, excl, incl, take, au, ace;
-      bool act;
-      const uint32_t nn = lay_out_arcs(TQ, qh2, nq, qu, excl, incl, take, au, ace, act);
-      const bool single = nn == 0;
-      const uint32_t u1 = W::uni(TQ[qh2]);
-      const uint32_t cb = single ? eoff(u1) : 0, cee = single ? eoff(u1 + 1) : 0;
-      for (uint32_t base = cb; single ? base < cee : base == 0; base += W::WIDTH) {
-        if (single) { au = u1; ace = base + lane; act = ace < cee; }
-        bool arc = false;
-        uint32_t v = 0;
-        if (act) {
-          arc = !gts_edge_is_marked(M.cstate[ace]) &&
-                ((M.cflags[ace] & GTS_F_SENSE) != 0) == (orient[au] == 2);
-          if (arc) v = M.cend[ace];
-        }
-        const uint64_t peers = same_key_lanes(arc, v, tbits);
-        const bool lead = arc && (peers & W::lanemask_lt(lane)) == 0;
-        bool ready = false;
-        if (lead) {
-          const uint32_t d = indeg[v] - W::popc(peers);
-          indeg[v] = d;
-          ready = d == 0;
-        }
-        const uint64_t rm = W::ballot(ready);
-        if (ready) TQ[nq + W::popc_below(rm, lane)] = v;
-        nq += W::popc(rm);
-        W::fence();
-      }
-      qh2 += single ? 1 : nn;
-    }
-    return nq == nr;
-  }
-
-  /* removecycles' DFS from `start` (algorithms.c:448-492) cannot meet a vertex
-     that is still on its stack if the states it can reach form a DAG with one
-     direction per vertex and no u-turn arc: then it returns NULL and leaves no
-     trace (algorithms.c:550-553).  Returns true if that is proven. */
-  GTS_HD bool dfs_is_futile(uint32_t start, bool dir)
-  {
-    const uint32_t lane = W::lane();
-    uint32_t nr = 0;
-    bool ok = reach_pass(start, dir, nr);
-    if (ok) ok = peel_pass(start, nr);
-    for (uint32_t k = lane; k < nr; k += W::WIDTH) M.st_dir[M.queue[k]] = 0;
-    W::fence();
-    return ok;
-  }
-
   GTS_HD bool create_walk_fast(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t lane = W::lane();
@@ -1015,89 +834,103 @@ struct GtsComponent {
     }
     if (has_s && has_a) { W::count(C.why + 0); return false; }
     if (!has_s && !has_a) return true;          /* nothing reachable: empty walk */
-    uint32_t nr = 1;
-    bool bad = !reach_pass(start, has_s, nr);
+    /* pass 1: reachable states, in-degrees */
+    uint32_t nr = 1, rh = 0;
+    bool bad = false;
+    R[0] = start;
+    orient[start] = has_s ? 2 : 1;              /* direction + 1 */
+    indeg[start] = 0;
+    W::fence();
+    while (rh < nr && !bad) {
+      const uint32_t u = W::uni(R[rh]);
+      ++rh;
+      const bool du = W::uni((uint32_t)orient[u]) == 2;
+      const uint32_t eb = eoff(u), ee = eoff(u + 1);
+      for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool arc = false, fresh = false, clash = false;
+        uint32_t v = 0, od = 0;
+        if (ce < ee) {
+          const uint32_t fl = M.cflags[ce];
+          arc = !gts_edge_is_marked(M.cstate[ce]) && ((fl & GTS_F_SENSE) != 0) == du;
+          if (arc) {
+            v = M.cend[ce];
+            od = gts_next_dir((uint8_t)fl) ? 2u : 1u;
+            const uint32_t ov = orient[v];
+            clash = v == u || v == start || gts_vertex_is_marked(M.vst[v]) ||
+                    (ov != 0 && ov != od) || (fl & GTS_F_UTURN);
+            fresh = ov == 0;
+          }
+        }
+        const uint64_t cm = W::ballot(clash);
+        if (cm) {
+          const uint32_t l = W::ctz(cm), cv = W::bcast(v, l);
+          const bool ut = (W::bcast((uint32_t)(ce < ee ? M.cflags[ce] : 0), l) & GTS_F_UTURN) != 0;
+          W::count(C.why + (cv == u || ut ? 1 : cv == start ? 2
+                            : gts_vertex_is_marked((uint8_t)W::uni(M.vst[cv])) ? 3 : 4));
+          bad = true; break;
+        }
+        const uint64_t fm = W::ballot(arc && fresh);
+        if (arc) {
+          if (fresh) {
+            orient[v] = (uint8_t)od;
+            indeg[v] = 1;
+            R[nr + W::popc_below(fm, lane)] = v;
+          } else
+            indeg[v] = indeg[v] + 1;
+        }
+        nr += W::popc(fm);
+        W::fence();
+      }
+    }
     /* pass 2: relaxation in topological order */
-    const uint32_t tbits = 32u - W::clz32(nv > 1 ? nv - 1 : 1);
     uint32_t nq = 1, qh2 = 0, processed = 0, best_t = GTS_NONE;
     uint64_t best_len = 0;
     bool inexact = false;     /* a label left the range where floats are exact */
     if (!bad) {
       TQ[0] = start;
       M.plen[start] = (uint64_t)M.cseq[start];
-      depth[start] = 0;
-      M.nd[start] = 0;
       W::fence();
       while (qh2 < nq && !bad) {
-        uint32_t qu, excl, incl, take, au, ace;
-        bool act;
-        const uint32_t nn = lay_out_arcs(TQ, qh2, nq, qu, excl, incl, take, au, ace, act);
-        const bool single = nn == 0;
-        const uint32_t u1 = W::uni(TQ[qh2]);
-        const uint32_t cb = single ? eoff(u1) : 0, cee = single ? eoff(u1 + 1) : 0;
-        bool us1 = false, ua1 = false;       /* single mode: flags of u1 */
-        uint64_t bs = 0, ba = 0;
-        for (uint32_t base = cb; single ? base < cee : base == 0; base += W::WIDTH) {
-          if (single) { au = u1; ace = base + lane; act = ace < cee; }
-          bool live = false, sense = false, arc = false;
+        const uint32_t u = W::uni(TQ[qh2]);
+        ++qh2; ++processed;
+        const bool du = W::uni((uint32_t)orient[u]) == 2;
+        const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
+        const uint64_t plu = (uint64_t)W::uni64((int64_t)M.plen[u]);
+        const uint32_t dpu = u == start ? 0 : W::uni(depth[u]);
+        const uint32_t eb = eoff(u), ee = eoff(u + 1);
+        bool us = false, ua = false;
+        for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
+          const uint32_t ce = base + lane;
+          bool live = false, sense = false, arc = false, ready = false, tie = false;
           uint32_t v = 0;
-          float cand = 0.0f, old = 0.0f;
-          int64_t w = 0;
-          uint64_t plu = 0;
-          uint32_t dpu = 0;
-          if (act) {
-            live = !gts_edge_is_marked(M.cstate[ace]);
-            sense = (M.cflags[ace] & GTS_F_SENSE) != 0;
-            arc = live && sense == (orient[au] == 2);
+          if (ce < ee) {
+            live = !gts_edge_is_marked(M.cstate[ce]);
+            sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+            arc = live && sense == du;
             if (arc) {
-              v = M.cend[ace];
-              w = M.cdist[ace];
-              cand = au == start ? (float)w : (float)(M.nd[au] + w);
-              plu = M.plen[au];
-              dpu = depth[au];
-              old = M.distmap[v];
+              v = M.cend[ce];
+              const int64_t w = M.cdist[ce];
+              const float cand = u == start ? (float)w : (float)(ndu + w);
+              const float old = M.distmap[v];
               if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
+              if (old == GTS_DIST_UNSET || old > cand) {
+                M.distmap[v] = cand;
+                M.edgemap[v] = ce;
+                M.nd[v] = u == start ? w : (int64_t)cand;
+                M.plen[v] = plu + (uint64_t)M.cseq[v];
+                depth[v] = dpu + 1;
+              } else if (old == cand)
+                tie = true;
+              const uint32_t d = indeg[v] - 1;
+              indeg[v] = d;
+              ready = d == 0;
             }
           }
-          bs = W::ballot(act && live && sense);
-          ba = W::ballot(act && live && !sense);
-          if (single) { us1 |= bs != 0; ua1 |= ba != 0; }
+          us |= W::ballot(live && sense) != 0;
+          ua |= W::ballot(live && !sense) != 0;
           inexact = W::ballot(inexact) != 0;
-          /* per target: the smallest candidate of the step; the first lane
-             holding it acts for the target */
-          const uint64_t peers = same_key_lanes(arc, v, tbits);
-          const uint64_t lt = W::lanemask_lt(lane);
-          float minc = cand;
-          bool earlier_eq = false;
-          {
-            uint64_t others = arc ? (peers & ~(1ull << lane)) : 0;
-            uint64_t any = W::ballot(others != 0);
-            while (any) {
-              const uint32_t mlane = others ? W::ctz(others) : 0;
-              const float cm = W::shflf(cand, mlane);
-              if (others) {
-                if (cm < minc) minc = cm;
-                if (cm == cand && mlane < lane) earlier_eq = true;
-                others &= others - 1;
-              }
-              any = W::ballot(others != 0);
-            }
-          }
-          const bool ismin = arc && cand == minc;
-          const bool lead = ismin && !earlier_eq;
-          bool tie = ismin && earlier_eq;        /* equal candidates in the step */
-          if (lead) {
-            if (old == GTS_DIST_UNSET || old > cand) {
-              M.distmap[v] = cand;
-              M.edgemap[v] = ace;
-              M.nd[v] = au == start ? w : (int64_t)cand;
-              M.plen[v] = plu + (uint64_t)M.cseq[v];
-              depth[v] = dpu + 1;
-            } else if (old == cand)
-              tie = true;
-          }
-          W::fence();
-          /* several in-arcs attain the label of v: edgemap keeps the one whose
+          /* two in-arcs attain the label of v: edgemap keeps the one whose
              value arrived first (algorithms.c:711-717), i.e. the arc whose
              source's final node is pushed first */
           uint64_t tm = W::ballot(tie);
@@ -1105,51 +938,30 @@ struct GtsComponent {
           while (tm) {
             const uint32_t l = W::ctz(tm);
             tm &= tm - 1;
-            const uint32_t tv = W::bcast(v, l), tce = W::bcast(ace, l), tu = W::bcast(au, l);
+            const uint32_t tv = W::bcast(v, l), tce = W::bcast(ce, l);
             const uint32_t up = W::uni(M.cstart[W::uni(M.edgemap[tv])]);
-            if (up != tu && pushed_after(up, tu, start)) {   /* tu's value came first */
+            if (pushed_after(up, u, start)) {       /* u's value came first */
               M.edgemap[tv] = tce;
-              M.plen[tv] = (uint64_t)W::uni64((int64_t)M.plen[tu]) + (uint64_t)W::uni64(M.cseq[tv]);
-              depth[tv] = (tu == start ? 0 : W::uni(depth[tu])) + 1;
+              M.plen[tv] = plu + (uint64_t)W::uni64(M.cseq[tv]);
+              depth[tv] = dpu + 1;
               W::fence();
             }
-          }
-          /* in-arc accounting, once per target */
-          const bool acct = arc && (peers & lt) == 0;
-          bool ready = false;
-          if (acct) {
-            const uint32_t d = indeg[v] - W::popc(peers);
-            indeg[v] = d;
-            ready = d == 0;
           }
           const uint64_t rm = W::ballot(ready);
           if (ready) TQ[nq + W::popc_below(rm, lane)] = v;
           nq += W::popc(rm);
           W::fence();
         }
-        if (bad) break;
-        /* reached terminals (algorithms.c:694): candidate ends of the walk; among
+        /* reached terminal (algorithms.c:694): candidate end of the walk; among
            equally long walks the reference keeps the terminal popped last
            (algorithms.c:732-756), whose last pop is its final node */
-        uint64_t termm;
-        if (single) termm = (u1 != start && !(us1 && ua1)) ? 1u : 0u;
-        else {
-          const uint64_t mine = W::range_mask(excl, incl);
-          termm = W::ballot(lane < nn && qu != start && !((bs & mine) != 0 && (ba & mine) != 0));
-        }
-        while (termm && !bad) {
-          const uint32_t l = W::ctz(termm);
-          termm &= termm - 1;
-          const uint32_t u = single ? u1 : W::bcast(qu, l);
-          const uint64_t plu = (uint64_t)W::uni64((int64_t)M.plen[u]);
+        if (!bad && u != start && !(us && ua)) {
           if (plu > best_len) { best_len = plu; best_t = u; }
           else if (plu == best_len && best_t != GTS_NONE) {
             if (inexact) { W::count(C.why + 7); bad = true; }
             else if (pushed_after(u, best_t, start)) best_t = u;
           }
         }
-        const uint32_t adv = single ? 1 : nn;
-        qh2 += adv; processed += adv;
       }
       if (!bad && processed != nr) {
         /* the reachable states hold a cycle: labels by a queue-based
