@@ -195,7 +195,7 @@ def main():
                            {k: eng.stat("top%d_%s" % (r, k)) for k in ("size", "ref_walks", "ref_us", "ref_pops")}
                            for r in range(3)]),
                    kernels_ms_per_step={k: round(v[1] / args.steps, 3) for k, v in
-                                        sorted(kt.items(), key=lambda kv: -kv[1][1])[:12]})
+                                        sorted(kt.items(), key=lambda kv: -kv[1][1])})
         if not args.no_cpu_baseline:
             cb, og, gs = cpu_baseline(pkg, args.cpu_sample, WORKLOAD["gen"], 99)
             out["cpu_baseline"] = cb
