@@ -105,6 +105,7 @@ def main():
                     help="contigs per GPU (default: the BASELINE configuration)")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
     ap.add_argument("--inversions", type=float, default=None,
                     help="fraction of the chimeric links that are inversions (default 0: the "
                          "reference's walk search is exponential on components holding one)")
@@ -133,7 +134,7 @@ def main():
     nrec = g["root"].numel()
     stream = torch.cuda.current_stream().cuda_stream
     eng = pkg.engine.Engine(local_rank, stream)
-    eng.set_option("profile", 1)
+    eng.set_option("profile", 0 if args.no_profile else 1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -161,6 +162,8 @@ def main():
     if rank == 0:
         n, m = eng.nv, eng.ne
         kt = eng.kernel_times()
+        if not kt:
+            kt = {"(profiling off)": (1, 0.0)}
         dom = max(kt.items(), key=lambda kv: kv[1][1])
         dname, (dcalls, dms) = dom
         avg_ms = dms / max(dcalls, 1)

@@ -6,8 +6,10 @@ removal, scaffold construction) as an MI355X-native engine.
   engine.py  ctypes binding of the C-ABI (device memory handed over as raw
              pointers; torch is only used by callers for allocation/streams)
   synth.py   synthetic contig / DistEst / A-stat inputs
+  dist.py    multi-GPU: component-partition step + sharded pipeline
 """
 from . import synth  # noqa: F401
+from . import dist  # noqa: F401
 
 try:
     from . import engine  # noqa: F401

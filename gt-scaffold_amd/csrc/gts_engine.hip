@@ -60,6 +60,10 @@ struct GtsgEngine {
   uint32_t nhub = 0;
   uint32_t *hubs = nullptr;
   bool built = false;
+  /* scratch of an open gtsg_filter_begin / gtsg_filter_end pair */
+  bool filter_open = false;
+  uint32_t *f_tpoly = nullptr, *f_lasthit = nullptr;
+  uint8_t *f_ovf = nullptr, *f_newstate = nullptr;
   /* workspace */
   char *pool = nullptr;
   size_t pool_cap = 0, pool_used = 0;
@@ -155,6 +159,7 @@ static int sync_stream(GtsgEngine *e)
 static int pool_reserve(GtsgEngine *e, size_t bytes)
 {
   e->pool_used = 0;
+  e->filter_open = false;   /* its scratch lives in the pool */
   if (bytes <= e->pool_cap) return 0;
   HIPCHK(hipStreamSynchronize(e->st));
   if (e->pool) HIPCHK(hipFree(e->pool));
@@ -1120,11 +1125,12 @@ int gtsg_mark_repeats(GtsgEngine *e, int have_file, float copy_num_cutoff,
   return sync_stream(e);
 }
 
-int gtsg_filter(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff)
+int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff)
 {
   if (!e || !e->built) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
   HIPCHK(hipSetDevice(e->device));
   const uint32_t n = e->n, m = e->m;
+  e->filter_open = false;
   if (!n) return 0;
   int rc;
   if ((rc = pool_reserve(e, (size_t)m * 2 + (size_t)n * 24 + (8u << 20)))) return rc;
@@ -1171,15 +1177,105 @@ int gtsg_filter(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff)
     if (!h) break;
   }
   LAUNCH("filter_lasthit", k_filter_lasthit, nblk(n), GTS_BLOCK, G, ovf, lasthit);
-  if (m) {
-    LAUNCH("filter_final", k_filter_final, nblk(m), GTS_BLOCK, G, e->estart, tpoly, ovf,
-           lasthit, newstate);
-    HIPCHK(hipMemcpyAsync(e->state, newstate, m, hipMemcpyDeviceToDevice, e->st));
-  }
-  LAUNCH("filter_final_vertices", k_filter_final_vertices, nblk(n), GTS_BLOCK, e->vstate,
-         tpoly, n);
   e->stats["filter_rounds_p"] = rounds_p;
   e->stats["filter_rounds_i"] = rounds_i;
+  e->f_tpoly = tpoly; e->f_ovf = ovf; e->f_lasthit = lasthit; e->f_newstate = newstate;
+  e->filter_open = true;
+  return sync_stream(e);
+}
+
+/* the "latest hit" table (2 x u32 per contig, GTS_NONE = none) between the two
+   halves of the filter; as int32 it is ordered (-1 = none), so shards that
+   share marked (repeat) vertices combine it with an all-reduce MAX */
+int gtsg_filter_get_lasthit(GtsgEngine *e, uint32_t *dst, int on_device)
+{
+  if (!e || !dst || !e->filter_open) return e ? fail(e, GTSG_EINVAL, "no open filter call") : GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipMemcpyAsync(dst, e->f_lasthit, 8ull * e->n,
+                        on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+int gtsg_filter_set_lasthit(GtsgEngine *e, const uint32_t *src, int on_device)
+{
+  if (!e || !src || !e->filter_open) return e ? fail(e, GTSG_EINVAL, "no open filter call") : GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipMemcpyAsync(e->f_lasthit, src, 8ull * e->n,
+                        on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->st));
+  return sync_stream(e);
+}
+
+int gtsg_filter_end(GtsgEngine *e)
+{
+  if (!e || !e->filter_open) return e ? fail(e, GTSG_EINVAL, "no open filter call") : GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  const uint32_t n = e->n, m = e->m;
+  GtsGraphView G = view_of(e);
+  e->filter_open = false;
+  if (m) {
+    LAUNCH("filter_final", k_filter_final, nblk(m), GTS_BLOCK, G, e->estart, e->f_tpoly,
+           e->f_ovf, e->f_lasthit, e->f_newstate);
+    HIPCHK(hipMemcpyAsync(e->state, e->f_newstate, m, hipMemcpyDeviceToDevice, e->st));
+  }
+  LAUNCH("filter_final_vertices", k_filter_final_vertices, nblk(n), GTS_BLOCK, e->vstate,
+         e->f_tpoly, n);
+  return sync_stream(e);
+}
+
+int gtsg_filter(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff)
+{
+  int rc = gtsg_filter_begin(e, pcutoff, cncutoff, ocutoff);
+  if (rc || !e->filter_open) return rc;
+  return gtsg_filter_end(e);
+}
+
+/* Component labels of the contigs under a slice of records (multi-GPU
+   partition step): labels[] holds parent pointers with labels[v] <= v (identity
+   at first, or the element-wise minimum over the shards' previous results);
+   every record whose two contigs are not skipped joins their trees (larger
+   root under the smaller); on return labels[v] is the root = smallest contig
+   of v's tree. */
+__global__ void k_label_union(const uint32_t *root, const uint32_t *ctg,
+                              const uint8_t *skip, uint32_t *parent, uint64_t nrec)
+{
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nrec) return;
+  uint32_t x = root[k], y = ctg[k];
+  if (skip && (skip[x] || skip[y])) return;
+  for (;;) {
+    x = uf_find(parent, x); y = uf_find(parent, y);
+    if (x == y) break;
+    if (x < y) { const uint32_t t = x; x = y; y = t; }
+    if (atomicCAS(&parent[x], x, y) == x) break;
+  }
+}
+__global__ void k_label_flatten(uint32_t *parent, uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) parent[v] = uf_find(parent, (uint32_t)v);
+}
+int gtsg_label_components(GtsgEngine *e, uint64_t n, uint64_t nrec, const uint32_t *root,
+                          const uint32_t *ctg, const uint8_t *skip, uint32_t *labels,
+                          int on_device)
+{
+  if (!e || !labels || (nrec && (!root || !ctg))) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  int rc;
+  const uint32_t *d_root = root, *d_ctg = ctg;
+  const uint8_t *d_skip = skip;
+  uint32_t *d_lab = labels;
+  if (!on_device) {
+    if ((rc = pool_reserve(e, nrec * 8 + n * 5 + (1u << 20)))) return rc;
+    PALLOC(tr, uint32_t, nrec + 1); PALLOC(tc, uint32_t, nrec + 1);
+    PALLOC(tl, uint32_t, n + 1); PALLOC(ts, uint8_t, n + 1);
+    upload(e, tr, root, nrec, 0); upload(e, tc, ctg, nrec, 0); upload(e, tl, labels, n, 0);
+    if (skip) upload(e, ts, skip, n, 0);
+    d_root = tr; d_ctg = tc; d_lab = tl; d_skip = skip ? ts : nullptr;
+  }
+  if (nrec)
+    LAUNCH("label_union", k_label_union, nblk(nrec), GTS_BLOCK, d_root, d_ctg, d_skip, d_lab, nrec);
+  if (n) LAUNCH("label_flatten", k_label_flatten, nblk(n), GTS_BLOCK, d_lab, (uint32_t)n);
+  if (!on_device)
+    HIPCHK(hipMemcpyAsync(labels, d_lab, n * 4, hipMemcpyDeviceToHost, e->st));
   return sync_stream(e);
 }
 

@@ -18,7 +18,8 @@ SYMBOLS = [
     "gtsg_build_from_records", "gtsg_set_astat", "gtsg_mark_repeats", "gtsg_filter",
     "gtsg_removecycles", "gtsg_makescaffold", "gtsg_num_vertices", "gtsg_num_edges",
     "gtsg_get_vertex_states", "gtsg_get_edge_states", "gtsg_get_edges", "gtsg_state_digest",
-    "gtsg_set_option", "gtsg_selftest_ambiguous", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
+    "gtsg_set_option", "gtsg_selftest_ambiguous", "gtsg_filter_begin", "gtsg_filter_end",
+    "gtsg_filter_get_lasthit", "gtsg_filter_set_lasthit", "gtsg_label_components", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
 ]
 
 
@@ -59,6 +60,11 @@ def lib():
         L.gtsg_set_astat.argtypes = [vp, vp, vp, ci]
         L.gtsg_mark_repeats.argtypes = [vp, ci, f32, f32]
         L.gtsg_filter.argtypes = [vp, f32, f32, i64]
+        L.gtsg_filter_begin.argtypes = [vp, f32, f32, i64]
+        L.gtsg_filter_end.argtypes = [vp]
+        L.gtsg_filter_get_lasthit.argtypes = [vp, vp, ci]
+        L.gtsg_filter_set_lasthit.argtypes = [vp, vp, ci]
+        L.gtsg_label_components.argtypes = [vp, u64, u64, vp, vp, vp, vp, ci]
         L.gtsg_removecycles.argtypes = [vp]
         L.gtsg_makescaffold.argtypes = [vp]
         L.gtsg_num_vertices.argtypes = [vp]
@@ -190,6 +196,26 @@ class Engine:
 
     def makescaffold(self):
         self._chk(self._L.gtsg_makescaffold(self._h))
+
+    # ---- multi-GPU hooks ----
+    def filter_begin(self, pcutoff=0.01, cncutoff=1.5, ocutoff=400):
+        self._chk(self._L.gtsg_filter_begin(self._h, pcutoff, cncutoff, int(ocutoff)))
+
+    def filter_end(self):
+        self._chk(self._L.gtsg_filter_end(self._h))
+
+    def filter_get_lasthit(self, dst):
+        p, d, k = _ptr(dst, np.int32)
+        self._chk(self._L.gtsg_filter_get_lasthit(self._h, p, d))
+
+    def filter_set_lasthit(self, src):
+        p, d, k = _ptr(src, np.int32)
+        self._chk(self._L.gtsg_filter_set_lasthit(self._h, p, d))
+
+    def label_components(self, n, root, ctg, skip, labels):
+        a = [_ptr(root, np.uint32), _ptr(ctg, np.uint32), _ptr(skip, np.uint8), _ptr(labels, np.uint32)]
+        self._chk(self._L.gtsg_label_components(self._h, int(n), len(root), a[0][0], a[1][0], a[2][0],
+                                                a[3][0], self._same_side([x[1] for x in a])))
 
     # ---- results ----
     @property

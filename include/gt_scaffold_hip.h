@@ -75,6 +75,25 @@ int gtsg_mark_repeats(GtsgEngine *e, int have_file, float copy_num_cutoff,
                       float astat_cutoff);
 /* ref gt_scaffolder_graph_filter, algorithms.c:261-343 */
 int gtsg_filter(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff);
+/* The filter in two halves, for graphs sharded over several GPUs by connected
+   component (multi-GPU): marked (repeat) contigs are shared between
+   shards and the only cross-shard effect of the filter is the time of the
+   latest inconsistency hit on their edges (algorithms.c:249-258).  Between
+   _begin and _end the shards combine the table (2 x u32 per contig, as int32:
+   -1 = none) with an element-wise MAX; no other engine call may intervene. */
+int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff);
+int gtsg_filter_get_lasthit(GtsgEngine *e, uint32_t *dst, int on_device);
+int gtsg_filter_set_lasthit(GtsgEngine *e, const uint32_t *src, int on_device);
+int gtsg_filter_end(GtsgEngine *e);
+
+/* Component-partition step: joins the contigs of every record (root, ctg) of a
+   slice whose contigs are both not skipped; labels[] (n entries, labels[v] <= v,
+   identity at first) are parent pointers on entry and the smallest contig of
+   each tree on return.  Shards iterate {label, all-reduce MIN} to a fixpoint. */
+int gtsg_label_components(GtsgEngine *e, uint64_t n, uint64_t n_records,
+                          const uint32_t *root, const uint32_t *ctg,
+                          const uint8_t *skip, uint32_t *labels, int on_device);
+
 /* ref gt_scaffolder_removecycles, algorithms.c:495-578 */
 int gtsg_removecycles(GtsgEngine *e);
 /* ref gt_scaffolder_makescaffold, algorithms.c:767-868 */
