@@ -141,8 +141,9 @@ def route_records(comm, owner, skip, rec):
     (global record index = file order) and any payload.  Returns this rank's
     records, sorted by k."""
     root, ctg, k = rec["root"], rec["ctg"], rec["k"]
+    # both contigs repeats: any rank, but the same one for every record of the pair
     dest = torch.where(~skip[root], owner[root],
-                       torch.where(~skip[ctg], owner[ctg], k % comm.world))
+                       torch.where(~skip[ctg], owner[ctg], torch.minimum(root, ctg) % comm.world))
     out = {}
     sel = [torch.nonzero(dest == r).flatten() for r in range(comm.world)]
     for name, t in rec.items():

@@ -64,7 +64,7 @@ def check_partition(comm, g):
     k = mine["k"]
     assert torch.all(k[1:] > k[:-1])                                # file order kept
     a, b = mine["root"], mine["ctg"]
-    dest = torch.where(~skip[a], owner[a], torch.where(~skip[b], owner[b], k % comm.world))
+    dest = torch.where(~skip[a], owner[a], torch.where(~skip[b], owner[b], torch.minimum(a, b) % comm.world))
     assert torch.all(dest == comm.rank)
     # payload travels with its record
     assert torch.equal(mine["dist"], torch.from_numpy(g["dist"])[k])
