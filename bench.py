@@ -109,6 +109,10 @@ def main():
     ap.add_argument("--inversions", type=float, default=None,
                     help="fraction of the chimeric links that are inversions (default 0: the "
                          "reference's walk search is exponential on components holding one)")
+    ap.add_argument("--mode", choices=["shards", "partition"], default="shards",
+                    help="shards: every rank scaffolds its own set of components (default); "
+                         "partition: ONE graph over all ranks, records split by file chunk, "
+                         "component-partition step over RCCL included in the timed region")
     ap.add_argument("--verify", action="store_true",
                     help="also run the oracle on the FULL workload and compare digests (slow)")
     args = ap.parse_args()
@@ -136,6 +140,43 @@ def main():
     eng = pkg.engine.Engine(local_rank, stream)
     eng.set_option("profile", 0 if args.no_profile else 1)
 
+    comm = contigs = rec = None
+    if args.mode == "partition":
+        # one graph of world x contigs: rank r generated the components with contig
+        # ids [r*n, (r+1)*n); its records are dealt out like chunks of one .de
+        # file (record i of every rank goes to rank i mod world), the contig
+        # table is replicated
+        comm = pkg.dist.TorchComm() if world > 1 else pkg.dist.ThreadComm(pkg.dist.ThreadComm.Shared(1), 0)
+        nloc = args.contigs
+        def gather(t):
+            if world == 1:
+                return t
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            return torch.cat(out)
+        contigs = dict(seq_len=gather(g["seq_len"]), astat=gather(g["astat"]), copy_num=gather(g["copy_num"]))
+        base = torch.tensor([nrec], dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(base) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allc, base)
+        else:
+            allc = [base]
+        k0 = int(sum(int(c.item()) for c in allc[:rank]))
+        full = dict(root=g["root"].to(torch.int64) + rank * nloc, ctg=g["ctg"].to(torch.int64) + rank * nloc,
+                    dist=g["dist"], std_dev=g["std_dev"], num_pairs=g["num_pairs"], flags=g["flags"],
+                    k=torch.arange(k0, k0 + nrec, dtype=torch.int64, device=dev))
+        idx = torch.arange(nrec, device=dev)
+        rec = {name: torch.cat(comm.exchange([t[idx % world == r] for r in range(world)]))
+               for name, t in full.items()}
+        o = torch.argsort(rec["k"])
+        rec = {name: t[o] for name, t in rec.items()}
+
+    def step():
+        if args.mode == "partition":
+            pkg.dist.scaffold_sharded(comm, eng, contigs, rec, CUTS)
+            return eng.ne
+        return run_step(eng, g)
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -143,13 +184,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        run_step(eng, g)
+        step()
     eng.reset_kernel_times()
     barrier()
     t0 = time.perf_counter()
     edges = 0
     for _ in range(args.steps):
-        edges += run_step(eng, g)
+        edges += step()
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -181,7 +222,7 @@ def main():
                    config=dict(workload=WORKLOAD["name"], contigs_per_gpu=n, edges_per_gpu=m,
                                records_per_gpu=nrec, components=eng.stat("components"),
                                max_component=eng.stat("max_component"),
-                               parallelism="components sharded, %d GPU(s)" % world),
+                               parallelism="components sharded, %d GPU(s), mode %s" % (world, args.mode)),
                    roofline=roof,
                    component_kernel=dict(
                        walks_fast=eng.stat("fast_walks"), walks_reference=eng.stat("slow_walks"),
