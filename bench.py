@@ -57,9 +57,14 @@ def algorithmic_bytes(name, n, m, nrec, eng):
         "filter_final": m * (4 + 4 + 1 + 1 + 1) + n * (4 + 4 + 1 + 8),
         "comp_live_union": m * (4 + 4 + 1 + 1) + n * 6,
         "comp_compact_fill": m * (4 + 1 + 4) + nce * 26 + ns * 8,
-        # the compact graph is read once and the marks written once
-        "components_makescaffold": nce * (4 + 4 + 8 + 1 + 1 + 4) + ns * (8 + 4 + 1) + m * 1 + n * 1,
     }
+    # component programs: the compact graph + vertex records of the components
+    # the launch handles, read once; states and marks written once
+    klass = {"components_makescaffold": "bytes_components_global_mem"}
+    for i, tag in enumerate(("4k", "8k", "16k", "32k", "64k", "160k")):
+        klass["components_makescaffold_lds" + tag] = "bytes_components_lds_class%d" % i
+    if name in klass:
+        return max(eng.stat(klass[name]), 0)
     return table.get(name)
 
 
@@ -214,6 +219,18 @@ def main():
                     unit="GB/s", frac=None, traffic=None, algorithmic_bytes=ab)
         if roof["achieved"] is not None:
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        # the component programs are latency bound (dependent pointer chasing in
+        # LDS); for reference, the largest HBM-streaming kernel of the step
+        stream = [(k, v) for k, v in kt.items() if not k.startswith("components_")
+                  and algorithmic_bytes(k, n, m, nrec, eng)]
+        roof_stream = None
+        if stream:
+            sk, (sc, sms) = max(stream, key=lambda kv: kv[1][1])
+            sab = algorithmic_bytes(sk, n, m, nrec, eng)
+            sach = sab / (sms / max(sc, 1) * 1e-3) / 1e9
+            roof_stream = dict(bound="hbm", kernel=sk, launches=sc, avg_ms=sms / max(sc, 1),
+                               achieved=sach, peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=sach / HBM_PEAK_GBS, traffic=None, algorithmic_bytes=sab)
         out = dict(metric="scaffold-graph edges processed/sec (build+filter+makescaffold)",
                    value=edges_all / dt_max, unit="edges/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=dt_max / args.steps * 1e3,
@@ -223,7 +240,7 @@ def main():
                                records_per_gpu=nrec, components=eng.stat("components"),
                                max_component=eng.stat("max_component"),
                                parallelism="components sharded, %d GPU(s), mode %s" % (world, args.mode)),
-                   roofline=roof,
+                   roofline=roof, roofline_largest_streaming_kernel=roof_stream,
                    component_kernel=dict(
                        walks_fast=eng.stat("fast_walks"), walks_reference=eng.stat("slow_walks"),
                        **{k: eng.stat(k) for k in

@@ -763,7 +763,7 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
 __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 uint32_t *keys, uint32_t *vals, uint32_t ncomp,
                                 const uint32_t *klass, uint32_t nklass,
-                                uint32_t *klass_count)
+                                uint32_t *klass_count, unsigned long long *klass_bytes)
 {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncomp) return;
@@ -774,6 +774,10 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
   uint32_t k = 0;
   while (k < nklass && need > klass[k]) ++k;   /* klass ascending; nklass = global */
   atomicAdd(&klass_count[k], 1u);
+  /* bytes the component's program has to touch once: its compact graph and
+     vertex records in, vertex states and edge marks out */
+  atomicAdd(&klass_bytes[k], (unsigned long long)(coff[s1] - coff[s0]) * 19ull +
+                                 (unsigned long long)(s1 - s0) * 18ull);
 }
 __global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
                                uint32_t *out /* [0]=overflow, [1]=loop */)
@@ -1394,8 +1398,10 @@ static int run_components(GtsgEngine *e, int mode)
     uint32_t *klass_d = e->d_scalars + 64, *klass_count = e->d_scalars + 72;
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, sizeof klass_h, hipMemcpyHostToDevice, e->st));
     HIPCHK(hipMemsetAsync(klass_count, 0, (GTS_NKLASS + 1) * 4, e->st));
+    HIPCHK(hipMemsetAsync(e->d_scalars + 112, 0, (GTS_NKLASS + 1) * 8, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
-           ncomp, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count);
+           ncomp, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
+           (unsigned long long *)(e->d_scalars + 112));
     const uint32_t *order;
     {
       int shifts[4] = {0, 8, 16, 24};
@@ -1403,7 +1409,9 @@ static int run_components(GtsgEngine *e, int mode)
       order = where ? ov1 : ov0;
     }
     uint32_t kcount[GTS_NKLASS + 1];
+    uint64_t kbytes[GTS_NKLASS + 1];
     HIPCHK(hipMemcpyAsync(kcount, klass_count, sizeof kcount, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(kbytes, e->d_scalars + 112, sizeof kbytes, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
     HIPCHK(hipMemsetAsync(e->d_scalars + 12, 0, 16, e->st));
     LAUNCH("comp_max_size", k_max_u32_diff, nblk(ncomp), GTS_BLOCK, comp_off, ncomp,
@@ -1459,6 +1467,9 @@ static int run_components(GtsgEngine *e, int mode)
         first += kcount[k];
       }
       e->stats["components_global_mem"] = kcount[nk];
+      e->stats["bytes_components_global_mem"] = (int64_t)kbytes[nk];
+      for (uint32_t k = 0; k < nk; ++k)
+        e->stats[std::string("bytes_components_lds_class") + char('0' + k)] = (int64_t)kbytes[k];
     }
     LAUNCH("comp_count_errors", k_count_errors, nblk(ncomp), GTS_BLOCK, cerr, ncomp,
            e->d_scalars + 12);
