@@ -366,37 +366,82 @@ __global__ void k_compact_ids(const uint32_t *flag, const uint32_t *idx,
 
 /* ---- mark_repeats ---- */
 __global__ void k_repeat_vertices(const float *astat, const float *cn,
-                                  uint8_t *vstate, uint32_t n, int have_file,
-                                  float cncut, float acut)
+                                  uint8_t *vstate, uint8_t *isrep, uint32_t n,
+                                  int have_file, float cncut, float acut)
 {
   uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < n && gts_is_repeat(astat[v], cn[v], have_file, cncut, acut))
-    vstate[v] = GIS_REPEAT;
+  if (v >= n) return;
+  const bool r = gts_is_repeat(astat[v], cn[v], have_file, cncut, acut);
+  isrep[v] = r ? 1 : 0;
+  if (r) vstate[v] = GIS_REPEAT;
 }
 /* an edge turns REPEAT iff one of its ends is marked by THIS call
    (mark_vertex marks the vertex' edges and their twins, algorithms.c:61-87) */
 __global__ void k_repeat_edges(const uint32_t *estart, const uint32_t *eend,
-                               const float *astat, const float *cn,
-                               uint8_t *state, uint32_t m, int have_file,
-                               float cncut, float acut)
+                               const uint8_t *isrep, uint8_t *state, uint32_t m)
 {
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= m) return;
-  const uint32_t a = estart[p], b = eend[p];
-  if (gts_is_repeat(astat[a], cn[a], have_file, cncut, acut) ||
-      gts_is_repeat(astat[b], cn[b], have_file, cncut, acut))
-    state[p] = GIS_REPEAT;
+  if (isrep[estart[p]] || isrep[eend[p]]) state[p] = GIS_REPEAT;
 }
 
 /* ---- filter ---- */
-__global__ void k_filter_pairs(GtsGraphView G, GtsFilterParams P, uint8_t *prop,
-                               uint8_t *vinfo, uint32_t hub_degree)
+/* The pair passes are the only O(degree^2) work of the filter.  A workgroup
+   takes GTS_BLOCK consecutive vertices; their adjacency lists are ONE
+   contiguous CSR range, which is staged in LDS with coalesced loads (plus one
+   gather per edge for the end vertex' copy number and length) and then paired
+   from LDS.  Without staging every pair re-gathers from HBM: 58 GB fetched for
+   1.9 GB of edges (profiles/r01b_pmc_traffic.json). */
+/* staged as 32-bit values (17 B per edge, 3584 edges = 60 KB of LDS); a block
+   holding a distance or length outside int32 pairs from global memory */
+#define GTS_FP_CAP 3584
+struct GtsEdgeAccLds {
+  const int32_t *d, *l;
+  const float *s, *c;
+  const uint8_t *f;
+  __device__ __forceinline__ uint8_t sense(uint32_t i) const { return f[i] & GTS_F_SENSE; }
+  __device__ __forceinline__ int64_t dist(uint32_t i) const { return d[i]; }
+  __device__ __forceinline__ float sd(uint32_t i) const { return s[i]; }
+  __device__ __forceinline__ float cn(uint32_t i) const { return c[i]; }
+  __device__ __forceinline__ int64_t len(uint32_t i) const { return l[i]; }
+  __device__ __forceinline__ bool marked(uint32_t i) const { return (f[i] & 0x80u) != 0; }
+};
+
+__global__ void __launch_bounds__(GTS_BLOCK)
+k_filter_pairs(GtsGraphView G, GtsFilterParams P, uint8_t *prop, uint8_t *vinfo,
+               uint32_t hub_degree)
 {
-  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ int32_t s_d[GTS_FP_CAP], s_l[GTS_FP_CAP];
+  __shared__ float s_s[GTS_FP_CAP], s_c[GTS_FP_CAP];
+  __shared__ uint8_t s_f[GTS_FP_CAP];
+  __shared__ uint32_t s_wide;
+  const uint32_t v0 = blockIdx.x * GTS_BLOCK;
+  const uint32_t v1 = v0 + GTS_BLOCK < G.n ? v0 + GTS_BLOCK : G.n;
+  const uint32_t e0 = G.row[v0], e1 = G.row[v1];
+  uint32_t ns = e1 - e0 < GTS_FP_CAP ? e1 - e0 : GTS_FP_CAP;
+  if (threadIdx.x == 0) s_wide = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < ns; i += GTS_BLOCK) {
+    const uint32_t p = e0 + i, x = G.end[p];
+    const int64_t d = G.dist[p], l = G.seq_len[x];
+    if (d != (int32_t)d || l != (int32_t)l) s_wide = 1;
+    s_d[i] = (int32_t)d; s_s[i] = G.sd[p]; s_f[i] = G.flags[p];
+    s_c[i] = G.copy_num[x]; s_l[i] = (int32_t)l;
+  }
+  __syncthreads();
+  if (s_wide) ns = 0;
+  const uint32_t v = v0 + threadIdx.x;
   if (v >= G.n) return;
   if (gts_vertex_is_marked(G.vstate[v])) { vinfo[v] = GTS_VI_INACTIVE; return; }
-  if (G.row[v + 1] - G.row[v] > hub_degree) { vinfo[v] = 0; return; }
-  vinfo[v] = (uint8_t)gts_filter_pairs(G, P, (uint32_t)v, 0, 1, prop);
+  const uint32_t b = G.row[v], e = G.row[v + 1];
+  if (e - b > hub_degree) { vinfo[v] = 0; return; }
+  if (e - e0 <= ns) {
+    GtsEdgeAccLds A = {s_d, s_l, s_s, s_c, s_f};
+    vinfo[v] = (uint8_t)gts_filter_pairs_acc(A, P, b - e0, e - e0, 0, 1, prop, e0);
+  } else {
+    GtsEdgeAccGlobal A(G);
+    vinfo[v] = (uint8_t)gts_filter_pairs_acc(A, P, b, e, 0, 1, prop, 0);
+  }
 }
 /* hub vertices: one wavefront per vertex, the outer pair index strided over
    the lanes */
@@ -425,31 +470,75 @@ __global__ void k_filter_active_round(GtsGraphView G, const uint8_t *prop,
   if (r) vinfo[v] = (uint8_t)(cur | r);
   else *pending = 1;
 }
-__global__ void k_filter_tpoly(GtsGraphView G, const uint8_t *prop,
-                               const uint8_t *vinfo, uint32_t *tpoly)
+/* first active proposer of every vertex, one lane per edge: edge p = (v -> u)
+   counts if its twin (u -> v) carries a proposal and u is active; few do */
+__global__ void k_filter_tpoly(GtsGraphView G, const uint32_t *estart,
+                               const uint8_t *prop, const uint8_t *vinfo,
+                               uint32_t *tpoly)
 {
-  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= G.n) return;
-  tpoly[v] = gts_vertex_is_marked(G.vstate[v])
-                 ? GTS_NONE
-                 : gts_filter_tpoly(G, (uint32_t)v, prop, vinfo);
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= G.m) return;
+  if (!prop[G.twin[p]]) return;
+  const uint32_t u = G.end[p], v = estart[p];
+  if (!(vinfo[u] & GTS_VI_ACTIVE0) || gts_vertex_is_marked(G.vstate[v])) return;
+  atomicMin(&tpoly[v], u);
 }
-__global__ void k_filter_ovf_init(GtsGraphView G, GtsFilterParams P,
-                                  const uint8_t *vinfo, const uint32_t *tpoly,
-                                  uint8_t *ovf, int zero_ovf,
-                                  uint32_t hub_degree)
+__global__ void __launch_bounds__(GTS_BLOCK)
+k_filter_ovf_init(GtsGraphView G, GtsFilterParams P, const uint32_t *estart,
+                  const uint8_t *vinfo, const uint32_t *tpoly, uint8_t *ovf,
+                  int zero_ovf, uint32_t hub_degree)
 {
-  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= G.n) return;
-  const uint8_t vi = vinfo[v];
-  if (!(vi & GTS_VI_ACTIVE0) || tpoly[v] == (uint32_t)v) { ovf[v] = GTS_OV_KNOWN; return; }
-  uint32_t o = GTS_OV_ACTIVE1;
-  if (zero_ovf) o |= GTS_OV0_A | GTS_OV0_S;
-  else if (vi & (GTS_VI_OVALL_A | GTS_VI_OVALL_S)) {
-    if (G.row[v + 1] - G.row[v] > hub_degree) { ovf[v] = (uint8_t)o; return; } /* hub pass */
-    o |= gts_filter_ovf0(G, P, (uint32_t)v, 0, 1, tpoly);
+  __shared__ int32_t s_d[GTS_FP_CAP], s_l[GTS_FP_CAP];
+  __shared__ uint8_t s_f[GTS_FP_CAP];
+  __shared__ uint32_t s_need, s_wide;
+  const uint32_t v0 = blockIdx.x * GTS_BLOCK;
+  const uint32_t v1 = v0 + GTS_BLOCK < G.n ? v0 + GTS_BLOCK : G.n;
+  const uint32_t v = v0 + threadIdx.x;
+  if (threadIdx.x == 0) { s_need = 0; s_wide = 0; }
+  __syncthreads();
+  /* who has to pair at all: ACTIVE1 vertices whose mark-free pre-test fired */
+  uint32_t o = 0;
+  bool pairing = false;
+  uint32_t b = 0, e = 0;
+  if (v < G.n) {
+    const uint8_t vi = vinfo[v];
+    b = G.row[v]; e = G.row[v + 1];
+    if (!(vi & GTS_VI_ACTIVE0) || tpoly[v] == v) o = GTS_OV_KNOWN;
+    else {
+      o = GTS_OV_ACTIVE1;
+      if (zero_ovf) o |= GTS_OV0_A | GTS_OV0_S;
+      else if ((vi & (GTS_VI_OVALL_A | GTS_VI_OVALL_S)) && e - b <= hub_degree) pairing = true;
+      /* hubs with the pre-test set are finished by k_filter_ovf_init_hub */
+    }
   }
-  if (!zero_ovf && !(o & (GTS_OV0_A | GTS_OV0_S))) o |= GTS_OV_KNOWN;
+  if (pairing) s_need = 1;
+  __syncthreads();
+  if (s_need) {
+    const uint32_t e0 = G.row[v0], e1 = G.row[v1];
+    uint32_t ns = e1 - e0 < GTS_FP_CAP ? e1 - e0 : GTS_FP_CAP;
+    for (uint32_t i = threadIdx.x; i < ns; i += GTS_BLOCK) {
+      const uint32_t p = e0 + i, x = G.end[p];
+      const bool mk = gts_edge_is_marked(G.state[p]) || tpoly[x] <= estart[p];
+      const int64_t d = G.dist[p], l = G.seq_len[x];
+      if (d != (int32_t)d || l != (int32_t)l) s_wide = 1;
+      s_d[i] = (int32_t)d; s_l[i] = (int32_t)l;
+      s_f[i] = (uint8_t)((G.flags[p] & 3u) | (mk ? 0x80u : 0u));
+    }
+    __syncthreads();
+    if (s_wide) ns = 0;
+    if (pairing) {
+      if (e - e0 <= ns) {
+        GtsEdgeAccLds A = {s_d, s_l, nullptr, nullptr, s_f};
+        o |= gts_filter_ovf0_acc(A, P, b - e0, e - e0, 0, 1);
+      } else
+        o |= gts_filter_ovf0(G, P, v, 0, 1, tpoly);
+    }
+  }
+  if (v >= G.n) return;
+  const bool hub_pending = (o & GTS_OV_ACTIVE1) && !zero_ovf && e - b > hub_degree &&
+                           (vinfo[v] & (GTS_VI_OVALL_A | GTS_VI_OVALL_S));
+  if ((o & GTS_OV_ACTIVE1) && !zero_ovf && !hub_pending && !(o & (GTS_OV0_A | GTS_OV0_S)))
+    o |= GTS_OV_KNOWN;
   ovf[v] = (uint8_t)o;
 }
 __global__ void __launch_bounds__(GTS_BLOCK)
@@ -480,15 +569,19 @@ __global__ void k_filter_hit_round(GtsGraphView G, uint8_t *ovf, int zero_ovf,
   if (r) ovf[v] = (uint8_t)r;
   else *pending = 1;
 }
-__global__ void k_filter_lasthit(GtsGraphView G, const uint8_t *ovf,
-                                 uint32_t *lasthit)
+/* latest neighbour whose overflow marks direction d of the start vertex, one
+   lane per edge q = (a -> y); lasthit[] is pre-set to GTS_NONE = -1 as int32 */
+__global__ void k_filter_lasthit(GtsGraphView G, const uint32_t *estart,
+                                 const uint8_t *ovf, uint32_t *lasthit)
 {
-  uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= G.n) return;
-  uint32_t out[2];
-  gts_filter_lasthit(G, (uint32_t)a, ovf, out);
-  lasthit[2 * a] = out[0];
-  lasthit[2 * a + 1] = out[1];
+  uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= G.m) return;
+  const uint32_t y = G.end[q];
+  const uint32_t oy = ovf[y];
+  if (!(oy & GTS_OV_ACTIVE1) || !(oy & (GTS_OV_A | GTS_OV_S))) return;
+  const uint8_t ff = G.flags[G.twin[q]];      /* the edge y -> a */
+  if (!(oy & ((ff & GTS_F_SENSE) ? GTS_OV_S : GTS_OV_A))) return;
+  atomicMax((int *)&lasthit[2 * (uint64_t)estart[q] + (gts_twin_dir(ff) ? 1 : 0)], (int)y);
 }
 __global__ void k_filter_final(GtsGraphView G, const uint32_t *estart,
                                const uint32_t *tpoly, const uint8_t *ovf,
@@ -589,41 +682,44 @@ __global__ void k_slot_bases(const uint32_t *head, const uint32_t *cidx,
   if (s < nslots) slot_base[s] = comp_off[cidx[s] + head[s] - 1];
 }
 /* an edge enters the compact graph if it or its twin is live: marking a walk
-   edge's twin SCAFFOLD (algorithms.c:842-845) revives a marked twin */
-__global__ void k_compact_count(GtsGraphView G, const uint8_t *live,
+   edge's twin SCAFFOLD (algorithms.c:842-845) revives a marked twin.  One lane
+   per edge position; the rank of an edge among the included edges of its
+   vertex comes from one prefix sum over all positions. */
+__global__ void k_compact_flags(const uint8_t *live, const uint32_t *twin,
+                                uint32_t *incl, uint32_t m)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < m) incl[p] = (live[p] || live[twin[p]]) ? 1u : 0u;
+}
+__global__ void k_compact_count(const uint32_t *row, const uint32_t *ipos,
                                 const uint32_t *slot_v, uint32_t *cnt,
                                 uint32_t nslots)
 {
   uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nslots) return;
   const uint32_t v = slot_v[s];
-  uint32_t k = 0;
-  for (uint32_t p = G.row[v]; p < G.row[v + 1]; ++p)
-    if (live[p] || live[G.twin[p]]) ++k;
-  cnt[s] = k;
+  cnt[s] = ipos[row[v + 1]] - ipos[row[v]];
 }
-__global__ void k_compact_fill(GtsGraphView G, const uint8_t *live,
-                               const uint32_t *slot_v, const uint32_t *slot_of,
-                               const uint32_t *slot_base,
+__global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
+                               const uint32_t *incl, const uint32_t *ipos,
+                               const uint32_t *slot_of, const uint32_t *slot_base,
                                const uint32_t *coff, uint32_t *cstart,
                                uint32_t *cend, int64_t *cdist, uint8_t *cflags,
-                               uint32_t *cgpos, uint8_t *cstate, uint32_t *cmap,
-                               uint32_t nslots)
+                               uint32_t *cgpos, uint8_t *cstate, uint32_t *cmap)
 {
-  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nslots) return;
-  const uint32_t v = slot_v[s];
-  uint32_t k = coff[s];
-  for (uint32_t p = G.row[v]; p < G.row[v + 1]; ++p)
-    if (live[p] || live[G.twin[p]]) {
-      cstart[k] = (uint32_t)s - slot_base[s]; cend[k] = slot_of[G.end[p]] - slot_base[s];
-      const uint8_t f = G.flags[p], ft = G.flags[G.twin[p]];
-      const bool uturn = ((ft & GTS_F_SENSE) != 0) == gts_next_dir(f);
-      cdist[k] = G.dist[p]; cflags[k] = (uint8_t)((f & 3u) | (uturn ? GTS_F_UTURN : 0u)); cgpos[k] = p;
-      cstate[k] = G.state[p]; cmap[p] = k;
-      ++k;
-    }
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= G.m) return;
+  if (!incl[p]) { cmap[p] = GTS_NONE; return; }
+  const uint32_t a = estart[p], s = slot_of[a], base = slot_base[s];
+  const uint32_t k = coff[s] + (ipos[p] - ipos[G.row[a]]);
+  const uint8_t f = G.flags[p], ft = G.flags[G.twin[p]];
+  const bool uturn = ((ft & GTS_F_SENSE) != 0) == gts_next_dir(f);
+  cstart[k] = s - base; cend[k] = slot_of[G.end[p]] - base;
+  cdist[k] = G.dist[p]; cflags[k] = (uint8_t)((f & 3u) | (uturn ? GTS_F_UTURN : 0u));
+  cgpos[k] = (uint32_t)p; cstate[k] = G.state[p];
+  cmap[p] = k;
 }
+
 /* gfx950 wave policy of gts_component.hpp */
 struct GtsWave64 {
   static const uint32_t WIDTH = 64;
@@ -1120,12 +1216,16 @@ int gtsg_mark_repeats(GtsgEngine *e, int have_file, float copy_num_cutoff,
 {
   if (!e || !e->built) return e ? fail(e, GTSG_EINVAL, "graph not built") : GTSG_EINVAL;
   HIPCHK(hipSetDevice(e->device));
+  int rc;
+  if (e->pool_cap < (size_t)e->n + 4096) { if ((rc = pool_reserve(e, (size_t)e->n + 4096))) return rc; }
+  else pool_reserve(e, 0);
+  PALLOC(isrep, uint8_t, (size_t)e->n + 1);
   if (e->n)
     LAUNCH("repeat_vertices", k_repeat_vertices, nblk(e->n), GTS_BLOCK, e->astat,
-           e->copy_num, e->vstate, e->n, have_file, copy_num_cutoff, astat_cutoff);
+           e->copy_num, e->vstate, isrep, e->n, have_file, copy_num_cutoff, astat_cutoff);
   if (e->m)
-    LAUNCH("repeat_edges", k_repeat_edges, nblk(e->m), GTS_BLOCK, e->estart, e->eend,
-           e->astat, e->copy_num, e->state, e->m, have_file, copy_num_cutoff, astat_cutoff);
+    LAUNCH("repeat_edges", k_repeat_edges, nblk(e->m), GTS_BLOCK, e->estart, e->eend, isrep,
+           e->state, e->m);
   return sync_stream(e);
 }
 
@@ -1164,9 +1264,10 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
     if ((rc = read_u32(e, pending, &h))) return rc;
     if (!h) break;
   }
-  LAUNCH("filter_tpoly", k_filter_tpoly, nblk(n), GTS_BLOCK, G, prop, vinfo, tpoly);
-  LAUNCH("filter_ovf_init", k_filter_ovf_init, nblk(n), GTS_BLOCK, G, P, vinfo, tpoly, ovf,
-         zero_ovf, (uint32_t)e->hub_degree);
+  HIPCHK(hipMemsetAsync(tpoly, 0xFF, (size_t)n * 4, e->st));
+  if (m) LAUNCH("filter_tpoly", k_filter_tpoly, nblk(m), GTS_BLOCK, G, e->estart, prop, vinfo, tpoly);
+  LAUNCH("filter_ovf_init", k_filter_ovf_init, nblk(n), GTS_BLOCK, G, P, e->estart, vinfo, tpoly,
+         ovf, zero_ovf, (uint32_t)e->hub_degree);
   if (e->nhub && !zero_ovf)
     LAUNCH("filter_ovf_init_hub", k_filter_ovf_init_hub,
            nblk((uint64_t)e->nhub * GTS_WAVE), GTS_BLOCK, G, P, vinfo, tpoly, ovf, e->hubs,
@@ -1180,7 +1281,8 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
     if ((rc = read_u32(e, pending, &h))) return rc;
     if (!h) break;
   }
-  LAUNCH("filter_lasthit", k_filter_lasthit, nblk(n), GTS_BLOCK, G, ovf, lasthit);
+  HIPCHK(hipMemsetAsync(lasthit, 0xFF, (size_t)n * 8, e->st));
+  if (m) LAUNCH("filter_lasthit", k_filter_lasthit, nblk(m), GTS_BLOCK, G, e->estart, ovf, lasthit);
   e->stats["filter_rounds_p"] = rounds_p;
   e->stats["filter_rounds_i"] = rounds_i;
   e->f_tpoly = tpoly; e->f_ovf = ovf; e->f_lasthit = lasthit; e->f_newstate = newstate;
@@ -1297,7 +1399,7 @@ static int run_components(GtsgEngine *e, int mode)
   for (;;) {
     /* phase A: sizes are data dependent, so the workspace is reserved in two
        steps (the pool cannot grow while pointers into it are live) */
-    const size_t wsA = (size_t)m * (2 + 4) + (size_t)n * 40 +
+    const size_t wsA = (size_t)m * (2 + 4 + 8) + (size_t)n * 40 +
                        (gts_sort_tmp_elems(n) + 2 * gts_scan_tmp_elems((uint64_t)n + m)) * 8 +
                        (size_t)n + m + (16u << 20);
     /* upper bounds for phase B: slots <= n, compact edges <= m */
@@ -1356,7 +1458,10 @@ static int run_components(GtsgEngine *e, int mode)
     LAUNCH("comp_slot_bases", k_slot_bases, nblk(nslots), GTS_BLOCK, head, cidx, comp_off,
            slot_base, nslots);
     PALLOC(coff, uint32_t, (size_t)nslots + 1);
-    LAUNCH("comp_compact_count", k_compact_count, nblk(nslots), GTS_BLOCK, G, live, slot_v,
+    PALLOC(incl, uint32_t, (size_t)m + 1); PALLOC(ipos, uint32_t, (size_t)m + 2);
+    if (m) LAUNCH("comp_compact_flags", k_compact_flags, nblk(m), GTS_BLOCK, live, e->twin, incl, m);
+    gts_exscan<uint32_t, uint32_t>(incl, ipos, m, sctmp, ipos + m, e->st);
+    LAUNCH("comp_compact_count", k_compact_count, nblk(nslots), GTS_BLOCK, e->row, ipos, slot_v,
            coff, nslots);
     gts_exscan<uint32_t, uint32_t>(coff, coff, nslots, sctmp, e->d_scalars, e->st);
     uint32_t nce = 0;
@@ -1366,9 +1471,9 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cgpos, uint32_t, (size_t)nce + 1); PALLOC(cdist, int64_t, (size_t)nce + 1);
     PALLOC(cflags, uint8_t, (size_t)nce + 1); PALLOC(cstate, uint8_t, (size_t)nce + 1);
     PALLOC(cmap, uint32_t, (size_t)m + 1);
-    HIPCHK(hipMemsetAsync(cmap, 0xFF, ((size_t)m + 1) * 4, e->st));
-    LAUNCH("comp_compact_fill", k_compact_fill, nblk(nslots), GTS_BLOCK, G, live, slot_v,
-           slot_of, slot_base, coff, cstart, cend, cdist, cflags, cgpos, cstate, cmap, nslots);
+    if (m)
+      LAUNCH("comp_compact_fill", k_compact_fill, nblk(m), GTS_BLOCK, G, e->estart, incl, ipos,
+             slot_of, slot_base, coff, cstart, cend, cdist, cflags, cgpos, cstate, cmap);
     /* walk queue pool of the reference search */
     const uint64_t wq_pool = (uint64_t)pool_entries;
     PALLOC(wq_edge, uint32_t, wq_pool + 1); PALLOC(wq_dist, int64_t, wq_pool + 1);

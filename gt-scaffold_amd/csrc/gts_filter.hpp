@@ -87,6 +87,64 @@ GTS_HD bool gts_is_repeat(float astat, float copy_num, bool have_file,
   return astat <= astat_cutoff || (have_file && copy_num < copy_num_cutoff);
 }
 
+/* Edge attributes as the pair passes see them.  GtsEdgeAccGlobal reads the CSR
+   arrays (and gathers the end vertex' attributes per access); the kernels
+   stage a block's edges in LDS once and use their own accessor. */
+struct GtsEdgeAccGlobal {
+  const GtsGraphView &G;
+  GTS_HD GtsEdgeAccGlobal(const GtsGraphView &g) : G(g) {}
+  GTS_HD uint8_t sense(uint32_t p) const { return G.flags[p] & GTS_F_SENSE; }
+  GTS_HD int64_t dist(uint32_t p) const { return G.dist[p]; }
+  GTS_HD float sd(uint32_t p) const { return G.sd[p]; }
+  GTS_HD float cn(uint32_t p) const { return G.copy_num[G.end[p]]; }
+  GTS_HD int64_t len(uint32_t p) const { return G.seq_len[G.end[p]]; }
+};
+
+template <class Acc>
+GTS_HD uint32_t gts_filter_pairs_acc(const Acc &A, const GtsFilterParams &P,
+                                     uint32_t b, uint32_t e, uint32_t lane,
+                                     uint32_t nlanes, uint8_t *prop, uint32_t prop_base)
+{
+  uint32_t ovall = 0;
+  for (uint32_t i = b + lane; i < e; i += nlanes) {
+    const uint8_t fi = A.sense(i);
+    const int64_t di = A.dist(i);
+    const float si = A.sd(i);
+    const float cni = A.cn(i);
+    const int64_t li = A.len(i);
+    for (uint32_t j = i + 1; j < e; ++j) {
+      if (A.sense(j) != fi) continue;
+      const int64_t dj = A.dist(j);
+      const float cnj = A.cn(j);
+      if ((cni + cnj) < P.cncutoff && gts_ambiguous(di, si, dj, A.sd(j), P.amb))
+        prop[prop_base + (cni < cnj ? i : j)] = 1;
+      if (gts_overlap(di, li, dj, A.len(j)) > P.ocutoff)
+        ovall |= fi ? GTS_VI_OVALL_S : GTS_VI_OVALL_A;
+    }
+  }
+  return ovall;
+}
+
+/* (I) static part over an accessor that also knows which edges are marked */
+template <class Acc>
+GTS_HD uint32_t gts_filter_ovf0_acc(const Acc &A, const GtsFilterParams &P,
+                                    uint32_t b, uint32_t e, uint32_t lane,
+                                    uint32_t nlanes)
+{
+  uint32_t bits = 0;
+  for (uint32_t i = b + lane; i < e; i += nlanes) {
+    if (A.marked(i)) continue;
+    const uint8_t fi = A.sense(i);
+    const int64_t di = A.dist(i), li = A.len(i);
+    for (uint32_t j = i + 1; j < e; ++j) {
+      if (A.sense(j) != fi || A.marked(j)) continue;
+      if (gts_overlap(di, li, A.dist(j), A.len(j)) > P.ocutoff)
+        bits |= fi ? GTS_OV0_S : GTS_OV0_A;
+    }
+  }
+  return bits;
+}
+
 /* (P) static part: proposal flags prop[p] = "start(p) proposes end(p)" and
    the mark-free overflow pre-test.  Returns the GTS_VI_OVALL_* bits seen by
    this lane.  Only called for vertices that are not pre-marked. */
