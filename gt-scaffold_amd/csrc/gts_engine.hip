@@ -861,19 +861,31 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 const uint32_t *klass, uint32_t nklass,
                                 uint32_t *klass_count, unsigned long long *klass_bytes)
 {
+  /* counters are summed per workgroup in LDS first: seven global counters hit by
+     every component serialise */
+  __shared__ uint32_t s_cnt[GTS_NKLASS + 1];
+  __shared__ unsigned long long s_bytes[GTS_NKLASS + 1];
+  if (threadIdx.x <= GTS_NKLASS) { s_cnt[threadIdx.x] = 0; s_bytes[threadIdx.x] = 0; }
+  __syncthreads();
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncomp) return;
-  const uint32_t s0 = comp_off[c], s1 = comp_off[c + 1];
-  const uint32_t need = gts_comp_lds_bytes(s1 - s0, coff[s1] - coff[s0]);
-  keys[c] = ~need;   /* ascending sort = largest first */
-  vals[c] = (uint32_t)c;
-  uint32_t k = 0;
-  while (k < nklass && need > klass[k]) ++k;   /* klass ascending; nklass = global */
-  atomicAdd(&klass_count[k], 1u);
-  /* bytes the component's program has to touch once: its compact graph and
-     vertex records in, vertex states and edge marks out */
-  atomicAdd(&klass_bytes[k], (unsigned long long)(coff[s1] - coff[s0]) * 19ull +
-                                 (unsigned long long)(s1 - s0) * 18ull);
+  if (c < ncomp) {
+    const uint32_t s0 = comp_off[c], s1 = comp_off[c + 1];
+    const uint32_t need = gts_comp_lds_bytes(s1 - s0, coff[s1] - coff[s0]);
+    keys[c] = ~need;   /* ascending sort = largest first */
+    vals[c] = (uint32_t)c;
+    uint32_t k = 0;
+    while (k < nklass && need > klass[k]) ++k;   /* klass ascending; nklass = global */
+    atomicAdd(&s_cnt[k], 1u);
+    /* bytes the component's program has to touch once: its compact graph and
+       vertex records in, vertex states and edge marks out */
+    atomicAdd(&s_bytes[k], (unsigned long long)(coff[s1] - coff[s0]) * 19ull +
+                               (unsigned long long)(s1 - s0) * 18ull);
+  }
+  __syncthreads();
+  if (threadIdx.x <= GTS_NKLASS && s_cnt[threadIdx.x]) {
+    atomicAdd(&klass_count[threadIdx.x], s_cnt[threadIdx.x]);
+    atomicAdd(&klass_bytes[threadIdx.x], s_bytes[threadIdx.x]);
+  }
 }
 __global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
                                uint32_t *out /* [0]=overflow, [1]=loop */)
