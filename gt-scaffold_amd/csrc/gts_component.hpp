@@ -104,31 +104,46 @@ template <class T> struct GtsPtrSel<T, true> {
 #endif
 #define GTS_P(T) typename GtsPtrSel<T, LDS>::type
 
+/* Element types of the working set.  In the global arrays everything is
+   32 / 64 bit.  The LDS copy is packed: component-local slot and edge numbers
+   fit 16 bits (a component that fits 160 KB of LDS has far fewer than 65535
+   vertices or edges), distances and contig lengths are staged as int32 (a
+   component holding a wider value is run from global memory instead). */
+template <bool LDS> struct GtsCompTypes {
+  typedef uint32_t idx_t; typedef int64_t dist_t; typedef int64_t seq_t;
+};
+template <> struct GtsCompTypes<true> {
+  typedef uint16_t idx_t; typedef int32_t dist_t; typedef int32_t seq_t;
+};
+
 /* base pointers of ONE component, component-local indices */
 template <bool LDS>
 struct GtsCompMemT {
+  typedef typename GtsCompTypes<LDS>::idx_t idx_t;
+  typedef typename GtsCompTypes<LDS>::dist_t dist_t;
+  typedef typename GtsCompTypes<LDS>::seq_t seq_t;
   uint32_t nv, ne;           /* slots, compact edges of the component */
   uint32_t e0;               /* value to subtract from coff[] entries */
-  GTS_P(const uint32_t) coff;      /* nv+1 */
-  GTS_P(const uint32_t) cstart;
-  GTS_P(const uint32_t) cend;
-  GTS_P(const int64_t) cdist;
+  GTS_P(const idx_t) coff;   /* nv+1 */
+  GTS_P(const idx_t) cstart;
+  GTS_P(const idx_t) cend;
+  GTS_P(const dist_t) cdist;
   GTS_P(const uint8_t) cflags;
-  GTS_P(const int64_t) cseq;
+  GTS_P(const seq_t) cseq;
   GTS_P(uint8_t) cstate;
   GTS_P(uint8_t) vst;
-  GTS_P(uint32_t) queue;
-  GTS_P(uint32_t) term;
-  GTS_P(uint32_t) visited;
-  GTS_P(uint32_t) st_v;
-  GTS_P(uint32_t) st_par;
-  GTS_P(uint32_t) st_cur;
-  GTS_P(uint32_t) edgemap;
+  GTS_P(idx_t) queue;
+  GTS_P(idx_t) term;
+  GTS_P(idx_t) visited;
+  GTS_P(idx_t) st_v;
+  GTS_P(idx_t) st_par;
+  GTS_P(idx_t) st_cur;
+  GTS_P(idx_t) edgemap;
   GTS_P(uint32_t) lastpop;
-  GTS_P(uint32_t) wterm;
-  GTS_P(uint32_t) touched;
-  GTS_P(uint32_t) cc_best;
-  GTS_P(uint32_t) ccoff;
+  GTS_P(idx_t) wterm;
+  GTS_P(idx_t) touched;
+  GTS_P(idx_t) cc_best;
+  GTS_P(idx_t) ccoff;
   GTS_P(uint8_t) st_dir;
   GTS_P(uint8_t) tight;
   GTS_P(float) distmap;
@@ -137,20 +152,24 @@ struct GtsCompMemT {
 };
 typedef GtsCompMemT<false> GtsCompMem;
 
-/* LDS bytes needed to stage a component (every array 16-byte aligned) */
+/* LDS bytes needed to stage a component in the packed layout (every array
+   16-byte aligned) */
 GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
 {
   const uint32_t a = 16;
   uint32_t b = 0;
-  b += (((nv + 1) * 4 + a - 1) / a) * a * 2;          /* coff, ccoff */
-  b += ((nv * 4 + a - 1) / a) * a * 12;               /* queue..cc_best, distmap */
-  b += ((nv * 8 + a - 1) / a) * a * 3;                /* cseq, nd, plen */
+  b += (((nv + 1) * 2 + a - 1) / a) * a * 2;          /* coff, ccoff */
+  b += ((nv * 2 + a - 1) / a) * a * 10;               /* queue .. cc_best */
+  b += ((nv * 4 + a - 1) / a) * a * 3;                /* lastpop, distmap, cseq */
+  b += ((nv * 8 + a - 1) / a) * a * 2;                /* nd, plen */
   b += ((nv + a - 1) / a) * a * 3;                    /* vst, st_dir, tight */
-  b += ((ne * 4 + a - 1) / a) * a * 2;                /* cstart, cend */
-  b += ((ne * 8 + a - 1) / a) * a;                    /* cdist */
+  b += ((ne * 2 + a - 1) / a) * a * 2;                /* cstart, cend */
+  b += ((ne * 4 + a - 1) / a) * a;                    /* cdist */
   b += ((ne + a - 1) / a) * a * 2;                    /* cflags, cstate */
   return b;
 }
+/* the packed layout addresses at most this many slots / edges */
+#define GTS_LDS_MAX_INDEX 65000u
 
 /* (float)GT_WORD_MAX, ref algorithms.c:650 */
 #define GTS_DIST_UNSET 9223372036854775808.0f
@@ -253,14 +272,17 @@ struct GtsComponent {
     const uint32_t lane = W::lane();
     uint32_t sp = 1;
     nvis = 0;
-    M.st_v[0] = start; M.st_par[0] = GTS_NONE; M.st_cur[0] = eoff(start);
+    M.st_v[0] = start; M.st_cur[0] = eoff(start);
+    M.st_par[0] = (typename GtsCompMemT<LDS>::idx_t)GTS_NONE;   /* truncated in the packed layout */
     M.st_dir[0] = dir0 ? 1 : 0;
     M.visited[nvis++] = start;
     M.vst[start] = GIS_VISITED;
     W::fence();
     while (sp > 0) {
       const uint32_t f = sp - 1;
-      const uint32_t v = W::uni(M.st_v[f]), par = W::uni(M.st_par[f]);
+      const uint32_t v = W::uni(M.st_v[f]);
+      /* the root's parent is GTS_NONE truncated to the index type: never a slot */
+      const uint32_t par = W::uni(M.st_par[f]);
       const bool dir = W::uni((uint32_t)M.st_dir[f]) != 0;
       uint32_t cur = W::uni(M.st_cur[f]);
       const uint32_t ee = eoff(v + 1);

@@ -674,12 +674,20 @@ __global__ void k_slot_finish(const uint32_t *labels, const uint32_t *cidx,
   vst[s] = vstate[v];
 }
 /* first slot of the component of every slot */
+/* first slot of the component of every slot; flags components that hold a
+   contig length the packed LDS layout (int32) cannot carry */
 __global__ void k_slot_bases(const uint32_t *head, const uint32_t *cidx,
-                             const uint32_t *comp_off, uint32_t *slot_base,
-                             uint32_t nslots)
+                             const uint32_t *comp_off, const int64_t *cseq,
+                             uint32_t *slot_base, uint32_t *slot_comp,
+                             uint8_t *comp_wide, uint32_t nslots)
 {
   uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < nslots) slot_base[s] = comp_off[cidx[s] + head[s] - 1];
+  if (s >= nslots) return;
+  const uint32_t c = cidx[s] + head[s] - 1;
+  slot_base[s] = comp_off[c];
+  slot_comp[s] = c;
+  const int64_t l = cseq[s];
+  if (l != (int32_t)l) comp_wide[c] = 1;
 }
 /* an edge enters the compact graph if it or its twin is live: marking a walk
    edge's twin SCAFFOLD (algorithms.c:842-845) revives a marked twin.  One lane
@@ -703,7 +711,8 @@ __global__ void k_compact_count(const uint32_t *row, const uint32_t *ipos,
 __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
                                const uint32_t *incl, const uint32_t *ipos,
                                const uint32_t *slot_of, const uint32_t *slot_base,
-                               const uint32_t *coff, uint32_t *cstart,
+                               const uint32_t *coff, const uint32_t *slot_comp,
+                               uint8_t *comp_wide, uint32_t *cstart,
                                uint32_t *cend, int64_t *cdist, uint8_t *cflags,
                                uint32_t *cgpos, uint8_t *cstate, uint32_t *cmap)
 {
@@ -715,7 +724,9 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
   const uint8_t f = G.flags[p], ft = G.flags[G.twin[p]];
   const bool uturn = ((ft & GTS_F_SENSE) != 0) == gts_next_dir(f);
   cstart[k] = s - base; cend[k] = slot_of[G.end[p]] - base;
-  cdist[k] = G.dist[p]; cflags[k] = (uint8_t)((f & 3u) | (uturn ? GTS_F_UTURN : 0u));
+  const int64_t d = G.dist[p];
+  if (d != (int32_t)d) comp_wide[slot_comp[s]] = 1;
+  cdist[k] = d; cflags[k] = (uint8_t)((f & 3u) | (uturn ? GTS_F_UTURN : 0u));
   cgpos[k] = (uint32_t)p; cstate[k] = G.state[p];
   cmap[p] = k;
 }
@@ -821,31 +832,32 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
   const uint32_t nv = G0.nv, ne = G0.ne, lane = threadIdx.x;
   gts_lds_cursor p = (gts_lds_cursor)smem;
   GtsCompMemT<true> M;
+  typedef GtsCompMemT<true>::idx_t idx_t;
   M.nv = nv; M.ne = ne; M.e0 = 0;
-  auto coff = lds_carve<uint32_t>(p, nv + 1);
-  M.ccoff = lds_carve<uint32_t>(p, nv + 1);
-  M.queue = lds_carve<uint32_t>(p, nv); M.term = lds_carve<uint32_t>(p, nv);
-  M.visited = lds_carve<uint32_t>(p, nv); M.st_v = lds_carve<uint32_t>(p, nv);
-  M.st_par = lds_carve<uint32_t>(p, nv); M.st_cur = lds_carve<uint32_t>(p, nv);
-  M.edgemap = lds_carve<uint32_t>(p, nv); M.lastpop = lds_carve<uint32_t>(p, nv);
-  M.wterm = lds_carve<uint32_t>(p, nv); M.touched = lds_carve<uint32_t>(p, nv);
-  M.cc_best = lds_carve<uint32_t>(p, nv); M.distmap = lds_carve<float>(p, nv);
-  auto cseq = lds_carve<int64_t>(p, nv);
+  auto coff = lds_carve<idx_t>(p, nv + 1);
+  M.ccoff = lds_carve<idx_t>(p, nv + 1);
+  M.queue = lds_carve<idx_t>(p, nv); M.term = lds_carve<idx_t>(p, nv);
+  M.visited = lds_carve<idx_t>(p, nv); M.st_v = lds_carve<idx_t>(p, nv);
+  M.st_par = lds_carve<idx_t>(p, nv); M.st_cur = lds_carve<idx_t>(p, nv);
+  M.edgemap = lds_carve<idx_t>(p, nv); M.wterm = lds_carve<idx_t>(p, nv);
+  M.touched = lds_carve<idx_t>(p, nv); M.cc_best = lds_carve<idx_t>(p, nv);
+  M.lastpop = lds_carve<uint32_t>(p, nv); M.distmap = lds_carve<float>(p, nv);
+  auto cseq = lds_carve<int32_t>(p, nv);
   M.nd = lds_carve<int64_t>(p, nv); M.plen = lds_carve<uint64_t>(p, nv);
   M.vst = lds_carve<uint8_t>(p, nv); M.st_dir = lds_carve<uint8_t>(p, nv);
   M.tight = lds_carve<uint8_t>(p, nv);
-  auto cstart = lds_carve<uint32_t>(p, ne);
-  auto cend = lds_carve<uint32_t>(p, ne);
-  auto cdist = lds_carve<int64_t>(p, ne);
+  auto cstart = lds_carve<idx_t>(p, ne);
+  auto cend = lds_carve<idx_t>(p, ne);
+  auto cdist = lds_carve<int32_t>(p, ne);
   auto cflags = lds_carve<uint8_t>(p, ne);
   M.cstate = lds_carve<uint8_t>(p, ne);
-  for (uint32_t i = lane; i <= nv; i += GTS_WAVE) coff[i] = G0.coff[i] - G0.e0;
+  for (uint32_t i = lane; i <= nv; i += GTS_WAVE) coff[i] = (idx_t)(G0.coff[i] - G0.e0);
   for (uint32_t i = lane; i < nv; i += GTS_WAVE) {
-    cseq[i] = G0.cseq[i]; M.vst[i] = G0.vst[i];
+    cseq[i] = (int32_t)G0.cseq[i]; M.vst[i] = G0.vst[i];
     M.lastpop[i] = 0; M.distmap[i] = GTS_DIST_UNSET; M.st_dir[i] = 0; M.tight[i] = 0;
   }
   for (uint32_t i = lane; i < ne; i += GTS_WAVE) {
-    cstart[i] = G0.cstart[i]; cend[i] = G0.cend[i]; cdist[i] = G0.cdist[i];
+    cstart[i] = (idx_t)G0.cstart[i]; cend[i] = (idx_t)G0.cend[i]; cdist[i] = (int32_t)G0.cdist[i];
     cflags[i] = G0.cflags[i]; M.cstate[i] = G0.cstate[i];
   }
   M.coff = coff; M.cseq = cseq; M.cstart = cstart; M.cend = cend; M.cdist = cdist;
@@ -858,6 +870,7 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
    components fit each size class */
 __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 uint32_t *keys, uint32_t *vals, uint32_t ncomp,
+                                const uint8_t *comp_wide,
                                 const uint32_t *klass, uint32_t nklass,
                                 uint32_t *klass_count, unsigned long long *klass_bytes)
 {
@@ -870,7 +883,10 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c < ncomp) {
     const uint32_t s0 = comp_off[c], s1 = comp_off[c + 1];
-    const uint32_t need = gts_comp_lds_bytes(s1 - s0, coff[s1] - coff[s0]);
+    const uint32_t cnv = s1 - s0, cne = coff[s1] - coff[s0];
+    uint32_t need = gts_comp_lds_bytes(cnv, cne);
+    /* not representable in the packed LDS layout: run from global memory */
+    if (comp_wide[c] || cnv > GTS_LDS_MAX_INDEX || cne > GTS_LDS_MAX_INDEX) need = 0x7FFFFFFFu;
     keys[c] = ~need;   /* ascending sort = largest first */
     vals[c] = (uint32_t)c;
     uint32_t k = 0;
@@ -1415,7 +1431,7 @@ static int run_components(GtsgEngine *e, int mode)
                        (gts_sort_tmp_elems(n) + 2 * gts_scan_tmp_elems((uint64_t)n + m)) * 8 +
                        (size_t)n + m + (16u << 20);
     /* upper bounds for phase B: slots <= n, compact edges <= m */
-    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64) + (size_t)m * (4 * 3 + 8 + 2) +
+    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64 + 8) + (size_t)m * (4 * 3 + 8 + 2) +
                        (size_t)pool_entries * 12 + (size_t)n * 24 + (16u << 20);
     if (!e->pool || e->pool_cap < wsA + wsB) {
       if ((rc = pool_reserve(e, wsA + wsB))) return rc;
@@ -1467,8 +1483,10 @@ static int run_components(GtsgEngine *e, int mode)
            e->seq_len, e->vstate, comp_off, slot_of, cseq, vst, nslots);
     LAUNCH("fill", k_fill<uint32_t>, 1, 1, comp_off + ncomp, nslots, (uint64_t)1);
     PALLOC(slot_base, uint32_t, nslots);
-    LAUNCH("comp_slot_bases", k_slot_bases, nblk(nslots), GTS_BLOCK, head, cidx, comp_off,
-           slot_base, nslots);
+    PALLOC(slot_comp, uint32_t, nslots); PALLOC(comp_wide, uint8_t, (size_t)ncomp + 1);
+    HIPCHK(hipMemsetAsync(comp_wide, 0, (size_t)ncomp + 1, e->st));
+    LAUNCH("comp_slot_bases", k_slot_bases, nblk(nslots), GTS_BLOCK, head, cidx, comp_off, cseq,
+           slot_base, slot_comp, comp_wide, nslots);
     PALLOC(coff, uint32_t, (size_t)nslots + 1);
     PALLOC(incl, uint32_t, (size_t)m + 1); PALLOC(ipos, uint32_t, (size_t)m + 2);
     if (m) LAUNCH("comp_compact_flags", k_compact_flags, nblk(m), GTS_BLOCK, live, e->twin, incl, m);
@@ -1485,7 +1503,8 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cmap, uint32_t, (size_t)m + 1);
     if (m)
       LAUNCH("comp_compact_fill", k_compact_fill, nblk(m), GTS_BLOCK, G, e->estart, incl, ipos,
-             slot_of, slot_base, coff, cstart, cend, cdist, cflags, cgpos, cstate, cmap);
+             slot_of, slot_base, coff, slot_comp, comp_wide, cstart, cend, cdist, cflags, cgpos,
+             cstate, cmap);
     /* walk queue pool of the reference search */
     const uint64_t wq_pool = (uint64_t)pool_entries;
     PALLOC(wq_edge, uint32_t, wq_pool + 1); PALLOC(wq_dist, int64_t, wq_pool + 1);
@@ -1517,7 +1536,7 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemsetAsync(klass_count, 0, (GTS_NKLASS + 1) * 4, e->st));
     HIPCHK(hipMemsetAsync(e->d_scalars + 112, 0, (GTS_NKLASS + 1) * 8, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
-           ncomp, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
+           ncomp, comp_wide, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
            (unsigned long long *)(e->d_scalars + 112));
     const uint32_t *order;
     {
