@@ -295,7 +295,7 @@ def main():
                            for r in range(3)]),
                    kernels_ms_per_step={k: round(v[1] / args.steps, 3) for k, v in
                                         sorted(kt.items(), key=lambda kv: -kv[1][1])})
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
             cb, og, gs = cpu_baseline(pkg, args.cpu_sample, WORKLOAD["gen"], 99)
             out["cpu_baseline"] = cb
         if args.verify:
