@@ -281,6 +281,9 @@ def main():
                    roofline=roof, roofline_largest_streaming_kernel=roof_stream,
                    component_kernel=dict(
                        walks_fast=eng.stat("fast_walks"), walks_reference=eng.stat("slow_walks"),
+                       clean_components=eng.stat("clean_components"),
+                       components_per_lds_class=[eng.stat("components_lds_class%d" % i) for i in range(6)],
+                       components_global_mem=eng.stat("components_global_mem"),
                        **{k: eng.stat(k) for k in
                           ("us_sum_removecycles", "us_max_removecycles", "us_sum_makescaffold_other",
                            "us_max_makescaffold_other", "us_sum_walks_fast", "us_max_walks_fast",

@@ -82,6 +82,9 @@ struct GtsCompView {
   int64_t *nd;               /* slot -> integer label pushed with the node */
   uint64_t *plen;            /* slot -> contig length of the tree path */
   uint8_t *tight;            /* slot -> number of tight in-arcs (saturating) */
+  uint8_t *gorient;          /* slot -> strand + 1 of the whole-component analysis */
+  uint32_t *topo, *tpos;     /* topological order of the forward sheet, inverse */
+  uint32_t *stat_clean;      /* per component: 1 if the analysis succeeded */
   uint32_t *stat_fast, *stat_slow;  /* per component: walks by path taken */
   unsigned long long *why;   /* [8] why walks left the linear path: mixed start,
                                 self arc, back at start, marked end, two
@@ -149,6 +152,11 @@ struct GtsCompMemT {
   GTS_P(float) distmap;
   GTS_P(int64_t) nd;
   GTS_P(uint64_t) plen;
+  /* whole-component analysis (analyze): strand of every vertex + 1, a
+     topological order of the forward sheet and its inverse */
+  GTS_P(uint8_t) gorient;
+  GTS_P(idx_t) topo;
+  GTS_P(idx_t) tpos;
 };
 typedef GtsCompMemT<false> GtsCompMem;
 
@@ -159,10 +167,10 @@ GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
   const uint32_t a = 16;
   uint32_t b = 0;
   b += (((nv + 1) * 2 + a - 1) / a) * a * 2;          /* coff, ccoff */
-  b += ((nv * 2 + a - 1) / a) * a * 10;               /* queue .. cc_best */
+  b += ((nv * 2 + a - 1) / a) * a * 12;               /* queue .. cc_best, topo, tpos */
   b += ((nv * 4 + a - 1) / a) * a * 3;                /* lastpop, distmap, cseq */
   b += ((nv * 8 + a - 1) / a) * a * 2;                /* nd, plen */
-  b += ((nv + a - 1) / a) * a * 3;                    /* vst, st_dir, tight */
+  b += ((nv + a - 1) / a) * a * 4;                    /* vst, st_dir, tight, gorient */
   b += ((ne * 2 + a - 1) / a) * a * 2;                /* cstart, cend */
   b += ((ne * 4 + a - 1) / a) * a;                    /* cdist */
   b += ((ne + a - 1) / a) * a * 2;                    /* cflags, cstate */
@@ -187,11 +195,12 @@ struct GtsComponent {
   uint32_t ntouch;
   uint32_t nfast, nslow;
   uint64_t tfast, tslow, npops;
+  bool clean;           /* analyze() succeeded and nothing changed since */
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -209,6 +218,7 @@ struct GtsComponent {
     m.touched = C.touched + s0; m.cc_best = C.cc_best + s0;
     m.ccoff = C.ccoff + s0 + comp; m.st_dir = C.st_dir + s0; m.tight = C.tight + s0;
     m.distmap = C.distmap + s0; m.nd = C.nd + s0; m.plen = C.plen + s0;
+    m.gorient = C.gorient + s0; m.topo = C.topo + s0; m.tpos = C.tpos + s0;
     return m;
   }
 
@@ -1012,12 +1022,246 @@ struct GtsComponent {
     return !bad;
   }
 
+
+  /* ---- whole-component analysis ------------------------------------------
+     A scaffold graph is bidirected: a walk enters a contig at one end and
+     leaves at the other.  If the component has a consistent strand assignment
+     o(v) -- every compact edge (u -> v) relates the two strands by
+     o(v) = next_dir(e) xor (sense(e) != o(u)) without contradiction -- then
+     every traversal the reference starts (DFS of removecycles, search of
+     create_walk) stays on ONE sheet: the forward sheet (arcs with
+     sense == o(u)) or its mirror image.  If in addition no edge is a u-turn
+     and the forward sheet is acyclic, then
+       * no DFS of removecycles can meet a vertex on its stack: cycle removal
+         marks nothing and is reduced to its terminal search;
+       * one order serves every walk, which becomes a single sweep: edge
+         states are not symmetric, so the mirror sheet (live arcs with
+         sense != o(u)) is not the transpose of the forward sheet; the order
+         is a topological order of D = forward arcs + reversed mirror arcs
+         (from x's list: edges with sense == o(x) that are live or whose twin
+         is), swept upwards on the forward sheet and downwards on the mirror.
+     The analysis costs two passes over the component; the result is dropped
+     as soon as a SCAFFOLD mark revives a marked twin (new arcs). */
+  GTS_HD bool analyze()
+  {
+    const uint32_t lane = W::lane();
+    auto Q = M.queue;
+    auto indeg = M.st_v;
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.gorient[s] = 0; indeg[s] = 0; }
+    W::fence();
+    /* strands by a search over all compact edges, in-degrees of the forward
+       sheet on the way */
+    uint32_t qh2 = 0, qn2 = 1;
+    bool bad = false;
+    Q[0] = 0;
+    M.gorient[0] = 2;
+    W::fence();
+    while (qh2 < qn2 && !bad) {
+      const uint32_t u = W::uni(Q[qh2]);
+      ++qh2;
+      const bool ou = W::uni((uint32_t)M.gorient[u]) == 2;
+      const uint32_t eb = eoff(u), ee = eoff(u + 1);
+      for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool have = false, fresh = false, clash = false, fwd = false;
+        uint32_t v = 0, ov = 0;
+        if (ce < ee) {
+          const uint32_t fl = M.cflags[ce];
+          const bool sense = (fl & GTS_F_SENSE) != 0;
+          have = true;
+          v = M.cend[ce];
+          ov = (gts_next_dir((uint8_t)fl) != (sense != ou)) ? 2u : 1u;
+          const uint32_t cur = M.gorient[v];
+          clash = (fl & GTS_F_UTURN) || v == u || (cur != 0 && cur != ov);
+          fresh = cur == 0;
+          fwd = sense == ou && (!gts_edge_is_marked(M.cstate[ce]) || (fl & GTS_F_TWINLIVE));
+        }
+        if (W::ballot(clash)) { bad = true; break; }
+        const uint64_t fm = W::ballot(have && fresh);
+        if (have && fresh) {
+          M.gorient[v] = (uint8_t)ov;
+          Q[qn2 + W::popc_below(fm, lane)] = v;
+        }
+        if (fwd) indeg[v] = indeg[v] + 1;
+        qn2 += W::popc(fm);
+        W::fence();
+      }
+    }
+    if (bad || qn2 != nv) return false;
+    /* topological order of the forward sheet: topo[] is the peeling queue */
+    uint32_t th = 0, tn = 0;
+    for (uint32_t base = 0; base < nv; base += W::WIDTH) {
+      const uint32_t v = base + lane;
+      const bool src = v < nv && indeg[v] == 0;
+      const uint64_t sm = W::ballot(src);
+      if (src) M.topo[tn + W::popc_below(sm, lane)] = v;
+      tn += W::popc(sm);
+    }
+    W::fence();
+    while (th < tn) {
+      const uint32_t u = W::uni(M.topo[th]);
+      M.tpos[u] = th;
+      ++th;
+      const bool ou = W::uni((uint32_t)M.gorient[u]) == 2;
+      const uint32_t eb = eoff(u), ee = eoff(u + 1);
+      for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool ready = false;
+        uint32_t v = 0;
+        if (ce < ee) {
+          const uint32_t fl = M.cflags[ce];
+          if (((fl & GTS_F_SENSE) != 0) == ou &&
+              (!gts_edge_is_marked(M.cstate[ce]) || (fl & GTS_F_TWINLIVE))) {
+            v = M.cend[ce];
+            const uint32_t d = indeg[v] - 1;
+            indeg[v] = d;
+            ready = d == 0;
+          }
+        }
+        const uint64_t rm = W::ballot(ready);
+        if (ready) M.topo[tn + W::popc_below(rm, lane)] = v;
+        tn += W::popc(rm);
+        W::fence();
+      }
+    }
+    return tn == nv;
+  }
+
+  /* create_walk on a clean component: one sweep over the precomputed order
+     (see analyze and create_walk_fast for why the result is the reference's) */
+  GTS_HD bool create_walk_clean(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
+  {
+    const uint32_t lane = W::lane();
+    auto R = M.queue;
+    auto depth = M.st_par;
+    /* the start's live edges pick the sheet */
+    bool has_s = false, has_a = false;
+    {
+      const uint32_t eb = eoff(start), ee = eoff(start + 1);
+      for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool live = false, sense = false;
+        if (ce < ee) {
+          live = !gts_edge_is_marked(M.cstate[ce]);
+          sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+        }
+        has_s |= W::ballot(live && sense) != 0;
+        has_a |= W::ballot(live && !sense) != 0;
+      }
+    }
+    if (has_s && has_a) { W::count(C.why + 0); return false; }
+    if (!has_s && !has_a) return true;
+    const bool forward = has_s == (W::uni((uint32_t)M.gorient[start]) == 2);
+    uint32_t nr = 0, pending = 1, best_t = GTS_NONE;
+    uint64_t best_len = 0;
+    bool inexact = false, bad = false;
+    M.plen[start] = (uint64_t)M.cseq[start];
+    depth[start] = 0;
+    M.nd[start] = 0;
+    W::fence();
+    int64_t pos = (int64_t)W::uni(M.tpos[start]);
+    while (pending > 0 && !bad && pos >= 0 && pos < (int64_t)nv) {
+      /* next reached vertices in sweep order */
+      const int64_t mypos = forward ? pos + (int64_t)lane : pos - (int64_t)lane;
+      uint32_t cv = 0;
+      bool reached = false;
+      if (mypos >= 0 && mypos < (int64_t)nv) {
+        cv = M.topo[(uint32_t)mypos];
+        reached = cv == start ? mypos == (int64_t)W::uni(M.tpos[start])
+                              : M.distmap[cv] != GTS_DIST_UNSET;
+      }
+      uint64_t rm = W::ballot(reached);
+      while (rm && !bad) {
+        const uint32_t l = W::ctz(rm);
+        rm &= rm - 1;
+        const uint32_t u = W::bcast(cv, l);
+        --pending;
+        const bool du = (W::uni((uint32_t)M.gorient[u]) == 2) == forward;
+        const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
+        const uint64_t plu = (uint64_t)W::uni64((int64_t)M.plen[u]);
+        const uint32_t dpu = u == start ? 0 : W::uni(depth[u]);
+        const uint32_t eb = eoff(u), ee = eoff(u + 1);
+        bool us = false, ua = false;
+        for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
+          const uint32_t ce = base + lane;
+          bool live = false, sense = false, arc = false, tie = false, fresh = false;
+          uint32_t v = 0;
+          if (ce < ee) {
+            live = !gts_edge_is_marked(M.cstate[ce]);
+            sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+            arc = live && sense == du;
+            if (arc) {
+              v = M.cend[ce];
+              const int64_t w = M.cdist[ce];
+              const float cand = u == start ? (float)w : (float)(ndu + w);
+              const float old = M.distmap[v];
+              if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
+              if (old == GTS_DIST_UNSET || old > cand) {
+                fresh = old == GTS_DIST_UNSET;
+                M.distmap[v] = cand;
+                M.edgemap[v] = ce;
+                M.nd[v] = u == start ? w : (int64_t)cand;
+                M.plen[v] = plu + (uint64_t)M.cseq[v];
+                depth[v] = dpu + 1;
+              } else if (old == cand)
+                tie = true;
+            }
+          }
+          us |= W::ballot(live && sense) != 0;
+          ua |= W::ballot(live && !sense) != 0;
+          inexact = W::ballot(inexact) != 0;
+          const uint64_t fm = W::ballot(fresh);
+          if (fresh) R[nr + W::popc_below(fm, lane)] = v;
+          nr += W::popc(fm);
+          pending += W::popc(fm);
+          uint64_t tm = W::ballot(tie);
+          if (tm && inexact) { W::count(C.why + 5); bad = true; break; }
+          while (tm) {
+            const uint32_t tl = W::ctz(tm);
+            tm &= tm - 1;
+            const uint32_t tv = W::bcast(v, tl), tce = W::bcast(ce, tl);
+            const uint32_t up = W::uni(M.cstart[W::uni(M.edgemap[tv])]);
+            if (pushed_after(up, u, start)) {
+              M.edgemap[tv] = tce;
+              M.plen[tv] = plu + (uint64_t)W::uni64(M.cseq[tv]);
+              depth[tv] = dpu + 1;
+              W::fence();
+            }
+          }
+          W::fence();
+        }
+        if (!bad && u != start && !(us && ua)) {
+          if (plu > best_len) { best_len = plu; best_t = u; }
+          else if (plu == best_len && best_t != GTS_NONE) {
+            if (inexact) { W::count(C.why + 7); bad = true; }
+            else if (pushed_after(u, best_t, start)) best_t = u;
+          }
+        }
+      }
+      pos = forward ? pos + (int64_t)W::WIDTH : pos - (int64_t)W::WIDTH;
+    }
+    if (!bad && best_t != GTS_NONE && best_len > cc_len) {
+      uint32_t cv = best_t, n = 0;
+      while (cv != start) {
+        const uint32_t re = W::uni(M.edgemap[cv]);
+        M.cc_best[n++] = re;
+        cv = W::uni(M.cstart[re]);
+      }
+      cc_len = best_len;
+      cc_n = n;
+    }
+    for (uint32_t k = lane; k < nr; k += W::WIDTH) M.distmap[R[k]] = GTS_DIST_UNSET;
+    W::fence();
+    return !bad;
+  }
+
   GTS_HD bool create_walk(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t gv = C.slot_v[s0 + start];
     if (W::uni(C.G.row[gv + 1]) == W::uni(C.G.row[gv])) return true; /* :655 */
     const uint64_t t0 = W::clock();
-    if (C.fast_walks && create_walk_fast(start, cc_len, cc_n)) {
+    if (C.fast_walks && (clean ? create_walk_clean(start, cc_len, cc_n)
+                               : create_walk_fast(start, cc_len, cc_n))) {
       ++nfast; tfast += W::clock() - t0; return true;
     }
     const uint64_t t1 = W::clock();
@@ -1032,7 +1276,7 @@ struct GtsComponent {
   GTS_HD void makescaffold()
   {
     const uint32_t lane = W::lane();
-    calc_cc();
+    if (!clean) calc_cc();   /* clean: run() just computed the same ccs */
     for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }
     W::fence();
     auto ccoff = M.ccoff;
@@ -1059,6 +1303,7 @@ struct GtsComponent {
         /* mark the best walk, algorithms.c:835-848 (a walk without edges is
            undefined behaviour there and is left unmarked here) */
         if (cc_n > 0) {
+          bool revived = false;
           for (uint32_t k = lane; k < cc_n; k += W::WIDTH) {
             const uint32_t ce = M.cc_best[k];
             const uint32_t p = C.cgpos[e0g + ce], t = C.G.twin[p];
@@ -1066,10 +1311,14 @@ struct GtsComponent {
             C.G.state[p] = GIS_SCAFFOLD;
             C.G.state[t] = GIS_SCAFFOLD;
             const uint32_t ct = C.cmap[t];
-            if (ct != GTS_NONE) M.cstate[ct - e0g] = GIS_SCAFFOLD;
+            if (ct != GTS_NONE) {
+              if (gts_edge_is_marked(M.cstate[ct - e0g])) revived = true;   /* new arc */
+              M.cstate[ct - e0g] = GIS_SCAFFOLD;
+            }
             M.vst[M.cend[ce]] = GIS_SCAFFOLD;
             M.vst[M.cstart[ce]] = GIS_SCAFFOLD;
           }
+          if (W::ballot(revived)) clean = false;
           W::fence();
         }
       }
@@ -1080,8 +1329,18 @@ struct GtsComponent {
   {
     const uint32_t lane = W::lane();
     const uint64_t t0 = W::clock();
-    removecycles();
+    clean = C.fast_walks && nv > 1 && analyze();
+    if (clean) {
+      /* removecycles = its terminal search: every DFS is futile (analyze) */
+      calc_cc();
+      if (mode != GTS_MODE_MAKESCAFFOLD)
+        for (uint32_t s = lane; s < nv; s += W::WIDTH)
+          if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
+      W::fence();
+    } else
+      removecycles();
     const uint64_t t1 = W::clock();
+    const bool was_clean = clean;
     if (mode == GTS_MODE_MAKESCAFFOLD) makescaffold();
     const uint64_t t2 = W::clock();
     for (uint32_t s = lane; s < nv; s += W::WIDTH) {
@@ -1092,6 +1351,7 @@ struct GtsComponent {
     }
     if (lane == 0) {
       C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow;
+      C.stat_clean[c] = was_clean ? 1u : 0u;
       C.tstat[5 * (uint64_t)c] = t1 - t0;
       C.tstat[5 * (uint64_t)c + 1] = t2 - t1 - tfast - tslow;
       C.tstat[5 * (uint64_t)c + 2] = tfast;

@@ -33,6 +33,8 @@ enum : uint8_t {
    the pair is geometrically inconsistent and the reference's twin exclusion
    (algorithms.c:702) becomes path dependent */
 #define GTS_F_UTURN 4u
+/* compact edges only: the twin was live when the component was compacted */
+#define GTS_F_TWINLIVE 8u
 
 /* ref gt_scaffolder_algorithms.c:38-47 */
 GTS_HD bool gts_vertex_is_marked(uint8_t s)

@@ -708,7 +708,7 @@ __global__ void k_compact_count(const uint32_t *row, const uint32_t *ipos,
   const uint32_t v = slot_v[s];
   cnt[s] = ipos[row[v + 1]] - ipos[row[v]];
 }
-__global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
+__global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart, const uint8_t *live,
                                const uint32_t *incl, const uint32_t *ipos,
                                const uint32_t *slot_of, const uint32_t *slot_base,
                                const uint32_t *coff, const uint32_t *slot_comp,
@@ -726,7 +726,9 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
   cstart[k] = s - base; cend[k] = slot_of[G.end[p]] - base;
   const int64_t d = G.dist[p];
   if (d != (int32_t)d) comp_wide[slot_comp[s]] = 1;
-  cdist[k] = d; cflags[k] = (uint8_t)((f & 3u) | (uturn ? GTS_F_UTURN : 0u));
+  cdist[k] = d;
+  cflags[k] = (uint8_t)((f & 3u) | (uturn ? GTS_F_UTURN : 0u) |
+                        (live[G.twin[p]] ? GTS_F_TWINLIVE : 0u));
   cgpos[k] = (uint32_t)p; cstate[k] = G.state[p];
   cmap[p] = k;
 }
@@ -845,7 +847,8 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
   auto cseq = lds_carve<int32_t>(p, nv);
   M.nd = lds_carve<int64_t>(p, nv); M.plen = lds_carve<uint64_t>(p, nv);
   M.vst = lds_carve<uint8_t>(p, nv); M.st_dir = lds_carve<uint8_t>(p, nv);
-  M.tight = lds_carve<uint8_t>(p, nv);
+  M.tight = lds_carve<uint8_t>(p, nv); M.gorient = lds_carve<uint8_t>(p, nv);
+  M.topo = lds_carve<idx_t>(p, nv); M.tpos = lds_carve<idx_t>(p, nv);
   auto cstart = lds_carve<idx_t>(p, ne);
   auto cend = lds_carve<idx_t>(p, ne);
   auto cdist = lds_carve<int32_t>(p, ne);
@@ -1431,7 +1434,7 @@ static int run_components(GtsgEngine *e, int mode)
                        (gts_sort_tmp_elems(n) + 2 * gts_scan_tmp_elems((uint64_t)n + m)) * 8 +
                        (size_t)n + m + (16u << 20);
     /* upper bounds for phase B: slots <= n, compact edges <= m */
-    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64 + 8) + (size_t)m * (4 * 3 + 8 + 2) +
+    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64 + 8 + 16) + (size_t)m * (4 * 3 + 8 + 2) +
                        (size_t)pool_entries * 12 + (size_t)n * 24 + (16u << 20);
     if (!e->pool || e->pool_cap < wsA + wsB) {
       if ((rc = pool_reserve(e, wsA + wsB))) return rc;
@@ -1502,7 +1505,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cflags, uint8_t, (size_t)nce + 1); PALLOC(cstate, uint8_t, (size_t)nce + 1);
     PALLOC(cmap, uint32_t, (size_t)m + 1);
     if (m)
-      LAUNCH("comp_compact_fill", k_compact_fill, nblk(m), GTS_BLOCK, G, e->estart, incl, ipos,
+      LAUNCH("comp_compact_fill", k_compact_fill, nblk(m), GTS_BLOCK, G, e->estart, live, incl, ipos,
              slot_of, slot_base, coff, slot_comp, comp_wide, cstart, cend, cdist, cflags, cgpos,
              cstate, cmap);
     /* walk queue pool of the reference search */
@@ -1521,6 +1524,8 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cerr, uint32_t, ncomp);
     PALLOC(s_nd, int64_t, nslots); PALLOC(s_plen, uint64_t, nslots); PALLOC(s_tight, uint8_t, nslots);
     PALLOC(stat_fast, uint32_t, ncomp); PALLOC(stat_slow, uint32_t, ncomp);
+    PALLOC(stat_clean, uint32_t, ncomp);
+    PALLOC(s_gorient, uint8_t, nslots); PALLOC(s_topo, uint32_t, nslots); PALLOC(s_tpos, uint32_t, nslots);
     PALLOC(tstat, uint64_t, 5 * (size_t)ncomp);
     PALLOC(ok0, uint32_t, ncomp); PALLOC(ok1, uint32_t, ncomp);
     PALLOC(ov0, uint32_t, ncomp); PALLOC(ov1, uint32_t, ncomp);
@@ -1563,7 +1568,8 @@ static int run_components(GtsgEngine *e, int mode)
     C.wq_pool = wq_pool; C.wq_factor = (uint64_t)factor;
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
     C.fast_walks = (int)e->fast_walks; C.nd = s_nd; C.plen = s_plen; C.tight = s_tight;
-    C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat;
+    C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat; C.stat_clean = stat_clean;
+    C.gorient = s_gorient; C.topo = s_topo; C.tpos = s_tpos;
     C.why = (unsigned long long *)(e->d_scalars + 96);
     HIPCHK(hipMemsetAsync(C.why, 0, 64, e->st));
     {
@@ -1614,6 +1620,9 @@ static int run_components(GtsgEngine *e, int mode)
            (unsigned long long *)(e->d_scalars + 16));
     LAUNCH("comp_walk_stats", k_sum_u32, nblk(ncomp), GTS_BLOCK, stat_slow, ncomp,
            (unsigned long long *)(e->d_scalars + 18));
+    HIPCHK(hipMemsetAsync(e->d_scalars + 20, 0, 8, e->st));
+    LAUNCH("comp_walk_stats", k_sum_u32, nblk(ncomp), GTS_BLOCK, stat_clean, ncomp,
+           (unsigned long long *)(e->d_scalars + 20));
     HIPCHK(hipMemsetAsync(e->d_scalars + 32, 0, 64, e->st));
     LAUNCH("comp_walk_stats", k_tstat_reduce, nblk(ncomp), GTS_BLOCK, tstat, ncomp,
            (unsigned long long *)(e->d_scalars + 32));
@@ -1622,9 +1631,9 @@ static int run_components(GtsgEngine *e, int mode)
     uint64_t why[8];
     HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 64, hipMemcpyDeviceToHost, e->st));
     uint32_t res[3] = {0, 0, 0};
-    uint64_t wstat[2] = {0, 0};
+    uint64_t wstat[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 12, hipMemcpyDeviceToHost, e->st));
-    HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 16, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 24, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
     {
       static const char *nm[4] = {"removecycles", "makescaffold_other", "walks_fast", "walks_reference"};
@@ -1658,6 +1667,7 @@ static int run_components(GtsgEngine *e, int mode)
     }
     e->stats["fast_walks"] = (int64_t)wstat[0];
     e->stats["slow_walks"] = (int64_t)wstat[1];
+    e->stats["clean_components"] = (int64_t)wstat[2];
     e->stats["components"] = ncomp;
     e->stats["max_component"] = res[2];
     e->stats["compact_edges"] = nce;

@@ -71,7 +71,7 @@ def hostsim():
         L.hs_filter.argtypes = [C.c_uint32, C.c_uint32] + [vp] * 12 + [C.c_float, C.c_float, C.c_int64]
         L.hs_filter.restype = C.c_uint32
         L.hs_components.argtypes = [C.c_uint32, C.c_uint32] + [vp] * 8 + [C.c_int, C.c_uint32,
-                                                                         C.c_uint64, vp, vp, C.c_int, vp, vp]
+                                                                         C.c_uint64, vp, vp, C.c_int, vp, vp, vp]
         L.hs_components.restype = C.c_uint32
         _HS = L
     return _HS
@@ -107,13 +107,14 @@ class HostSimGraph:
         mc = C.c_uint32()
         nf = C.c_uint64()
         ns = C.c_uint64()
+        ncl = C.c_uint64()
         nerr = hostsim().hs_components(g["n"], g["m"], _p(g["row"]), _p(g["seq_len"]),
                                        _p(self.vstate), _p(g["end"]), _p(g["dist"]), _p(g["flags"]),
                                        _p(self.state), _p(g["twin"]), mode, wq_factor, max_pops,
                                        C.byref(nc), C.byref(mc), fast_walks, C.byref(nf),
-                                       C.byref(ns))
+                                       C.byref(ns), C.byref(ncl))
         self.ncomp, self.maxcomp = nc.value, mc.value
-        self.fast_walks, self.slow_walks = nf.value, ns.value
+        self.fast_walks, self.slow_walks, self.clean_components = nf.value, ns.value, ncl.value
         return nerr
 
     def removecycles(self, **kw):

@@ -129,7 +129,7 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
                        const uint32_t *twin, int mode, uint32_t wq_factor,
                        uint64_t max_pops, uint32_t *out_ncomp,
                        uint32_t *out_maxcomp, int fast_walks,
-                       uint64_t *out_fast, uint64_t *out_slow)
+                       uint64_t *out_fast, uint64_t *out_slow, uint64_t *out_clean)
 {
   GtsGraphView G = {n, m, row, seq_len, nullptr, nullptr, vstate, end, dist,
                     nullptr, flags, state, twin, nullptr};
@@ -194,7 +194,8 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
         cstart[k] = s - lab_first[label[v]]; cend[k] = slot_of[end[p]] - lab_first[label[v]];
         cdist[k] = dist[p];
         const bool uturn = ((flags[twin[p]] & GTS_F_SENSE) != 0) == gts_next_dir(flags[p]);
-        cflags[k] = (uint8_t)((flags[p] & 3u) | (uturn ? GTS_F_UTURN : 0u));
+        cflags[k] = (uint8_t)((flags[p] & 3u) | (uturn ? GTS_F_UTURN : 0u) |
+                              (live(twin[p]) ? GTS_F_TWINLIVE : 0u));
         cstate[k] = state[p]; cgpos[k] = p; cmap[p] = k; k++;
       }
   }
@@ -228,6 +229,8 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   C.fast_walks = fast_walks; C.nd = nd.data(); C.plen = plen.data(); C.tight = tight.data();
   std::vector<uint64_t> tstat(5 * (size_t)(ncomp ? ncomp : 1), 0);
   unsigned long long why[8] = {0};
+  std::vector<uint8_t> gorient(S); std::vector<uint32_t> topo(S), tpos(S), sclean(ncomp ? ncomp : 1, 0);
+  C.gorient = gorient.data(); C.topo = topo.data(); C.tpos = tpos.data(); C.stat_clean = sclean.data();
   C.stat_fast = sf.data(); C.stat_slow = ss.data(); C.tstat = tstat.data(); C.why = why;
   uint32_t nerr = 0;
   for (uint32_t c = 0; c < ncomp; c++) {
@@ -238,6 +241,9 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   }
   uint64_t tf = 0, ts = 0;
   for (uint32_t c = 0; c < ncomp; c++) { tf += sf[c]; ts += ss[c]; }
+  uint64_t ncl = 0;
+  for (uint32_t c = 0; c < ncomp; c++) ncl += sclean[c];
+  if (out_clean) *out_clean = ncl;
   if (out_fast) *out_fast = tf;
   if (out_slow) *out_slow = ts;
   if (out_ncomp) *out_ncomp = ncomp;

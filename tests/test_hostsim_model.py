@@ -72,6 +72,7 @@ def test_medium():
     out, hs = run_both(g)
     check(out)
     assert hs.ncomp > 100
+    assert hs.clean_components > hs.ncomp // 2      # whole-component analysis applies
 
 
 @pytest.mark.parametrize("fast", [0, 1])
