@@ -58,7 +58,7 @@ struct GtsCompView {
   const uint32_t *cstart;    /* compact edge -> start slot, component-local */
   const uint32_t *cend;      /* compact edge -> end slot, component-local */
   const int64_t *cdist;
-  const uint8_t *cflags;
+  uint8_t *cflags;
   const uint32_t *cgpos;     /* compact edge -> global position */
   uint8_t *cstate;           /* compact copy of the edge state */
   uint8_t *vst;              /* slot -> vertex state */
@@ -131,7 +131,7 @@ struct GtsCompMemT {
   GTS_P(const idx_t) cstart;
   GTS_P(const idx_t) cend;
   GTS_P(const dist_t) cdist;
-  GTS_P(const uint8_t) cflags;
+  GTS_P(uint8_t) cflags;       /* GTS_F_TWINLIVE is cleared when a twin dies */
   GTS_P(const seq_t) cseq;
   GTS_P(uint8_t) cstate;
   GTS_P(uint8_t) vst;
@@ -196,11 +196,12 @@ struct GtsComponent {
   uint32_t nfast, nslow;
   uint64_t tfast, tslow, npops;
   bool clean;           /* analyze() succeeded and nothing changed since */
+  bool reuse_cc;        /* makescaffold may use the ccs run() computed */
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -352,8 +353,14 @@ struct GtsComponent {
       C.G.state[p] = GIS_CYCLIC;
       C.G.state[t] = GIS_CYCLIC;
       const uint32_t cp = C.cmap[p], ct = C.cmap[t];
-      if (cp != GTS_NONE) M.cstate[cp - e0g] = GIS_CYCLIC;
-      if (ct != GTS_NONE) M.cstate[ct - e0g] = GIS_CYCLIC;
+      if (cp != GTS_NONE) {
+        M.cstate[cp - e0g] = GIS_CYCLIC;
+        M.cflags[cp - e0g] = (uint8_t)(M.cflags[cp - e0g] & ~GTS_F_TWINLIVE);
+      }
+      if (ct != GTS_NONE) {
+        M.cstate[ct - e0g] = GIS_CYCLIC;
+        M.cflags[ct - e0g] = (uint8_t)(M.cflags[ct - e0g] & ~GTS_F_TWINLIVE);
+      }
     }
     W::fence();
   }
@@ -1164,16 +1171,20 @@ struct GtsComponent {
       /* next reached vertices in sweep order */
       const int64_t mypos = forward ? pos + (int64_t)lane : pos - (int64_t)lane;
       uint32_t cv = 0;
-      bool reached = false;
-      if (mypos >= 0 && mypos < (int64_t)nv) {
-        cv = M.topo[(uint32_t)mypos];
-        reached = cv == start ? mypos == (int64_t)W::uni(M.tpos[start])
-                              : M.distmap[cv] != GTS_DIST_UNSET;
-      }
-      uint64_t rm = W::ballot(reached);
-      while (rm && !bad) {
+      const bool inrange = mypos >= 0 && mypos < (int64_t)nv;
+      if (inrange) cv = M.topo[(uint32_t)mypos];
+      /* a vertex handled in this chunk may label a later vertex of the same
+         chunk: look again after every vertex */
+      uint32_t next_lane = 0;
+      while (!bad) {
+        bool reached = false;
+        if (inrange && lane >= next_lane)
+          reached = cv == start ? next_lane == 0 && mypos == (int64_t)W::uni(M.tpos[start])
+                                : M.distmap[cv] != GTS_DIST_UNSET;
+        const uint64_t rm = W::ballot(reached);
+        if (!rm) break;
         const uint32_t l = W::ctz(rm);
-        rm &= rm - 1;
+        next_lane = l + 1;
         const uint32_t u = W::bcast(cv, l);
         --pending;
         const bool du = (W::uni((uint32_t)M.gorient[u]) == 2) == forward;
@@ -1276,7 +1287,7 @@ struct GtsComponent {
   GTS_HD void makescaffold()
   {
     const uint32_t lane = W::lane();
-    if (!clean) calc_cc();   /* clean: run() just computed the same ccs */
+    if (!reuse_cc) calc_cc();   /* else run() just computed the same ccs */
     for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }
     W::fence();
     auto ccoff = M.ccoff;
@@ -1330,6 +1341,7 @@ struct GtsComponent {
     const uint32_t lane = W::lane();
     const uint64_t t0 = W::clock();
     clean = C.fast_walks && nv > 1 && analyze();
+    reuse_cc = clean;
     if (clean) {
       /* removecycles = its terminal search: every DFS is futile (analyze) */
       calc_cc();
@@ -1337,8 +1349,14 @@ struct GtsComponent {
         for (uint32_t s = lane; s < nv; s += W::WIDTH)
           if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
       W::fence();
-    } else
+    } else {
       removecycles();
+      /* with its cycles cut out the component may be clean for the walks */
+      if (mode == GTS_MODE_MAKESCAFFOLD && C.fast_walks && nv > 1) {
+        clean = analyze();
+        reuse_cc = false;
+      }
+    }
     const uint64_t t1 = W::clock();
     const bool was_clean = clean;
     if (mode == GTS_MODE_MAKESCAFFOLD) makescaffold();
