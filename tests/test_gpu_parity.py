@@ -274,3 +274,41 @@ def test_sharded_pipeline_matches_unsharded_oracle(world):
             seen[(int(a), int(b))] = int(s)
     assert np.array_equal(vs, og.vertex_states())
     assert seen == want
+
+
+def test_self_loop_and_repeated_records():
+    """records whose two contigs coincide (ref parser.c:359-378 creates two edges
+    r -> r) and pairs listed many times with growing / equal / shrinking std_dev"""
+    g = make_inputs(1500, 77, p_chimeric=0.05)
+    rng = np.random.default_rng(5)
+    m = len(g["root"])
+    extra = 200
+    idx = rng.integers(0, m, extra)
+    g2 = {k: v.copy() for k, v in g.items()}
+    add = {k: g[k][idx].copy() for k in ("root", "ctg", "dist", "std_dev", "num_pairs", "flags")}
+    add["ctg"][:60] = add["root"][:60]                       # self loops
+    add["std_dev"][60:] = np.float32(rng.choice([0.5, 1.0, 50.0], extra - 60))   # ties and overrides
+    add["flags"][120:] = rng.integers(0, 4, extra - 120).astype(np.uint8)       # other geometry
+    pos = np.sort(rng.integers(0, m, extra))
+    for k in add:
+        g2[k] = np.insert(g[k], pos, add[k])
+    run_pipeline(g2)
+
+
+def test_ragged_inputs():
+    """most contigs without any record, one contig linked to everything"""
+    g = make_inputs(400, 9)
+    n = len(g["seq_len"])
+    hub = 7
+    others = np.array([v for v in range(n) if v != hub][:150], dtype=np.uint32)
+    k = len(others)
+    rng = np.random.default_rng(1)
+    rec = dict(root=np.full(k, hub, np.uint32), ctg=others,
+               dist=rng.integers(-90, 3000, k).astype(np.int64),
+               std_dev=(rng.random(k) * 20).astype(np.float32),
+               num_pairs=rng.integers(1, 50, k).astype(np.uint64),
+               flags=rng.integers(0, 4, k).astype(np.uint8))
+    for name in rec:
+        g[name] = rec[name]
+    g["astat"][hub] = 100.0; g["copy_num"][hub] = 1.0           # the hub is not a repeat
+    run_pipeline(g, hub_degree=16)
