@@ -85,6 +85,18 @@ struct GtsCompView {
   uint8_t *gorient;          /* slot -> strand + 1 of the whole-component analysis */
   uint32_t *topo, *tpos;     /* topological order of the forward sheet, inverse */
   uint32_t *stat_clean;      /* per component: 1 if the analysis succeeded */
+  /* walks of large clean components fan out: the component program emits one
+     task per terminal, k_walk_tasks runs every walk on its own wavefront,
+     the select pass keeps the best walk of every cc (gts_engine.hip) */
+  uint32_t defer_min_nv;     /* 0: never defer */
+  uint8_t *defer_flag;       /* ncomp */
+  uint32_t *comp_task0, *comp_ncc, *comp_nterm;   /* ncomp */
+  unsigned long long *ntasks, *path_used;         /* device counters */
+  uint64_t task_cap, path_cap;
+  uint32_t *task_comp, *task_start, *task_n;      /* task_cap */
+  uint8_t *task_skip;
+  uint64_t *task_len, *task_poff;
+  uint32_t *paths;           /* path_cap: walk edges (component-local) per task */
   uint32_t *stat_fast, *stat_slow;  /* per component: walks by path taken */
   unsigned long long *why;   /* [8] why walks left the linear path: mixed start,
                                 self arc, back at start, marked end, two
@@ -197,11 +209,12 @@ struct GtsComponent {
   uint64_t tfast, tslow, npops;
   bool clean;           /* analyze() succeeded and nothing changed since */
   bool reuse_cc;        /* makescaffold may use the ccs run() computed */
+  bool revivable;       /* analyze(): a marked edge with a live twin exists */
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), revivable(false) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -1060,6 +1073,7 @@ struct GtsComponent {
        sheet on the way */
     uint32_t qh2 = 0, qn2 = 1;
     bool bad = false;
+    revivable = false;
     Q[0] = 0;
     M.gorient[0] = 2;
     W::fence();
@@ -1070,7 +1084,7 @@ struct GtsComponent {
       const uint32_t eb = eoff(u), ee = eoff(u + 1);
       for (uint32_t base = eb; base < ee; base += W::WIDTH) {
         const uint32_t ce = base + lane;
-        bool have = false, fresh = false, clash = false, fwd = false;
+        bool have = false, fresh = false, clash = false, fwd = false, rv = false;
         uint32_t v = 0, ov = 0;
         if (ce < ee) {
           const uint32_t fl = M.cflags[ce];
@@ -1082,7 +1096,9 @@ struct GtsComponent {
           clash = (fl & GTS_F_UTURN) || v == u || (cur != 0 && cur != ov);
           fresh = cur == 0;
           fwd = sense == ou && (!gts_edge_is_marked(M.cstate[ce]) || (fl & GTS_F_TWINLIVE));
+          if (gts_edge_is_marked(M.cstate[ce]) && (fl & GTS_F_TWINLIVE)) rv = true;
         }
+        if (W::ballot(rv)) revivable = true;
         if (W::ballot(clash)) { bad = true; break; }
         const uint64_t fm = W::ballot(have && fresh);
         if (have && fresh) {
@@ -1336,6 +1352,128 @@ struct GtsComponent {
     }
   }
 
+
+  /* ---- fan-out of the walks of a large clean component --------------------
+     Without revivable twins a SCAFFOLD mark cannot change what any other walk
+     of the component sees, so all walks of all ccs are independent; only the
+     choice inside a cc follows the terminal order.  The component program
+     then stops after its terminal search and publishes one task per terminal
+     plus what the tasks need (terminal lists, strands, sweep order). */
+  GTS_HD bool try_defer()
+  {
+    const uint32_t lane = W::lane();
+    if (!C.defer_min_nv || nv < C.defer_min_nv || revivable || nterm < 2) return false;
+    const uint64_t t0 = W::alloc(C.ntasks, nterm);
+    if (t0 + nterm > C.task_cap) return false;
+    const uint64_t p0 = W::alloc(C.path_used, (uint64_t)nterm * nv);
+    if (p0 + (uint64_t)nterm * nv > C.path_cap) {   /* pool full: walk in place */
+      for (uint32_t j = lane; j < nterm; j += W::WIDTH) { C.task_comp[t0 + j] = c; C.task_skip[t0 + j] = 1; }
+      return false;
+    }
+    auto ccoff = M.ccoff;
+    /* a cc with one terminal: algorithms.c:790-807 */
+    for (uint32_t i = 0; i < ncc; ++i) {
+      const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
+      const bool skip = te - tb < 2;
+      if (te - tb == 1) {
+        const uint32_t v = W::uni(M.term[tb]);
+        const uint32_t eb = eoff(v), ee = eoff(v + 1);
+        bool any_live = false;
+        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+          const uint32_t ce = base + lane;
+          any_live |= W::ballot(ce < ee && !gts_edge_is_marked(M.cstate[ce])) != 0;
+        }
+        if (!any_live) M.vst[v] = GIS_SCAFFOLD;
+      }
+      for (uint32_t j = tb + lane; j < te; j += W::WIDTH) {
+        const uint64_t t = t0 + j;
+        C.task_comp[t] = c;
+        C.task_start[t] = M.term[j];
+        C.task_skip[t] = skip ? 1 : 0;
+        C.task_poff[t] = p0 + (uint64_t)j * nv;
+        C.task_len[t] = 0;
+        C.task_n[t] = 0;
+      }
+    }
+    /* what the tasks and the select pass read (no-op copies when M already
+       points into the global arrays) */
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) {
+      C.gorient[s0 + s] = M.gorient[s];
+      C.topo[s0 + s] = M.topo[s];
+      C.tpos[s0 + s] = M.tpos[s];
+      C.term[s0 + s] = M.term[s];
+    }
+    for (uint32_t i = lane; i <= ncc; i += W::WIDTH) C.ccoff[s0 + c + i] = ccoff[i];
+    /* marks of removecycles live in the working copy: publish them */
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) C.vst[s0 + s] = M.vst[s];
+    for (uint32_t k = lane; k < M.ne; k += W::WIDTH) {
+      C.cstate[e0g + k] = M.cstate[k];
+      C.cflags[e0g + k] = M.cflags[k];
+    }
+    if (lane == 0) {
+      C.defer_flag[c] = 1;
+      C.comp_task0[c] = (uint32_t)t0;
+      C.comp_ncc[c] = ncc;
+      C.comp_nterm[c] = nterm;
+    }
+    W::fence();
+    return true;
+  }
+
+  /* one deferred walk: the program object is constructed on a staged copy of
+     the component with gorient / topo / tpos loaded */
+  GTS_HD void walk_task(uint64_t t)
+  {
+    const uint32_t lane = W::lane();
+    clean = true;
+    uint64_t len = 0;
+    uint32_t n = 0;
+    create_walk(W::uni(C.task_start[t]), len, n);
+    const uint64_t po = C.task_poff[t];
+    for (uint32_t k = lane; k < n; k += W::WIDTH) C.paths[po + k] = M.cc_best[k];
+    if (lane == 0) {
+      C.task_len[t] = len;
+      C.task_n[t] = n;
+      if (err) C.cerr[c] = err;
+      if (nfast) W::count_n(C.stat_fast + c, nfast);
+      if (nslow) W::count_n(C.stat_slow + c, nslow);
+    }
+    W::fence();
+  }
+
+  /* keeps, for every cc of a deferred component, the first strictly longest
+     walk in terminal order (algorithms.c:823-832) and marks it
+     (algorithms.c:835-848).  Works on the global arrays only. */
+  static GTS_HD void select_walks(const GtsCompView &C, uint32_t c)
+  {
+    const uint32_t lane = W::lane();
+    const uint32_t s0 = C.comp_off[c], e0g = C.coff[s0];
+    const uint32_t ncc = C.comp_ncc[c], t0 = C.comp_task0[c];
+    const uint32_t *ccoff = C.ccoff + s0 + c;
+    for (uint32_t i = 0; i < ncc; ++i) {
+      const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
+      if (te - tb < 2) continue;
+      uint64_t best = 0;
+      uint32_t bj = GTS_NONE;
+      for (uint32_t j = tb; j < te; ++j) {
+        const uint64_t len = (uint64_t)W::uni64((int64_t)C.task_len[t0 + j]);
+        if (len > best) { best = len; bj = j; }
+      }
+      if (bj == GTS_NONE) continue;
+      const uint32_t n = W::uni(C.task_n[t0 + bj]);
+      const uint64_t po = C.task_poff[t0 + bj];
+      for (uint32_t k = lane; k < n; k += W::WIDTH) {
+        const uint32_t ce = C.paths[po + k];
+        const uint32_t p = C.cgpos[e0g + ce], t = C.G.twin[p];
+        C.G.state[p] = GIS_SCAFFOLD;
+        C.G.state[t] = GIS_SCAFFOLD;
+        C.G.vstate[C.slot_v[s0 + C.cend[e0g + ce]]] = GIS_SCAFFOLD;
+        C.G.vstate[C.slot_v[s0 + C.cstart[e0g + ce]]] = GIS_SCAFFOLD;
+      }
+    }
+    W::fence();
+  }
+
   GTS_HD void run(int mode)
   {
     const uint32_t lane = W::lane();
@@ -1359,7 +1497,14 @@ struct GtsComponent {
     }
     const uint64_t t1 = W::clock();
     const bool was_clean = clean;
-    if (mode == GTS_MODE_MAKESCAFFOLD) makescaffold();
+    bool deferred = false;
+    if (mode == GTS_MODE_MAKESCAFFOLD) {
+      if (clean) {
+        if (!reuse_cc) { calc_cc(); reuse_cc = true; }   /* makescaffold's terminal search */
+        deferred = try_defer();
+      }
+      if (!deferred) makescaffold();
+    }
     const uint64_t t2 = W::clock();
     for (uint32_t s = lane; s < nv; s += W::WIDTH) {
       const uint8_t st = M.vst[s];
@@ -1396,6 +1541,7 @@ struct GtsWave1 {
   static GTS_HD void fence() {}
   static GTS_HD uint64_t clock() { return 0; }
   static GTS_HD void count(unsigned long long *p) { ++*p; }
+  static GTS_HD void count_n(uint32_t *p, uint32_t n) { *p += n; }
   static GTS_HD uint64_t alloc(unsigned long long *used, uint64_t n)
   { const uint64_t o = *used; *used += n; return o; }
   static GTS_HD uint32_t clz32(uint32_t v) { uint32_t n = 0; while (n < 32 && !(v & (0x80000000u >> n))) ++n; return n; }

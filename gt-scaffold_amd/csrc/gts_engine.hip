@@ -71,6 +71,7 @@ struct GtsgEngine {
   /* options */
   int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
   int64_t walk_pool_entries = 1ll << 26;
+  int64_t defer_min_contigs = 96, walk_path_entries = 1ll << 25;
   int64_t fast_walks = 1, lds_components = 1;
   bool profile = false;
   /* profiling */
@@ -762,6 +763,7 @@ struct GtsWave64 {
   static __device__ __forceinline__ uint64_t clock() { return wall_clock64(); }
   static __device__ __forceinline__ void count(unsigned long long *p)
   { if (lane() == 0) atomicAdd(p, 1ull); }
+  static __device__ __forceinline__ void count_n(uint32_t *p, uint32_t n) { atomicAdd(p, n); }
   static __device__ __forceinline__ uint32_t clz32(uint32_t v) { return (uint32_t)__clz((int)v); }
   /* inclusive prefix sum of values < 128: one ballot per bit, the lower-lane
      population count of each ballot weighted by the bit */
@@ -805,6 +807,7 @@ k_components(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t coun
 {
   if (blockIdx.x >= count) return;
   const uint32_t c = order[first + blockIdx.x];
+  C.defer_min_nv = 0;   /* deferred walks are staged in LDS: not for this class */
   const GtsCompMem M = GtsComponent<GtsWave64>::global_mem(C, c);
   GtsComponent<GtsWave64> prog(C, M, c);
   prog.run(mode);
@@ -824,16 +827,14 @@ __device__ __forceinline__ T __attribute__((address_space(3))) *lds_carve(gts_ld
   p += ((count * (uint32_t)sizeof(T) + 15u) / 16u) * 16u;
   return r;
 }
-__global__ void __launch_bounds__(GTS_WAVE)
-k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode)
+/* stages component c into the workgroup's LDS (packed layout) and points M at
+   it; with_analysis also loads the strands / sweep order a deferred walk needs */
+__device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c, char *smem,
+                                                GtsCompMemT<true> &M, bool with_analysis)
 {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (blockIdx.x >= count) return;
-  const uint32_t c = order[first + blockIdx.x];
   const GtsCompMem G0 = GtsComponent<GtsWave64>::global_mem(C, c);
   const uint32_t nv = G0.nv, ne = G0.ne, lane = threadIdx.x;
   gts_lds_cursor p = (gts_lds_cursor)smem;
-  GtsCompMemT<true> M;
   typedef GtsCompMemT<true>::idx_t idx_t;
   M.nv = nv; M.ne = ne; M.e0 = 0;
   auto coff = lds_carve<idx_t>(p, nv + 1);
@@ -843,37 +844,73 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
   M.st_par = lds_carve<idx_t>(p, nv); M.st_cur = lds_carve<idx_t>(p, nv);
   M.edgemap = lds_carve<idx_t>(p, nv); M.wterm = lds_carve<idx_t>(p, nv);
   M.touched = lds_carve<idx_t>(p, nv); M.cc_best = lds_carve<idx_t>(p, nv);
+  M.topo = lds_carve<idx_t>(p, nv); M.tpos = lds_carve<idx_t>(p, nv);
   M.lastpop = lds_carve<uint32_t>(p, nv); M.distmap = lds_carve<float>(p, nv);
   auto cseq = lds_carve<int32_t>(p, nv);
   M.nd = lds_carve<int64_t>(p, nv); M.plen = lds_carve<uint64_t>(p, nv);
   M.vst = lds_carve<uint8_t>(p, nv); M.st_dir = lds_carve<uint8_t>(p, nv);
   M.tight = lds_carve<uint8_t>(p, nv); M.gorient = lds_carve<uint8_t>(p, nv);
-  M.topo = lds_carve<idx_t>(p, nv); M.tpos = lds_carve<idx_t>(p, nv);
   auto cstart = lds_carve<idx_t>(p, ne);
   auto cend = lds_carve<idx_t>(p, ne);
   auto cdist = lds_carve<int32_t>(p, ne);
-  auto cflags = lds_carve<uint8_t>(p, ne);
+  M.cflags = lds_carve<uint8_t>(p, ne);
   M.cstate = lds_carve<uint8_t>(p, ne);
   for (uint32_t i = lane; i <= nv; i += GTS_WAVE) coff[i] = (idx_t)(G0.coff[i] - G0.e0);
   for (uint32_t i = lane; i < nv; i += GTS_WAVE) {
     cseq[i] = (int32_t)G0.cseq[i]; M.vst[i] = G0.vst[i];
     M.lastpop[i] = 0; M.distmap[i] = GTS_DIST_UNSET; M.st_dir[i] = 0; M.tight[i] = 0;
+    if (with_analysis) {
+      M.gorient[i] = G0.gorient[i]; M.topo[i] = (idx_t)G0.topo[i]; M.tpos[i] = (idx_t)G0.tpos[i];
+    }
   }
   for (uint32_t i = lane; i < ne; i += GTS_WAVE) {
     cstart[i] = (idx_t)G0.cstart[i]; cend[i] = (idx_t)G0.cend[i]; cdist[i] = (int32_t)G0.cdist[i];
-    cflags[i] = G0.cflags[i]; M.cstate[i] = G0.cstate[i];
+    M.cflags[i] = G0.cflags[i]; M.cstate[i] = G0.cstate[i];
   }
   M.coff = coff; M.cseq = cseq; M.cstart = cstart; M.cend = cend; M.cdist = cdist;
-  M.cflags = cflags;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+__global__ void __launch_bounds__(GTS_WAVE)
+k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x >= count) return;
+  const uint32_t c = order[first + blockIdx.x];
+  GtsCompMemT<true> M;
+  stage_component(C, c, smem, M, false);
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.run(mode);
+}
+
+/* one deferred walk per workgroup (gts_component.hpp, try_defer / walk_task);
+   launched once per LDS size class, a workgroup whose task belongs to another
+   class leaves at once */
+__global__ void __launch_bounds__(GTS_WAVE)
+k_walk_tasks(GtsCompView C, const uint8_t *comp_klass, uint32_t klass, uint32_t ntasks)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t t = blockIdx.x;
+  if (t >= ntasks || C.task_skip[t]) return;
+  const uint32_t c = C.task_comp[t];
+  if (comp_klass[c] != klass) return;
+  GtsCompMemT<true> M;
+  stage_component(C, c, smem, M, true);
+  GtsComponent<GtsWave64, true> prog(C, M, c);
+  prog.walk_task(t);
+}
+__global__ void __launch_bounds__(GTS_WAVE)
+k_select_walks(GtsCompView C)
+{
+  const uint32_t c = blockIdx.x;
+  if (c >= C.ncomp || !C.defer_flag[c]) return;
+  GtsComponent<GtsWave64, false>::select_walks(C, c);
 }
 /* LDS footprint of every component as a descending sort key, and how many
    components fit each size class */
 __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 uint32_t *keys, uint32_t *vals, uint32_t ncomp,
-                                const uint8_t *comp_wide,
+                                const uint8_t *comp_wide, uint8_t *comp_klass,
                                 const uint32_t *klass, uint32_t nklass,
                                 uint32_t *klass_count, unsigned long long *klass_bytes)
 {
@@ -894,6 +931,7 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
     vals[c] = (uint32_t)c;
     uint32_t k = 0;
     while (k < nklass && need > klass[k]) ++k;   /* klass ascending; nklass = global */
+    comp_klass[c] = (uint8_t)k;
     atomicAdd(&s_cnt[k], 1u);
     /* bytes the component's program has to touch once: its compact graph and
        vertex records in, vertex states and edge marks out */
@@ -1031,6 +1069,10 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
       delete e; return GTSG_EHIP;
     }
   if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { delete e; return GTSG_EHIP; }
+  if (hipFuncSetAttribute((const void *)k_walk_tasks,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
+    delete e; return GTSG_EHIP;
+  }
   if (hipFuncSetAttribute((const void *)k_components_lds,
                           hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
     fprintf(stderr, "gtsg_create: cannot raise the dynamic LDS limit to 160 KiB\n");
@@ -1082,6 +1124,8 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "hub_degree") && value >= 1) e->hub_degree = value;
   else if (!strcmp(name, "fast_walks")) e->fast_walks = value != 0;
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
+  else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
+  else if (!strcmp(name, "walk_path_entries") && value >= 1) e->walk_path_entries = value;
   else if (!strcmp(name, "profile")) e->profile = value != 0;
   else return fail(e, GTSG_EINVAL, "unknown option %s", name);
   return 0;
@@ -1434,7 +1478,7 @@ static int run_components(GtsgEngine *e, int mode)
                        (gts_sort_tmp_elems(n) + 2 * gts_scan_tmp_elems((uint64_t)n + m)) * 8 +
                        (size_t)n + m + (16u << 20);
     /* upper bounds for phase B: slots <= n, compact edges <= m */
-    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64 + 8 + 16) + (size_t)m * (4 * 3 + 8 + 2) +
+    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64 + 8 + 16 + 48) + (size_t)e->walk_path_entries * 4 + (size_t)m * (4 * 3 + 8 + 2) +
                        (size_t)pool_entries * 12 + (size_t)n * 24 + (16u << 20);
     if (!e->pool || e->pool_cap < wsA + wsB) {
       if ((rc = pool_reserve(e, wsA + wsB))) return rc;
@@ -1525,6 +1569,15 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(s_nd, int64_t, nslots); PALLOC(s_plen, uint64_t, nslots); PALLOC(s_tight, uint8_t, nslots);
     PALLOC(stat_fast, uint32_t, ncomp); PALLOC(stat_slow, uint32_t, ncomp);
     PALLOC(stat_clean, uint32_t, ncomp);
+    PALLOC(comp_klass, uint8_t, (size_t)ncomp + 1); PALLOC(defer_flag, uint8_t, (size_t)ncomp + 1);
+    PALLOC(comp_task0, uint32_t, ncomp); PALLOC(comp_ncc, uint32_t, ncomp); PALLOC(comp_nterm, uint32_t, ncomp);
+    const uint64_t task_cap = nslots, path_cap = (uint64_t)e->walk_path_entries;
+    PALLOC(task_comp, uint32_t, task_cap); PALLOC(task_start, uint32_t, task_cap);
+    PALLOC(task_n, uint32_t, task_cap); PALLOC(task_skip, uint8_t, task_cap);
+    PALLOC(task_len, uint64_t, task_cap); PALLOC(task_poff, uint64_t, task_cap);
+    PALLOC(task_paths, uint32_t, path_cap + 1);
+    HIPCHK(hipMemsetAsync(defer_flag, 0, (size_t)ncomp + 1, e->st));
+    HIPCHK(hipMemsetAsync(e->d_scalars + 128, 0, 16, e->st));
     PALLOC(s_gorient, uint8_t, nslots); PALLOC(s_topo, uint32_t, nslots); PALLOC(s_tpos, uint32_t, nslots);
     PALLOC(tstat, uint64_t, 5 * (size_t)ncomp);
     PALLOC(ok0, uint32_t, ncomp); PALLOC(ok1, uint32_t, ncomp);
@@ -1541,7 +1594,7 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemsetAsync(klass_count, 0, (GTS_NKLASS + 1) * 4, e->st));
     HIPCHK(hipMemsetAsync(e->d_scalars + 112, 0, (GTS_NKLASS + 1) * 8, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
-           ncomp, comp_wide, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
+           ncomp, comp_wide, comp_klass, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
            (unsigned long long *)(e->d_scalars + 112));
     const uint32_t *order;
     {
@@ -1570,6 +1623,12 @@ static int run_components(GtsgEngine *e, int mode)
     C.fast_walks = (int)e->fast_walks; C.nd = s_nd; C.plen = s_plen; C.tight = s_tight;
     C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat; C.stat_clean = stat_clean;
     C.gorient = s_gorient; C.topo = s_topo; C.tpos = s_tpos;
+    C.defer_min_nv = mode == GTS_MODE_MAKESCAFFOLD && e->lds_components ? (uint32_t)e->defer_min_contigs : 0u;
+    C.defer_flag = defer_flag; C.comp_task0 = comp_task0; C.comp_ncc = comp_ncc; C.comp_nterm = comp_nterm;
+    C.ntasks = (unsigned long long *)(e->d_scalars + 128); C.path_used = (unsigned long long *)(e->d_scalars + 130);
+    C.task_cap = task_cap; C.path_cap = path_cap;
+    C.task_comp = task_comp; C.task_start = task_start; C.task_n = task_n; C.task_skip = task_skip;
+    C.task_len = task_len; C.task_poff = task_poff; C.paths = task_paths;
     C.why = (unsigned long long *)(e->d_scalars + 96);
     HIPCHK(hipMemsetAsync(C.why, 0, 64, e->st));
     {
@@ -1608,6 +1667,28 @@ static int run_components(GtsgEngine *e, int mode)
         e->stats[std::string("components_lds_class") + char('0' + k)] = kcount[k];
         first += kcount[k];
       }
+      /* deferred walks: one task per terminal of the large clean components */
+      uint64_t ntasks = 0;
+      if (C.defer_min_nv) {
+        if ((rc = read_u64(e, (uint64_t *)(e->d_scalars + 128), &ntasks))) return rc;
+        if (ntasks > task_cap) ntasks = task_cap;
+        if (ntasks) {
+          HIPCHK(hipEventRecord(e->ev_fork, e->st));
+          for (int k = (int)nk - 1; k >= 0; --k) {
+            if (!kcount[k]) continue;
+            hipStream_t ss = e->side[k];
+            HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
+            hipEvent_t _a = nullptr, _b = nullptr;
+            if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
+            k_walk_tasks<<<(uint32_t)ntasks, GTS_WAVE, klass_h[k], ss>>>(C, comp_klass, (uint32_t)k, (uint32_t)ntasks);
+            if (e->profile) { hipEventRecord(_b, ss); e->pending.push_back({"components_walk_tasks", _a, _b}); }
+            HIPCHK(hipEventRecord(e->ev_join[k], ss));
+            HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
+          }
+          LAUNCH("components_select_walks", k_select_walks, ncomp, GTS_WAVE, C);
+        }
+      }
+      e->stats["walk_tasks"] = (int64_t)ntasks;
       e->stats["components_global_mem"] = kcount[nk];
       e->stats["bytes_components_global_mem"] = (int64_t)kbytes[nk];
       for (uint32_t k = 0; k < nk; ++k)

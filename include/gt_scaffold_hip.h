@@ -129,7 +129,9 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      "hub_degree" (default 32), "profile" (0/1),
      "fast_walks" (default 1; 0 forces the reference's label-correcting search
      for every walk), "lds_components" (default 1; 0 runs every component
-     from global memory) */
+     from global memory), "defer_min_contigs" (default 96; clean components
+     with at least that many contigs hand their walks to one task per terminal,
+     0 = never), "walk_path_entries" (default 2^25, pool for the tasks' walks) */
 
 /* per-kernel timing collected with hipEvents on the engine's stream while
    option "profile" is 1.  Fills up to cap entries, returns the number of
@@ -143,7 +145,8 @@ int gtsg_get_kernel_times(GtsgEngine *e, GtsgKernelTime *out, int cap);
 void gtsg_reset_kernel_times(GtsgEngine *e);
 /* counters of the last calls: "filter_rounds_p", "filter_rounds_i",
    "components", "max_component", "slots", "compact_edges", "hubs",
-   "walk_retries", "fast_walks", "slow_walks" */
+   "walk_retries", "fast_walks", "slow_walks", "clean_components",
+   "walk_tasks" */
 int64_t gtsg_get_stat(const GtsgEngine *e, const char *name);
 
 #ifdef __cplusplus

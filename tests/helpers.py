@@ -71,7 +71,7 @@ def hostsim():
         L.hs_filter.argtypes = [C.c_uint32, C.c_uint32] + [vp] * 12 + [C.c_float, C.c_float, C.c_int64]
         L.hs_filter.restype = C.c_uint32
         L.hs_components.argtypes = [C.c_uint32, C.c_uint32] + [vp] * 8 + [C.c_int, C.c_uint32,
-                                                                         C.c_uint64, vp, vp, C.c_int, vp, vp, vp]
+                                                                         C.c_uint64, vp, vp, C.c_int, vp, vp, vp, C.c_uint32, vp]
         L.hs_components.restype = C.c_uint32
         _HS = L
     return _HS
@@ -101,20 +101,22 @@ class HostSimGraph:
                                 _p(g["eid"]), pcutoff, cncutoff, ocutoff)
         self.rounds = (r >> 16, r & 0xFFFF)
 
-    def _components(self, mode, wq_factor=8, max_pops=1 << 40, fast_walks=1):
+    def _components(self, mode, wq_factor=8, max_pops=1 << 40, fast_walks=1, defer_min_nv=0):
         g = self.g
         nc = C.c_uint32()
         mc = C.c_uint32()
         nf = C.c_uint64()
         ns = C.c_uint64()
         ncl = C.c_uint64()
+        ndf = C.c_uint64()
         nerr = hostsim().hs_components(g["n"], g["m"], _p(g["row"]), _p(g["seq_len"]),
                                        _p(self.vstate), _p(g["end"]), _p(g["dist"]), _p(g["flags"]),
                                        _p(self.state), _p(g["twin"]), mode, wq_factor, max_pops,
                                        C.byref(nc), C.byref(mc), fast_walks, C.byref(nf),
-                                       C.byref(ns), C.byref(ncl))
+                                       C.byref(ns), C.byref(ncl), defer_min_nv, C.byref(ndf))
         self.ncomp, self.maxcomp = nc.value, mc.value
         self.fast_walks, self.slow_walks, self.clean_components = nf.value, ns.value, ncl.value
+        self.deferred_components = ndf.value
         return nerr
 
     def removecycles(self, **kw):

@@ -129,7 +129,8 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
                        const uint32_t *twin, int mode, uint32_t wq_factor,
                        uint64_t max_pops, uint32_t *out_ncomp,
                        uint32_t *out_maxcomp, int fast_walks,
-                       uint64_t *out_fast, uint64_t *out_slow, uint64_t *out_clean)
+                       uint64_t *out_fast, uint64_t *out_slow, uint64_t *out_clean,
+                       uint32_t defer_min_nv, uint64_t *out_deferred)
 {
   GtsGraphView G = {n, m, row, seq_len, nullptr, nullptr, vstate, end, dist,
                     nullptr, flags, state, twin, nullptr};
@@ -232,13 +233,43 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   std::vector<uint8_t> gorient(S); std::vector<uint32_t> topo(S), tpos(S), sclean(ncomp ? ncomp : 1, 0);
   C.gorient = gorient.data(); C.topo = topo.data(); C.tpos = tpos.data(); C.stat_clean = sclean.data();
   C.stat_fast = sf.data(); C.stat_slow = ss.data(); C.tstat = tstat.data(); C.why = why;
+  /* deferred walks (as the engine's k_walk_tasks / k_select_walks) */
+  std::vector<uint8_t> defer_flag(ncomp ? ncomp : 1, 0), task_skip(S, 0);
+  std::vector<uint32_t> comp_task0(ncomp ? ncomp : 1, 0), comp_ncc(ncomp ? ncomp : 1, 0),
+      comp_nterm(ncomp ? ncomp : 1, 0), task_comp(S), task_start(S), task_n(S);
+  std::vector<uint64_t> task_len(S), task_poff(S);
+  uint64_t path_cap = 1;
+  for (uint32_t c = 0; c < ncomp; c++) {
+    const uint64_t k = comp_off[c + 1] - comp_off[c];
+    path_cap += k * k;
+  }
+  std::vector<uint32_t> paths(path_cap);
+  unsigned long long ntasks = 0, path_used = 0;
+  C.defer_min_nv = defer_min_nv; C.defer_flag = defer_flag.data();
+  C.comp_task0 = comp_task0.data(); C.comp_ncc = comp_ncc.data(); C.comp_nterm = comp_nterm.data();
+  C.ntasks = &ntasks; C.path_used = &path_used; C.task_cap = S; C.path_cap = path_cap;
+  C.task_comp = task_comp.data(); C.task_start = task_start.data(); C.task_n = task_n.data();
+  C.task_skip = task_skip.data(); C.task_len = task_len.data(); C.task_poff = task_poff.data();
+  C.paths = paths.data();
   uint32_t nerr = 0;
   for (uint32_t c = 0; c < ncomp; c++) {
     GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
     GtsComponent<GtsWave1> prog(C, mem, c);
     prog.run(mode);
+  }
+  for (uint64_t t = 0; t < ntasks; t++) {
+    if (task_skip[t]) continue;
+    const uint32_t c = task_comp[t];
+    GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
+    GtsComponent<GtsWave1> prog(C, mem, c);
+    prog.walk_task(t);
+  }
+  uint64_t ndefer = 0;
+  for (uint32_t c = 0; c < ncomp; c++) {
+    if (defer_flag[c]) { GtsComponent<GtsWave1>::select_walks(C, c); ndefer++; }
     if (cerr[c]) nerr++;
   }
+  if (out_deferred) *out_deferred = ndefer;
   uint64_t tf = 0, ts = 0;
   for (uint32_t c = 0; c < ncomp; c++) { tf += sf[c]; ts += ss[c]; }
   uint64_t ncl = 0;

@@ -128,6 +128,23 @@ def test_misjoin_heavy_graphs_need_no_reference_search(seed):
     assert eng.stat("slow_walks") == 0 and eng.stat("fast_walks") > 0
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_deferred_walk_tasks(seed):
+    """large clean components fan their walks out to one workgroup per
+    terminal; same scaffolds as walking in place"""
+    kw = dict(p_chimeric=0.08, p_inversion=0.0, p_bubble=0.05, links_per_side=4,
+              unique_pairs=True) if seed else dict(p_chimeric=0.03)
+    g = make_inputs(8000, 1200 + seed, **kw)
+    eng, _ = run_pipeline(g, defer_min_contigs=3)
+    assert eng.stat("walk_tasks") > 0
+    eng0, _ = run_pipeline(g, defer_min_contigs=0)
+    assert eng0.stat("walk_tasks") == 0
+    assert eng.digest() == eng0.digest()
+    # a pool too small for any component: every component walks in place
+    eng1, _ = run_pipeline(g, defer_min_contigs=3, walk_path_entries=1)
+    assert eng1.digest() == eng0.digest()
+
+
 def test_fast_walks_resolve_ties():
     g = make_inputs(3000, 21, dist_range_small=True, contig_median=300)
     eng, _ = run_pipeline(g)
