@@ -1353,16 +1353,26 @@ struct GtsComponent {
   }
 
 
-  /* ---- fan-out of the walks of a large clean component --------------------
-     Without revivable twins a SCAFFOLD mark cannot change what any other walk
-     of the component sees, so all walks of all ccs are independent; only the
+  /* ---- fan-out of the walks of a large component -------------------------
+     SCAFFOLD is an unmarked state, so marking a walk changes what another
+     walk sees only when it revives a marked twin.  Without revivable twins
+     all walks of all ccs are independent (the terminals of every cc are
+     found before the first walk, algorithms.c:784); only the
      choice inside a cc follows the terminal order.  The component program
      then stops after its terminal search and publishes one task per terminal
      plus what the tasks need (terminal lists, strands, sweep order). */
   GTS_HD bool try_defer()
   {
     const uint32_t lane = W::lane();
-    if (!C.defer_min_nv || nv < C.defer_min_nv || revivable || nterm < 2) return false;
+    if (!C.defer_min_nv || nv < C.defer_min_nv || nterm < 2) return false;
+    /* a marked edge with a live twin (analyze may have stopped before seeing it) */
+    bool rv = false;
+    for (uint32_t base = 0; base < M.ne && !rv; base += W::WIDTH) {
+      const uint32_t ce = base + lane;
+      rv = W::ballot(ce < M.ne && (M.cflags[ce] & GTS_F_TWINLIVE) &&
+                     gts_edge_is_marked(M.cstate[ce])) != 0;
+    }
+    if (rv) return false;
     const uint64_t t0 = W::alloc(C.ntasks, nterm);
     if (t0 + nterm > C.task_cap) return false;
     const uint64_t p0 = W::alloc(C.path_used, (uint64_t)nterm * nv);
@@ -1411,7 +1421,7 @@ struct GtsComponent {
       C.cflags[e0g + k] = M.cflags[k];
     }
     if (lane == 0) {
-      C.defer_flag[c] = 1;
+      C.defer_flag[c] = clean ? 2 : 1;
       C.comp_task0[c] = (uint32_t)t0;
       C.comp_ncc[c] = ncc;
       C.comp_nterm[c] = nterm;
@@ -1425,7 +1435,7 @@ struct GtsComponent {
   GTS_HD void walk_task(uint64_t t)
   {
     const uint32_t lane = W::lane();
-    clean = true;
+    clean = W::uni((uint32_t)C.defer_flag[c]) == 2;
     uint64_t len = 0;
     uint32_t n = 0;
     create_walk(W::uni(C.task_start[t]), len, n);
@@ -1499,7 +1509,7 @@ struct GtsComponent {
     const bool was_clean = clean;
     bool deferred = false;
     if (mode == GTS_MODE_MAKESCAFFOLD) {
-      if (clean) {
+      if (C.defer_min_nv && nv >= C.defer_min_nv) {
         if (!reuse_cc) { calc_cc(); reuse_cc = true; }   /* makescaffold's terminal search */
         deferred = try_defer();
       }

@@ -129,14 +129,18 @@ def test_cyclic_state_graphs_take_the_queue_relaxation_path(seed):
 
 @pytest.mark.parametrize("seed", range(5))
 def test_deferred_walks_give_the_same_scaffolds(seed):
-    # large clean components hand their walks to separate tasks (one per terminal)
-    # and a select pass; force it for every component with at least 2 vertices
-    g = make_inputs(3000, 700 + seed, p_chimeric=0.05, p_inversion=0.3 * (seed % 2), p_bubble=0.04)
+    # large components without revivable twins hand their walks to separate tasks
+    # (one per terminal) and a select pass; force it for every component with at
+    # least 2 vertices, clean or not (odd seeds: inversions, relisted pairs)
+    g = make_inputs(3000, 700 + seed, p_chimeric=0.05, p_inversion=1.0 * (seed % 2), p_bubble=0.04,
+                    p_relist=0.05 * (seed % 2))
     og = oracle_from_inputs(g)
     hs = HostSimGraph(csr_from_oracle(og))
     og.mark_repeats(); hs.mark_repeats(); og.filter(); hs.filter()
     og.makescaffold(True)
     assert hs.makescaffold(fast_walks=1, defer_min_nv=2) == 0
     assert hs.deferred_components > 10
+    if seed == 1:
+        assert hs.slow_walks > 0   # tasks that fall back to the reference search
     assert np.array_equal(og.vertex_states(), hs.vertex_states())
     assert np.array_equal(og.edge_states(), hs.edge_states())
