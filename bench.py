@@ -245,6 +245,11 @@ def main():
     if rank == 0:
         n, m = eng.nv, eng.ne
         kt = eng.kernel_times()
+        if not args.no_profile and args.mode == "shards":
+            # one more, untimed, step that also copies the per-component clocks back
+            eng.set_option("profile", 2)
+            step()
+            eng.set_option("profile", 1)
         if not kt:
             kt = {"(profiling off)": (1, 0.0)}
         dom = max(kt.items(), key=lambda kv: kv[1][1])
@@ -293,9 +298,13 @@ def main():
                                                   "why_marked_end", "why_two_directions",
                                                   "why_inexact_tie", "why_cycle",
                                                   "why_inexact_length_tie")},
-                       slowest_reference_components=[
-                           {k: eng.stat("top%d_%s" % (r, k)) for k in ("size", "ref_walks", "ref_us", "ref_pops")}
-                           for r in range(3)]),
+                       walk_tasks=eng.stat("walk_tasks"),
+                       deferred_components=eng.stat("deferred_components"),
+                       slowest_components=[
+                           {k: eng.stat("top%d_%s" % (r, k)) for k in
+                            ("size", "edges", "terminals", "clean", "deferred", "why_not_deferred", "walks",
+                             "ref_walks", "removecycles_us", "other_us", "walks_us", "ref_us", "ref_pops")}
+                           for r in range(12)]),
                    kernels_ms_per_step={k: round(v[1] / args.steps, 3) for k, v in
                                         sorted(kt.items(), key=lambda kv: -kv[1][1])})
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only

@@ -84,7 +84,8 @@ struct GtsCompView {
   uint8_t *tight;            /* slot -> number of tight in-arcs (saturating) */
   uint8_t *gorient;          /* slot -> strand + 1 of the whole-component analysis */
   uint32_t *topo, *tpos;     /* topological order of the forward sheet, inverse */
-  uint32_t *stat_clean;      /* per component: 1 if the analysis succeeded */
+  uint32_t *stat_clean;      /* per component: bit0 the analysis succeeded, bit1 walks deferred,
+                                bits2-3 why not (1 revivable twin, 2 one terminal, 3 pool full), nterm << 8 */
   /* walks of large clean components fan out: the component program emits one
      task per terminal, k_walk_tasks runs every walk on its own wavefront,
      the select pass keeps the best walk of every cc (gts_engine.hip) */
@@ -164,7 +165,7 @@ struct GtsCompMemT {
   GTS_P(float) distmap;
   GTS_P(int64_t) nd;
   GTS_P(uint64_t) plen;
-  /* whole-component analysis (analyze): strand of every vertex + 1, a
+  /* whole-component analysis (orient + peel): strand of every vertex + 1, a
      topological order of the forward sheet and its inverse */
   GTS_P(uint8_t) gorient;
   GTS_P(idx_t) topo;
@@ -207,14 +208,14 @@ struct GtsComponent {
   uint32_t ntouch;
   uint32_t nfast, nslow;
   uint64_t tfast, tslow, npops;
-  bool clean;           /* analyze() succeeded and nothing changed since */
+  bool clean;           /* oriented, D acyclic (orient + peel) and nothing changed since */
   bool reuse_cc;        /* makescaffold may use the ccs run() computed */
-  bool revivable;       /* analyze(): a marked edge with a live twin exists */
+  uint32_t nodefer;     /* statistics: why try_defer declined */
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), revivable(false) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -378,14 +379,24 @@ struct GtsComponent {
     W::fence();
   }
 
-  /* ---- ref algorithms.c:495-578 ---- */
-  GTS_HD void removecycles()
+  /* ---- ref algorithms.c:495-578 ----
+     keep_cc: the caller goes on with makescaffold, whose terminal search
+     (algorithms.c:784) would repeat the one of the last pass.
+     With strands assigned (orient) a DFS that starts where no cycle of D can
+     be reached is futile -- it marks nothing and restores every state it
+     touched (algorithms.c:551-554) -- and is skipped; D is peeled again after
+     every mark.  Once D is acyclic the pass ends there and the component is
+     clean for the walks (topo / tpos are those of the last peeling). */
+  GTS_HD void removecycles(bool keep_cc)
   {
     const uint32_t lane = W::lane();
+    const bool oriented = C.fast_walks && nv > 1 && orient();
     bool found = true;
+    clean = false;
     while (found) {
       found = false;
       calc_cc();
+      if (oriented && peel()) { clean = true; break; }
       for (uint32_t s = lane; s < nv; s += W::WIDTH)
         if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
       W::fence();
@@ -411,6 +422,11 @@ struct GtsComponent {
         }
         if (!set_dir) continue;
         if (gts_vertex_is_marked((uint8_t)W::uni(M.vst[start]))) continue;
+        if (oriented) {
+          const uint32_t g = W::uni((uint32_t)M.gorient[start]);
+          const bool forward = dir == ((g & 3u) == 2);
+          if (!(g & (forward ? 8u : 4u))) continue;   /* no cycle ahead */
+        }
         uint32_t nvis = 0;
         const uint32_t back = detect_cycle(start, dir, nvis);
         for (uint32_t k = lane; k < nvis; k += W::WIDTH)
@@ -421,8 +437,16 @@ struct GtsComponent {
           const uint32_t a = W::uni(M.cstart[back]), b = W::uni(M.cend[back]);
           mark_vertex_cyclic(a);
           mark_vertex_cyclic(b);
+          if (oriented) peel();
         }
       }
+    }
+    /* clean exit: the states are those of calc_cc; the reference ends with
+       every unmarked vertex UNVISITED (algorithms.c:513-517, 551-554) */
+    if (clean && !keep_cc) {
+      for (uint32_t s = lane; s < nv; s += W::WIDTH)
+        if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
+      W::fence();
     }
   }
 
@@ -1062,18 +1086,16 @@ struct GtsComponent {
          is), swept upwards on the forward sheet and downwards on the mirror.
      The analysis costs two passes over the component; the result is dropped
      as soon as a SCAFFOLD mark revives a marked twin (new arcs). */
-  GTS_HD bool analyze()
+  /* strands by a search over all compact edges, whatever their state.  False
+     on a contradiction, a u-turn arc or a self loop. */
+  GTS_HD bool orient()
   {
     const uint32_t lane = W::lane();
     auto Q = M.queue;
-    auto indeg = M.st_v;
-    for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.gorient[s] = 0; indeg[s] = 0; }
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) M.gorient[s] = 0;
     W::fence();
-    /* strands by a search over all compact edges, in-degrees of the forward
-       sheet on the way */
     uint32_t qh2 = 0, qn2 = 1;
     bool bad = false;
-    revivable = false;
     Q[0] = 0;
     M.gorient[0] = 2;
     W::fence();
@@ -1084,74 +1106,103 @@ struct GtsComponent {
       const uint32_t eb = eoff(u), ee = eoff(u + 1);
       for (uint32_t base = eb; base < ee; base += W::WIDTH) {
         const uint32_t ce = base + lane;
-        bool have = false, fresh = false, clash = false, fwd = false, rv = false;
+        bool fresh = false, clash = false;
         uint32_t v = 0, ov = 0;
         if (ce < ee) {
           const uint32_t fl = M.cflags[ce];
           const bool sense = (fl & GTS_F_SENSE) != 0;
-          have = true;
           v = M.cend[ce];
           ov = (gts_next_dir((uint8_t)fl) != (sense != ou)) ? 2u : 1u;
           const uint32_t cur = M.gorient[v];
           clash = (fl & GTS_F_UTURN) || v == u || (cur != 0 && cur != ov);
           fresh = cur == 0;
-          fwd = sense == ou && (!gts_edge_is_marked(M.cstate[ce]) || (fl & GTS_F_TWINLIVE));
-          if (gts_edge_is_marked(M.cstate[ce]) && (fl & GTS_F_TWINLIVE)) rv = true;
         }
-        if (W::ballot(rv)) revivable = true;
         if (W::ballot(clash)) { bad = true; break; }
-        const uint64_t fm = W::ballot(have && fresh);
-        if (have && fresh) {
+        const uint64_t fm = W::ballot(fresh);
+        if (fresh) {
           M.gorient[v] = (uint8_t)ov;
           Q[qn2 + W::popc_below(fm, lane)] = v;
         }
-        if (fwd) indeg[v] = indeg[v] + 1;
         qn2 += W::popc(fm);
         W::fence();
       }
     }
-    if (bad || qn2 != nv) return false;
-    /* topological order of the forward sheet: topo[] is the peeling queue */
-    uint32_t th = 0, tn = 0;
-    for (uint32_t base = 0; base < nv; base += W::WIDTH) {
-      const uint32_t v = base + lane;
-      const bool src = v < nv && indeg[v] == 0;
-      const uint64_t sm = W::ballot(src);
-      if (src) M.topo[tn + W::popc_below(sm, lane)] = v;
-      tn += W::popc(sm);
-    }
-    W::fence();
-    while (th < tn) {
-      const uint32_t u = W::uni(M.topo[th]);
-      M.tpos[u] = th;
-      ++th;
-      const bool ou = W::uni((uint32_t)M.gorient[u]) == 2;
-      const uint32_t eb = eoff(u), ee = eoff(u + 1);
-      for (uint32_t base = eb; base < ee; base += W::WIDTH) {
-        const uint32_t ce = base + lane;
-        bool ready = false;
-        uint32_t v = 0;
-        if (ce < ee) {
-          const uint32_t fl = M.cflags[ce];
-          if (((fl & GTS_F_SENSE) != 0) == ou &&
-              (!gts_edge_is_marked(M.cstate[ce]) || (fl & GTS_F_TWINLIVE))) {
+    return !bad && qn2 == nv;
+  }
+
+  /* arc of D seen from its tail x (forward) or from its head (!forward) */
+  GTS_HD bool d_arc(uint32_t ce, bool ox, bool forward) const
+  {
+    const uint32_t fl = M.cflags[ce];
+    return (((fl & GTS_F_SENSE) != 0) == ox) == forward &&
+           (!gts_edge_is_marked(M.cstate[ce]) || (fl & GTS_F_TWINLIVE));
+  }
+
+  /* Topological order of D for an oriented component (topo / tpos); true if
+     D is acyclic.  Otherwise gorient gets, next to the strand, bit 2 for the
+     vertices some cycle of D reaches (left over by the peeling of sources)
+     and bit 3 for those that reach a cycle (left over by the peeling of
+     sinks): a traversal on the forward sheet can close a cycle only from a
+     vertex with bit 3, one on the mirror sheet only from a vertex with bit 2. */
+  GTS_HD bool peel()
+  {
+    const uint32_t lane = W::lane();
+    auto deg = M.st_v;
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool fwd = pass == 0;     /* pass 0 peels sources, pass 1 sinks */
+      const uint32_t bit = fwd ? 4u : 8u;
+      auto Qp = M.topo;
+      if (!fwd) Qp = M.visited;
+      for (uint32_t s = lane; s < nv; s += W::WIDTH) {
+        const bool os = (M.gorient[s] & 3u) == 2;
+        uint32_t d = 0;
+        const uint32_t le = M.coff[s + 1] - M.e0;
+        for (uint32_t ce = M.coff[s] - M.e0; ce < le; ++ce)
+          d += d_arc(ce, os, !fwd) ? 1u : 0u;   /* in-arcs when peeling sources */
+        deg[s] = d;
+        M.gorient[s] = (uint8_t)((M.gorient[s] & (fwd ? 3u : 7u)) | bit);
+      }
+      W::fence();
+      uint32_t th = 0, tn = 0;
+      for (uint32_t base = 0; base < nv; base += W::WIDTH) {
+        const uint32_t v = base + lane;
+        const bool src = v < nv && deg[v] == 0;
+        const uint64_t sm = W::ballot(src);
+        if (src) Qp[tn + W::popc_below(sm, lane)] = v;
+        tn += W::popc(sm);
+      }
+      W::fence();
+      while (th < tn) {
+        const uint32_t u = W::uni(Qp[th]);
+        if (fwd) M.tpos[u] = th;
+        ++th;
+        const uint32_t gu = W::uni((uint32_t)M.gorient[u]);
+        M.gorient[u] = (uint8_t)(gu & ~bit);
+        const bool ou = (gu & 3u) == 2;
+        const uint32_t eb = eoff(u), ee = eoff(u + 1);
+        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+          const uint32_t ce = base + lane;
+          bool ready = false;
+          uint32_t v = 0;
+          if (ce < ee && d_arc(ce, ou, fwd)) {   /* out-arcs when peeling sources */
             v = M.cend[ce];
-            const uint32_t d = indeg[v] - 1;
-            indeg[v] = d;
+            const uint32_t d = deg[v] - 1;
+            deg[v] = d;
             ready = d == 0;
           }
+          const uint64_t rm = W::ballot(ready);
+          if (ready) Qp[tn + W::popc_below(rm, lane)] = v;
+          tn += W::popc(rm);
+          W::fence();
         }
-        const uint64_t rm = W::ballot(ready);
-        if (ready) M.topo[tn + W::popc_below(rm, lane)] = v;
-        tn += W::popc(rm);
-        W::fence();
       }
+      if (fwd && tn == nv) return true;   /* acyclic: flags all cleared */
     }
-    return tn == nv;
+    return false;
   }
 
   /* create_walk on a clean component: one sweep over the precomputed order
-     (see analyze and create_walk_fast for why the result is the reference's) */
+     (see orient / peel and create_walk_fast for why the result is the reference's) */
   GTS_HD bool create_walk_clean(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t lane = W::lane();
@@ -1174,7 +1225,7 @@ struct GtsComponent {
     }
     if (has_s && has_a) { W::count(C.why + 0); return false; }
     if (!has_s && !has_a) return true;
-    const bool forward = has_s == (W::uni((uint32_t)M.gorient[start]) == 2);
+    const bool forward = has_s == ((W::uni((uint32_t)M.gorient[start]) & 3u) == 2);
     uint32_t nr = 0, pending = 1, best_t = GTS_NONE;
     uint64_t best_len = 0;
     bool inexact = false, bad = false;
@@ -1203,7 +1254,7 @@ struct GtsComponent {
         next_lane = l + 1;
         const uint32_t u = W::bcast(cv, l);
         --pending;
-        const bool du = (W::uni((uint32_t)M.gorient[u]) == 2) == forward;
+        const bool du = ((W::uni((uint32_t)M.gorient[u]) & 3u) == 2) == forward;
         const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
         const uint64_t plu = (uint64_t)W::uni64((int64_t)M.plen[u]);
         const uint32_t dpu = u == start ? 0 : W::uni(depth[u]);
@@ -1364,19 +1415,21 @@ struct GtsComponent {
   GTS_HD bool try_defer()
   {
     const uint32_t lane = W::lane();
-    if (!C.defer_min_nv || nv < C.defer_min_nv || nterm < 2) return false;
-    /* a marked edge with a live twin (analyze may have stopped before seeing it) */
+    if (!C.defer_min_nv || nv < C.defer_min_nv) return false;
+    if (nterm < 2) { nodefer = 2; return false; }
+    /* a marked edge with a live twin */
     bool rv = false;
     for (uint32_t base = 0; base < M.ne && !rv; base += W::WIDTH) {
       const uint32_t ce = base + lane;
       rv = W::ballot(ce < M.ne && (M.cflags[ce] & GTS_F_TWINLIVE) &&
                      gts_edge_is_marked(M.cstate[ce])) != 0;
     }
-    if (rv) return false;
+    if (rv) { nodefer = 1; return false; }
     const uint64_t t0 = W::alloc(C.ntasks, nterm);
     if (t0 + nterm > C.task_cap) return false;
     const uint64_t p0 = W::alloc(C.path_used, (uint64_t)nterm * nv);
     if (p0 + (uint64_t)nterm * nv > C.path_cap) {   /* pool full: walk in place */
+      nodefer = 3;
       for (uint32_t j = lane; j < nterm; j += W::WIDTH) { C.task_comp[t0 + j] = c; C.task_skip[t0 + j] = 1; }
       return false;
     }
@@ -1488,23 +1541,8 @@ struct GtsComponent {
   {
     const uint32_t lane = W::lane();
     const uint64_t t0 = W::clock();
-    clean = C.fast_walks && nv > 1 && analyze();
-    reuse_cc = clean;
-    if (clean) {
-      /* removecycles = its terminal search: every DFS is futile (analyze) */
-      calc_cc();
-      if (mode != GTS_MODE_MAKESCAFFOLD)
-        for (uint32_t s = lane; s < nv; s += W::WIDTH)
-          if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
-      W::fence();
-    } else {
-      removecycles();
-      /* with its cycles cut out the component may be clean for the walks */
-      if (mode == GTS_MODE_MAKESCAFFOLD && C.fast_walks && nv > 1) {
-        clean = analyze();
-        reuse_cc = false;
-      }
-    }
+    removecycles(mode == GTS_MODE_MAKESCAFFOLD);
+    reuse_cc = clean;   /* the terminal search of the last pass is makescaffold's */
     const uint64_t t1 = W::clock();
     const bool was_clean = clean;
     bool deferred = false;
@@ -1524,7 +1562,7 @@ struct GtsComponent {
     }
     if (lane == 0) {
       C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow;
-      C.stat_clean[c] = was_clean ? 1u : 0u;
+      C.stat_clean[c] = (was_clean ? 1u : 0u) | (deferred ? 2u : 0u) | (nodefer << 2) | (nterm << 8);
       C.tstat[5 * (uint64_t)c] = t1 - t0;
       C.tstat[5 * (uint64_t)c + 1] = t2 - t1 - tfast - tslow;
       C.tstat[5 * (uint64_t)c + 2] = tfast;

@@ -73,7 +73,7 @@ struct GtsgEngine {
   int64_t walk_pool_entries = 1ll << 26;
   int64_t defer_min_contigs = 96, walk_path_entries = 1ll << 25;
   int64_t fast_walks = 1, lds_components = 1;
-  bool profile = false;
+  int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
   /* profiling */
   struct Pending { const char *name; hipEvent_t a, b; };
   std::vector<Pending> pending;
@@ -967,6 +967,11 @@ __global__ void k_sum_u32(const uint32_t *a, uint32_t n, unsigned long long *out
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c < n && a[c]) atomicAdd(out, (unsigned long long)a[c]);
 }
+__global__ void k_sum_bit(const uint32_t *a, uint32_t n, uint32_t bit, unsigned long long *out)
+{
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n && (a[c] >> bit & 1u)) atomicAdd(out, 1ull);
+}
 __global__ void k_max_u32_diff(const uint32_t *off, uint32_t n, uint32_t *out)
 {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1126,7 +1131,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
   else if (!strcmp(name, "walk_path_entries") && value >= 1) e->walk_path_entries = value;
-  else if (!strcmp(name, "profile")) e->profile = value != 0;
+  else if (!strcmp(name, "profile")) e->profile = (int)value;
   else return fail(e, GTSG_EINVAL, "unknown option %s", name);
   return 0;
 }
@@ -1645,7 +1650,9 @@ static int run_components(GtsgEngine *e, int mode)
         first += kcount[nk];
       }
       /* the size classes are independent: fork them onto side streams so the
-         launches overlap (each has its own tail), join before the statistics */
+         launches overlap (each has its own tail), join before the statistics.
+         Three streams only: the runtime serves a process with four hardware
+         queues, a fourth concurrent stream waits for one of the others. */
       for (int k = (int)nk - 1; k >= 0; --k) {
         if (!kcount[k]) continue;
         static const char *const kn[2][GTS_NKLASS] = {
@@ -1655,7 +1662,7 @@ static int run_components(GtsgEngine *e, int mode)
             {"components_makescaffold_lds4k", "components_makescaffold_lds8k",
              "components_makescaffold_lds16k", "components_makescaffold_lds32k",
              "components_makescaffold_lds64k", "components_makescaffold_lds160k"}};
-        hipStream_t ss = e->side[k];
+        hipStream_t ss = e->side[((int)nk - 1 - k) % 3];
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
@@ -1676,7 +1683,7 @@ static int run_components(GtsgEngine *e, int mode)
           HIPCHK(hipEventRecord(e->ev_fork, e->st));
           for (int k = (int)nk - 1; k >= 0; --k) {
             if (!kcount[k]) continue;
-            hipStream_t ss = e->side[k];
+            hipStream_t ss = e->side[((int)nk - 1 - k) % 3];
             HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
             hipEvent_t _a = nullptr, _b = nullptr;
             if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
@@ -1701,9 +1708,11 @@ static int run_components(GtsgEngine *e, int mode)
            (unsigned long long *)(e->d_scalars + 16));
     LAUNCH("comp_walk_stats", k_sum_u32, nblk(ncomp), GTS_BLOCK, stat_slow, ncomp,
            (unsigned long long *)(e->d_scalars + 18));
-    HIPCHK(hipMemsetAsync(e->d_scalars + 20, 0, 8, e->st));
-    LAUNCH("comp_walk_stats", k_sum_u32, nblk(ncomp), GTS_BLOCK, stat_clean, ncomp,
+    HIPCHK(hipMemsetAsync(e->d_scalars + 20, 0, 16, e->st));
+    LAUNCH("comp_walk_stats", k_sum_bit, nblk(ncomp), GTS_BLOCK, stat_clean, ncomp, 0u,
            (unsigned long long *)(e->d_scalars + 20));
+    LAUNCH("comp_walk_stats", k_sum_bit, nblk(ncomp), GTS_BLOCK, stat_clean, ncomp, 1u,
+           (unsigned long long *)(e->d_scalars + 22));
     HIPCHK(hipMemsetAsync(e->d_scalars + 32, 0, 64, e->st));
     LAUNCH("comp_walk_stats", k_tstat_reduce, nblk(ncomp), GTS_BLOCK, tstat, ncomp,
            (unsigned long long *)(e->d_scalars + 32));
@@ -1712,9 +1721,9 @@ static int run_components(GtsgEngine *e, int mode)
     uint64_t why[8];
     HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 64, hipMemcpyDeviceToHost, e->st));
     uint32_t res[3] = {0, 0, 0};
-    uint64_t wstat[3] = {0, 0, 0};
+    uint64_t wstat[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 12, hipMemcpyDeviceToHost, e->st));
-    HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 24, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 32, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
     {
       static const char *nm[4] = {"removecycles", "makescaffold_other", "walks_fast", "walks_reference"};
@@ -1723,21 +1732,34 @@ static int run_components(GtsgEngine *e, int mode)
         e->stats[std::string("us_max_") + nm[k]] = (int64_t)(ts[4 + k] / 100);
       }
     }
-    if (e->profile) {   /* the three components with the longest reference walks */
+    if (e->profile >= 2) {   /* the three components that took longest */
       std::vector<uint64_t> ht(5 * (size_t)ncomp);
-      std::vector<uint32_t> hs(ncomp), ho((size_t)ncomp + 1);
+      std::vector<uint32_t> hs(ncomp), hf(ncomp), hc(ncomp), ho((size_t)ncomp + 1), hco((size_t)nslots + 1);
       HIPCHK(hipMemcpy(ht.data(), tstat, ht.size() * 8, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(hs.data(), stat_slow, (size_t)ncomp * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hf.data(), stat_fast, (size_t)ncomp * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hc.data(), stat_clean, (size_t)ncomp * 4, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(ho.data(), comp_off, ((size_t)ncomp + 1) * 4, hipMemcpyDeviceToHost));
-      for (int r = 0; r < 3; ++r) {
+      HIPCHK(hipMemcpy(hco.data(), coff, ((size_t)nslots + 1) * 4, hipMemcpyDeviceToHost));
+      auto total = [&](uint32_t c2) { const uint64_t *t = &ht[5 * (size_t)c2]; return t[0] + t[1] + t[2] + t[3]; };
+      for (int r = 0; r < 12 && r < (int)ncomp; ++r) {
         uint32_t best = 0;
-        for (uint32_t c2 = 1; c2 < ncomp; ++c2) if (ht[5 * (size_t)c2 + 3] > ht[5 * (size_t)best + 3]) best = c2;
-        const std::string pre = std::string("top") + char('0' + r) + "_";
+        for (uint32_t c2 = 1; c2 < ncomp; ++c2) if (total(c2) > total(best)) best = c2;
+        const std::string pre = "top" + std::to_string(r) + "_";
         e->stats[pre + "size"] = ho[best + 1] - ho[best];
+        e->stats[pre + "edges"] = hco[ho[best + 1]] - hco[ho[best]];
+        e->stats[pre + "terminals"] = hc[best] >> 8;
+        e->stats[pre + "clean"] = hc[best] & 1;
+        e->stats[pre + "deferred"] = hc[best] >> 1 & 1;
+        e->stats[pre + "why_not_deferred"] = hc[best] >> 2 & 3;
+        e->stats[pre + "walks"] = hf[best] + hs[best];
         e->stats[pre + "ref_walks"] = hs[best];
+        e->stats[pre + "removecycles_us"] = (int64_t)(ht[5 * (size_t)best] / 100);
+        e->stats[pre + "other_us"] = (int64_t)(ht[5 * (size_t)best + 1] / 100);
+        e->stats[pre + "walks_us"] = (int64_t)(ht[5 * (size_t)best + 2] / 100);
         e->stats[pre + "ref_us"] = (int64_t)(ht[5 * (size_t)best + 3] / 100);
         e->stats[pre + "ref_pops"] = (int64_t)ht[5 * (size_t)best + 4];
-        ht[5 * (size_t)best + 3] = 0;
+        for (int k = 0; k < 4; ++k) ht[5 * (size_t)best + k] = 0;
       }
     }
     {
@@ -1749,6 +1771,7 @@ static int run_components(GtsgEngine *e, int mode)
     e->stats["fast_walks"] = (int64_t)wstat[0];
     e->stats["slow_walks"] = (int64_t)wstat[1];
     e->stats["clean_components"] = (int64_t)wstat[2];
+    e->stats["deferred_components"] = (int64_t)wstat[3];
     e->stats["components"] = ncomp;
     e->stats["max_component"] = res[2];
     e->stats["compact_edges"] = nce;

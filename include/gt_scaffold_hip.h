@@ -126,7 +126,8 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      the pool the rings are carved from; both are quadrupled and the call is
      re-run from a snapshot if a ring or the pool overflows),
      "max_walk_pops" (default 2^32),
-     "hub_degree" (default 32), "profile" (0/1),
+     "hub_degree" (default 32), "profile" (0, 1 = hipEvents around every kernel,
+     2 = also the three slowest components as "top<r>_*" statistics),
      "fast_walks" (default 1; 0 forces the reference's label-correcting search
      for every walk), "lds_components" (default 1; 0 runs every component
      from global memory), "defer_min_contigs" (default 96; clean components
