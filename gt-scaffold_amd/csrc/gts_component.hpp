@@ -97,7 +97,11 @@ struct GtsCompView {
   uint32_t *task_comp, *task_start, *task_n;      /* task_cap */
   uint8_t *task_skip;
   uint64_t *task_len, *task_poff;
-  uint32_t *paths;           /* path_cap: walk edges (component-local) per task */
+  uint32_t *paths;           /* path_cap: per task nv walk edges (component-local) and the
+                                bitmap of the vertices the walk labelled */
+  uint32_t *comp_next_cc;    /* per deferred component: first cc not yet decided */
+  uint32_t *wbits;           /* nslots / 32 + ncomp + 1 words: select_walks' bitmap of component c
+                                starts at comp_off[c] / 32 + c */
   uint32_t *stat_fast, *stat_slow;  /* per component: walks by path taken */
   unsigned long long *why;   /* [8] why walks left the linear path: mixed start,
                                 self arc, back at start, marked end, two
@@ -211,11 +215,12 @@ struct GtsComponent {
   bool clean;           /* oriented, D acyclic (orient + peel) and nothing changed since */
   bool reuse_cc;        /* makescaffold may use the ccs run() computed */
   uint32_t nodefer;     /* statistics: why try_defer declined */
+  uint32_t *reach_bits; /* walk_task: bitmap of the vertices the walk labels */
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -238,6 +243,11 @@ struct GtsComponent {
   }
 
   GTS_HD uint32_t eoff(uint32_t ls) const { return W::uni(M.coff[ls]) - M.e0; }
+  /* walk_task: the vertices a search labels (see try_defer) */
+  GTS_HD void note_labelled(uint32_t v) const
+  {
+    if (reach_bits) W::or_bits(reach_bits + (v >> 5), 1u << (v & 31));
+  }
 
   /* ---- ref algorithms.c:379-436 (with isterminal, :346-373, fused) ---- */
   GTS_HD void calc_cc()
@@ -726,8 +736,11 @@ struct GtsComponent {
       W::fence();
     }
     /* leave the maps clean for the next walk */
-    for (uint32_t k = lane; k < ntouch; k += W::WIDTH)
-      M.distmap[M.touched[k]] = GTS_DIST_UNSET;
+    for (uint32_t k = lane; k < ntouch; k += W::WIDTH) {
+      const uint32_t v = M.touched[k];
+      M.distmap[v] = GTS_DIST_UNSET;
+      note_labelled(v);
+    }
     for (uint32_t k = lane; k < nwt; k += W::WIDTH)
       M.lastpop[M.wterm[k]] = 0;
     W::fence();
@@ -1061,6 +1074,7 @@ struct GtsComponent {
       orient[v] = 0;
       M.distmap[v] = GTS_DIST_UNSET;
       M.tight[v] = 0;
+      note_labelled(v);
     }
     W::fence();
     return !bad;
@@ -1328,7 +1342,10 @@ struct GtsComponent {
       cc_len = best_len;
       cc_n = n;
     }
-    for (uint32_t k = lane; k < nr; k += W::WIDTH) M.distmap[R[k]] = GTS_DIST_UNSET;
+    for (uint32_t k = lane; k < nr; k += W::WIDTH) {
+      M.distmap[R[k]] = GTS_DIST_UNSET;
+      note_labelled(R[k]);
+    }
     W::fence();
     return !bad;
   }
@@ -1405,55 +1422,45 @@ struct GtsComponent {
 
 
   /* ---- fan-out of the walks of a large component -------------------------
-     SCAFFOLD is an unmarked state, so marking a walk changes what another
-     walk sees only when it revives a marked twin.  Without revivable twins
-     all walks of all ccs are independent (the terminals of every cc are
-     found before the first walk, algorithms.c:784); only the
-     choice inside a cc follows the terminal order.  The component program
-     then stops after its terminal search and publishes one task per terminal
-     plus what the tasks need (terminal lists, strands, sweep order). */
+     The terminals of every cc are found before the first walk
+     (algorithms.c:784) and SCAFFOLD is an unmarked state, so marking the
+     best walk of a cc changes what a later walk sees only where it revives a
+     marked twin: a new arc in the list of the walk edge's end vertex.  A
+     search inspects the lists of the vertices it labels and nothing else, so
+     a walk computed BEFORE such marks is still the reference's walk as long
+     as no revived arc starts at a vertex it labelled.
+     The component program therefore stops after its terminal search and
+     publishes one task per terminal.  Rounds of (all pending walks in
+     parallel, one wave each) + (select_walks: the ccs in order, one wave per
+     component) follow: select_walks keeps a bitmap of the vertices that
+     gained an arc in this pass, accepts a cc only if none of its walks
+     labelled such a vertex, and otherwise hands the ccs from there on to the
+     next round -- only the walks that did touch such a vertex run again.  The
+     first pending cc of a pass is always accepted, so the rounds end. */
   GTS_HD bool try_defer()
   {
     const uint32_t lane = W::lane();
     if (!C.defer_min_nv || nv < C.defer_min_nv) return false;
     if (nterm < 2) { nodefer = 2; return false; }
-    /* a marked edge with a live twin */
-    bool rv = false;
-    for (uint32_t base = 0; base < M.ne && !rv; base += W::WIDTH) {
-      const uint32_t ce = base + lane;
-      rv = W::ballot(ce < M.ne && (M.cflags[ce] & GTS_F_TWINLIVE) &&
-                     gts_edge_is_marked(M.cstate[ce])) != 0;
-    }
-    if (rv) { nodefer = 1; return false; }
+    const uint32_t stride = nv + (nv + 31) / 32;   /* walk edges + labelled-vertex bitmap */
     const uint64_t t0 = W::alloc(C.ntasks, nterm);
     if (t0 + nterm > C.task_cap) return false;
-    const uint64_t p0 = W::alloc(C.path_used, (uint64_t)nterm * nv);
-    if (p0 + (uint64_t)nterm * nv > C.path_cap) {   /* pool full: walk in place */
+    const uint64_t p0 = W::alloc(C.path_used, (uint64_t)nterm * stride);
+    if (p0 + (uint64_t)nterm * stride > C.path_cap) {   /* pool full: walk in place */
       nodefer = 3;
       for (uint32_t j = lane; j < nterm; j += W::WIDTH) { C.task_comp[t0 + j] = c; C.task_skip[t0 + j] = 1; }
       return false;
     }
     auto ccoff = M.ccoff;
-    /* a cc with one terminal: algorithms.c:790-807 */
     for (uint32_t i = 0; i < ncc; ++i) {
       const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
       const bool skip = te - tb < 2;
-      if (te - tb == 1) {
-        const uint32_t v = W::uni(M.term[tb]);
-        const uint32_t eb = eoff(v), ee = eoff(v + 1);
-        bool any_live = false;
-        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
-          const uint32_t ce = base + lane;
-          any_live |= W::ballot(ce < ee && !gts_edge_is_marked(M.cstate[ce])) != 0;
-        }
-        if (!any_live) M.vst[v] = GIS_SCAFFOLD;
-      }
       for (uint32_t j = tb + lane; j < te; j += W::WIDTH) {
         const uint64_t t = t0 + j;
         C.task_comp[t] = c;
         C.task_start[t] = M.term[j];
         C.task_skip[t] = skip ? 1 : 0;
-        C.task_poff[t] = p0 + (uint64_t)j * nv;
+        C.task_poff[t] = p0 + (uint64_t)j * stride;
         C.task_len[t] = 0;
         C.task_n[t] = 0;
       }
@@ -1478,25 +1485,35 @@ struct GtsComponent {
       C.comp_task0[c] = (uint32_t)t0;
       C.comp_ncc[c] = ncc;
       C.comp_nterm[c] = nterm;
+      C.comp_next_cc[c] = 0;
     }
     W::fence();
     return true;
   }
 
   /* one deferred walk: the program object is constructed on a staged copy of
-     the component with gorient / topo / tpos loaded */
+     the component's published state (with gorient / topo / tpos while the
+     component is clean) */
   GTS_HD void walk_task(uint64_t t)
   {
     const uint32_t lane = W::lane();
     clean = W::uni((uint32_t)C.defer_flag[c]) == 2;
+    const uint64_t po = C.task_poff[t];
+    const uint32_t nw = (nv + 31) / 32;
+    reach_bits = C.paths + po + nv;
+    for (uint32_t k = lane; k < nw; k += W::WIDTH) reach_bits[k] = 0;
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }   /* as makescaffold */
+    W::fence();
     uint64_t len = 0;
     uint32_t n = 0;
-    create_walk(W::uni(C.task_start[t]), len, n);
-    const uint64_t po = C.task_poff[t];
+    const uint32_t start = W::uni(C.task_start[t]);
+    create_walk(start, len, n);
+    if (lane == 0) W::or_bits(reach_bits + (start >> 5), 1u << (start & 31));
     for (uint32_t k = lane; k < n; k += W::WIDTH) C.paths[po + k] = M.cc_best[k];
     if (lane == 0) {
       C.task_len[t] = len;
       C.task_n[t] = n;
+      C.task_skip[t] = 1;
       if (err) C.cerr[c] = err;
       if (nfast) W::count_n(C.stat_fast + c, nfast);
       if (nslow) W::count_n(C.stat_slow + c, nslow);
@@ -1504,18 +1521,53 @@ struct GtsComponent {
     W::fence();
   }
 
-  /* keeps, for every cc of a deferred component, the first strictly longest
-     walk in terminal order (algorithms.c:823-832) and marks it
-     (algorithms.c:835-848).  Works on the global arrays only. */
-  static GTS_HD void select_walks(const GtsCompView &C, uint32_t c)
+  /* true if the walk of task t labelled a vertex of the bitmap wb */
+  static GTS_HD bool task_touches(const GtsCompView &C, uint64_t t, uint32_t nv, const uint32_t *wb)
+  {
+    const uint32_t lane = W::lane(), nw = (nv + 31) / 32;
+    const uint32_t *rb = C.paths + C.task_poff[t] + nv;
+    bool hit = false;
+    for (uint32_t base = 0; base < nw && !hit; base += W::WIDTH) {
+      const uint32_t k = base + lane;
+      hit = W::ballot(k < nw && (rb[k] & wb[k]) != 0) != 0;
+    }
+    return hit;
+  }
+
+  /* One pass over the pending ccs of a deferred component, in order: the
+     lonesome test of a cc with one terminal (algorithms.c:790-807), the first
+     strictly longest walk in terminal order (algorithms.c:823-832) and its
+     marks (algorithms.c:835-848).  Works on the global arrays only; wb is
+     the component's scratch bitmap.  Returns true when ccs are left for
+     another round. */
+  static GTS_HD bool select_walks(const GtsCompView &C, uint32_t c, uint32_t *wb)
   {
     const uint32_t lane = W::lane();
     const uint32_t s0 = C.comp_off[c], e0g = C.coff[s0];
+    const uint32_t nv = C.comp_off[c + 1] - s0, nw = (nv + 31) / 32;
     const uint32_t ncc = C.comp_ncc[c], t0 = C.comp_task0[c];
     const uint32_t *ccoff = C.ccoff + s0 + c;
-    for (uint32_t i = 0; i < ncc; ++i) {
+    for (uint32_t k = lane; k < nw; k += W::WIDTH) wb[k] = 0;
+    W::fence();
+    bool revived_any = false;
+    uint32_t i = W::uni(C.comp_next_cc[c]);
+    for (; i < ncc; ++i) {
       const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
+      if (te - tb == 1) {
+        const uint32_t v = W::uni(C.term[s0 + tb]);
+        const uint32_t eb = W::uni(C.coff[s0 + v]), ee = W::uni(C.coff[s0 + v + 1]);
+        bool any_live = false;
+        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+          const uint32_t ce = base + lane;
+          any_live |= W::ballot(ce < ee && !gts_edge_is_marked(C.cstate[ce])) != 0;
+        }
+        if (!any_live && lane == 0) C.G.vstate[C.slot_v[s0 + v]] = GIS_SCAFFOLD;
+      }
       if (te - tb < 2) continue;
+      bool stale = false;
+      if (revived_any)
+        for (uint32_t j = tb; j < te && !stale; ++j) stale = task_touches(C, t0 + j, nv, wb);
+      if (stale) break;
       uint64_t best = 0;
       uint32_t bj = GTS_NONE;
       for (uint32_t j = tb; j < te; ++j) {
@@ -1525,16 +1577,49 @@ struct GtsComponent {
       if (bj == GTS_NONE) continue;
       const uint32_t n = W::uni(C.task_n[t0 + bj]);
       const uint64_t po = C.task_poff[t0 + bj];
-      for (uint32_t k = lane; k < n; k += W::WIDTH) {
-        const uint32_t ce = C.paths[po + k];
-        const uint32_t p = C.cgpos[e0g + ce], t = C.G.twin[p];
-        C.G.state[p] = GIS_SCAFFOLD;
-        C.G.state[t] = GIS_SCAFFOLD;
-        C.G.vstate[C.slot_v[s0 + C.cend[e0g + ce]]] = GIS_SCAFFOLD;
-        C.G.vstate[C.slot_v[s0 + C.cstart[e0g + ce]]] = GIS_SCAFFOLD;
+      bool revived = false;
+      for (uint32_t base = 0; base < n; base += W::WIDTH) {
+        const uint32_t k = base + lane;
+        bool rv = false;
+        if (k < n) {
+          const uint32_t ce = C.paths[po + k];
+          const uint32_t p = C.cgpos[e0g + ce], t = C.G.twin[p];
+          C.G.state[p] = GIS_SCAFFOLD;
+          C.G.state[t] = GIS_SCAFFOLD;
+          C.cstate[e0g + ce] = GIS_SCAFFOLD;
+          const uint32_t ct = C.cmap[t];
+          const uint32_t ve = C.cend[e0g + ce];
+          if (ct != GTS_NONE) {
+            if (gts_edge_is_marked(C.cstate[ct])) {   /* new arc out of ve */
+              rv = true;
+              W::or_bits(wb + (ve >> 5), 1u << (ve & 31));
+            }
+            C.cstate[ct] = GIS_SCAFFOLD;
+          }
+          C.G.vstate[C.slot_v[s0 + ve]] = GIS_SCAFFOLD;
+          C.G.vstate[C.slot_v[s0 + C.cstart[e0g + ce]]] = GIS_SCAFFOLD;
+        }
+        revived |= W::ballot(rv) != 0;
+      }
+      revived_any |= revived;
+      W::fence();
+    }
+    /* walks of the ccs left that labelled a vertex with a new arc run again */
+    for (uint32_t k = i; k < ncc; ++k) {
+      const uint32_t tb = W::uni(ccoff[k]), te = W::uni(ccoff[k + 1]);
+      if (te - tb < 2) continue;
+      for (uint32_t j = tb; j < te; ++j) {
+        const bool again = task_touches(C, t0 + j, nv, wb);
+        if (again && lane == 0) C.task_skip[t0 + j] = 0;
       }
     }
+    if (lane == 0) {
+      C.comp_next_cc[c] = i;
+      /* new arcs: the sweep order of a clean component is void */
+      C.defer_flag[c] = i == ncc ? 0 : (revived_any ? 1 : C.defer_flag[c]);
+    }
     W::fence();
+    return i < ncc;
   }
 
   GTS_HD void run(int mode)
@@ -1590,6 +1675,7 @@ struct GtsWave1 {
   static GTS_HD uint64_t clock() { return 0; }
   static GTS_HD void count(unsigned long long *p) { ++*p; }
   static GTS_HD void count_n(uint32_t *p, uint32_t n) { *p += n; }
+  static GTS_HD void or_bits(uint32_t *p, uint32_t m) { *p |= m; }
   static GTS_HD uint64_t alloc(unsigned long long *used, uint64_t n)
   { const uint64_t o = *used; *used += n; return o; }
   static GTS_HD uint32_t clz32(uint32_t v) { uint32_t n = 0; while (n < 32 && !(v & (0x80000000u >> n))) ++n; return n; }

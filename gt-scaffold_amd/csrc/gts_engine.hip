@@ -764,6 +764,7 @@ struct GtsWave64 {
   static __device__ __forceinline__ void count(unsigned long long *p)
   { if (lane() == 0) atomicAdd(p, 1ull); }
   static __device__ __forceinline__ void count_n(uint32_t *p, uint32_t n) { atomicAdd(p, n); }
+  static __device__ __forceinline__ void or_bits(uint32_t *p, uint32_t m) { atomicOr(p, m); }
   static __device__ __forceinline__ uint32_t clz32(uint32_t v) { return (uint32_t)__clz((int)v); }
   /* inclusive prefix sum of values < 128: one ballot per bit, the lower-lane
      population count of each ballot weighted by the bit */
@@ -893,18 +894,19 @@ k_walk_tasks(GtsCompView C, const uint8_t *comp_klass, uint32_t klass, uint32_t 
   const uint32_t t = blockIdx.x;
   if (t >= ntasks || C.task_skip[t]) return;
   const uint32_t c = C.task_comp[t];
-  if (comp_klass[c] != klass) return;
+  if (comp_klass[c] != klass || !C.defer_flag[c]) return;
   GtsCompMemT<true> M;
   stage_component(C, c, smem, M, true);
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.walk_task(t);
 }
 __global__ void __launch_bounds__(GTS_WAVE)
-k_select_walks(GtsCompView C)
+k_select_walks(GtsCompView C, uint32_t *remaining)
 {
   const uint32_t c = blockIdx.x;
   if (c >= C.ncomp || !C.defer_flag[c]) return;
-  GtsComponent<GtsWave64, false>::select_walks(C, c);
+  const bool more = GtsComponent<GtsWave64, false>::select_walks(C, c, C.wbits + C.comp_off[c] / 32 + c);
+  if (more && threadIdx.x == 0) atomicAdd(remaining, 1u);
 }
 /* LDS footprint of every component as a descending sort key, and how many
    components fit each size class */
@@ -1581,6 +1583,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(task_n, uint32_t, task_cap); PALLOC(task_skip, uint8_t, task_cap);
     PALLOC(task_len, uint64_t, task_cap); PALLOC(task_poff, uint64_t, task_cap);
     PALLOC(task_paths, uint32_t, path_cap + 1);
+    PALLOC(comp_next_cc, uint32_t, ncomp); PALLOC(wbits, uint32_t, (size_t)nslots / 32 + ncomp + 2);
     HIPCHK(hipMemsetAsync(defer_flag, 0, (size_t)ncomp + 1, e->st));
     HIPCHK(hipMemsetAsync(e->d_scalars + 128, 0, 16, e->st));
     PALLOC(s_gorient, uint8_t, nslots); PALLOC(s_topo, uint32_t, nslots); PALLOC(s_tpos, uint32_t, nslots);
@@ -1634,6 +1637,7 @@ static int run_components(GtsgEngine *e, int mode)
     C.task_cap = task_cap; C.path_cap = path_cap;
     C.task_comp = task_comp; C.task_start = task_start; C.task_n = task_n; C.task_skip = task_skip;
     C.task_len = task_len; C.task_poff = task_poff; C.paths = task_paths;
+    C.comp_next_cc = comp_next_cc; C.wbits = wbits;
     C.why = (unsigned long long *)(e->d_scalars + 96);
     HIPCHK(hipMemsetAsync(C.why, 0, 64, e->st));
     {
@@ -1679,7 +1683,8 @@ static int run_components(GtsgEngine *e, int mode)
       if (C.defer_min_nv) {
         if ((rc = read_u64(e, (uint64_t *)(e->d_scalars + 128), &ntasks))) return rc;
         if (ntasks > task_cap) ntasks = task_cap;
-        if (ntasks) {
+        uint32_t rounds = 0;
+        for (uint32_t left = ntasks ? 1 : 0; left; ++rounds) {
           HIPCHK(hipEventRecord(e->ev_fork, e->st));
           for (int k = (int)nk - 1; k >= 0; --k) {
             if (!kcount[k]) continue;
@@ -1692,8 +1697,11 @@ static int run_components(GtsgEngine *e, int mode)
             HIPCHK(hipEventRecord(e->ev_join[k], ss));
             HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
           }
-          LAUNCH("components_select_walks", k_select_walks, ncomp, GTS_WAVE, C);
+          HIPCHK(hipMemsetAsync(e->d_scalars + 132, 0, 4, e->st));
+          LAUNCH("components_select_walks", k_select_walks, ncomp, GTS_WAVE, C, e->d_scalars + 132);
+          if ((rc = read_u32(e, e->d_scalars + 132, &left))) return rc;
         }
+        e->stats["walk_task_rounds"] = rounds;
       }
       e->stats["walk_tasks"] = (int64_t)ntasks;
       e->stats["components_global_mem"] = kcount[nk];

@@ -109,14 +109,16 @@ class HostSimGraph:
         ns = C.c_uint64()
         ncl = C.c_uint64()
         ndf = C.c_uint64()
+        nrd = C.c_uint64()
         nerr = hostsim().hs_components(g["n"], g["m"], _p(g["row"]), _p(g["seq_len"]),
                                        _p(self.vstate), _p(g["end"]), _p(g["dist"]), _p(g["flags"]),
                                        _p(self.state), _p(g["twin"]), mode, wq_factor, max_pops,
                                        C.byref(nc), C.byref(mc), fast_walks, C.byref(nf),
-                                       C.byref(ns), C.byref(ncl), defer_min_nv, C.byref(ndf))
+                                       C.byref(ns), C.byref(ncl), defer_min_nv, C.byref(ndf), C.byref(nrd))
         self.ncomp, self.maxcomp = nc.value, mc.value
         self.fast_walks, self.slow_walks, self.clean_components = nf.value, ns.value, ncl.value
         self.deferred_components = ndf.value
+        self.walk_task_rounds = nrd.value
         return nerr
 
     def removecycles(self, **kw):

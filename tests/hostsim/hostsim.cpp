@@ -130,7 +130,7 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
                        uint64_t max_pops, uint32_t *out_ncomp,
                        uint32_t *out_maxcomp, int fast_walks,
                        uint64_t *out_fast, uint64_t *out_slow, uint64_t *out_clean,
-                       uint32_t defer_min_nv, uint64_t *out_deferred)
+                       uint32_t defer_min_nv, uint64_t *out_deferred, uint64_t *out_rounds)
 {
   GtsGraphView G = {n, m, row, seq_len, nullptr, nullptr, vstate, end, dist,
                     nullptr, flags, state, twin, nullptr};
@@ -241,7 +241,7 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   uint64_t path_cap = 1;
   for (uint32_t c = 0; c < ncomp; c++) {
     const uint64_t k = comp_off[c + 1] - comp_off[c];
-    path_cap += k * k;
+    path_cap += k * (k + (k + 31) / 32);
   }
   std::vector<uint32_t> paths(path_cap);
   unsigned long long ntasks = 0, path_used = 0;
@@ -251,29 +251,37 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   C.task_comp = task_comp.data(); C.task_start = task_start.data(); C.task_n = task_n.data();
   C.task_skip = task_skip.data(); C.task_len = task_len.data(); C.task_poff = task_poff.data();
   C.paths = paths.data();
+  std::vector<uint32_t> comp_next_cc(ncomp ? ncomp : 1, 0), wbits(S / 32 + ncomp + 2, 0);
+  C.comp_next_cc = comp_next_cc.data(); C.wbits = wbits.data();
   uint32_t nerr = 0;
   for (uint32_t c = 0; c < ncomp; c++) {
     GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
     GtsComponent<GtsWave1> prog(C, mem, c);
     prog.run(mode);
   }
-  for (uint64_t t = 0; t < ntasks; t++) {
-    if (task_skip[t]) continue;
-    const uint32_t c = task_comp[t];
-    GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
-    GtsComponent<GtsWave1> prog(C, mem, c);
-    prog.walk_task(t);
+  uint64_t ndefer = 0, rounds = 0;
+  for (uint32_t c = 0; c < ncomp; c++) ndefer += defer_flag[c] != 0;
+  for (bool left = ntasks != 0; left; rounds++) {
+    for (uint64_t t = 0; t < ntasks; t++) {
+      const uint32_t c = task_comp[t];
+      if (task_skip[t] || !defer_flag[c]) continue;
+      GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
+      GtsComponent<GtsWave1> prog(C, mem, c);
+      wq_used = 0;   /* serial harness: the ring of the previous task is free again */
+      prog.walk_task(t);
+    }
+    left = false;
+    for (uint32_t c = 0; c < ncomp; c++)
+      if (defer_flag[c] &&
+          GtsComponent<GtsWave1>::select_walks(C, c, wbits.data() + comp_off[c] / 32 + c)) left = true;
   }
-  uint64_t ndefer = 0;
-  for (uint32_t c = 0; c < ncomp; c++) {
-    if (defer_flag[c]) { GtsComponent<GtsWave1>::select_walks(C, c); ndefer++; }
-    if (cerr[c]) nerr++;
-  }
+  for (uint32_t c = 0; c < ncomp; c++) if (cerr[c]) nerr++;
+  if (out_rounds) *out_rounds = rounds;
   if (out_deferred) *out_deferred = ndefer;
   uint64_t tf = 0, ts = 0;
   for (uint32_t c = 0; c < ncomp; c++) { tf += sf[c]; ts += ss[c]; }
   uint64_t ncl = 0;
-  for (uint32_t c = 0; c < ncomp; c++) ncl += sclean[c];
+  for (uint32_t c = 0; c < ncomp; c++) ncl += sclean[c] & 1u;
   if (out_clean) *out_clean = ncl;
   if (out_fast) *out_fast = tf;
   if (out_slow) *out_slow = ts;
