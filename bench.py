@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine option (gtsg_set_option), e.g. defer_min_contigs=256")
     ap.add_argument("--inversions", type=float, default=None,
                     help="fraction of the chimeric links that are inversions (default 0: the "
                          "reference's walk search is exponential on components holding one)")
@@ -181,6 +183,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     eng = pkg.engine.Engine(local_rank, stream)
     eng.set_option("profile", 0 if args.no_profile else 1)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        eng.set_option(name, int(value))
 
     comm = contigs = rec = None
     if args.mode == "partition":
@@ -299,6 +304,7 @@ def main():
                                                   "why_inexact_tie", "why_cycle",
                                                   "why_inexact_length_tie")},
                        walk_tasks=eng.stat("walk_tasks"), walk_task_rounds=eng.stat("walk_task_rounds"),
+                       walk_task_runs=eng.stat("walk_task_runs"),
                        deferred_components=eng.stat("deferred_components"),
                        slowest_components=[
                            {k: eng.stat("top%d_%s" % (r, k)) for k in

@@ -97,9 +97,17 @@ struct GtsCompView {
   uint32_t *task_comp, *task_start, *task_n;      /* task_cap */
   uint8_t *task_skip;
   uint64_t *task_len, *task_poff;
-  uint32_t *paths;           /* path_cap: per task nv walk edges (component-local) and the
-                                bitmap of the vertices the walk labelled */
+  uint32_t *paths;           /* path_cap: pool for the tasks' bitmaps of labelled vertices
+                                (fixed at defer time) and their walks (component-local edges) */
   uint32_t *comp_next_cc;    /* per deferred component: first cc not yet decided */
+  uint64_t *task_roff;       /* task_cap: offset of the task's bitmap in paths */
+  uint64_t *comp_ring;       /* per component: 2 x u64, ring of select_walks' reference searches */
+  const uint8_t *comp_klass; /* per component: LDS size class (launch group of its tasks) */
+  uint32_t *tq;              /* task_cap: pending tasks, one segment per class */
+  const uint32_t *tq_base;   /* per class: start of its segment */
+  unsigned long long *tq_cnt;/* per class: pending tasks */
+  uint32_t *defer_list;      /* ncomp: the deferred components */
+  unsigned long long *ndeferred;
   uint32_t *wbits;           /* nslots / 32 + ncomp + 1 words: select_walks' bitmap of component c
                                 starts at comp_off[c] / 32 + c */
   uint32_t *stat_fast, *stat_slow;  /* per component: walks by path taken */
@@ -216,11 +224,13 @@ struct GtsComponent {
   bool reuse_cc;        /* makescaffold may use the ccs run() computed */
   uint32_t nodefer;     /* statistics: why try_defer declined */
   uint32_t *reach_bits; /* walk_task: bitmap of the vertices the walk labels */
+  bool no_reference;    /* walk_task: leave a walk that needs the reference search to select_walks */
+  bool needs_reference;
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), no_reference(false), needs_reference(false) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -1361,6 +1371,7 @@ struct GtsComponent {
     }
     const uint64_t t1 = W::clock();
     tfast += t1 - t0;
+    if (no_reference) { needs_reference = true; return true; }
     ++nslow;
     const bool ok = create_walk_reference(start, cc_len, cc_n);
     tslow += W::clock() - t1;
@@ -1442,16 +1453,20 @@ struct GtsComponent {
     const uint32_t lane = W::lane();
     if (!C.defer_min_nv || nv < C.defer_min_nv) return false;
     if (nterm < 2) { nodefer = 2; return false; }
-    const uint32_t stride = nv + (nv + 31) / 32;   /* walk edges + labelled-vertex bitmap */
+    const uint32_t nw = (nv + 31) / 32;   /* labelled-vertex bitmap of a task */
     const uint64_t t0 = W::alloc(C.ntasks, nterm);
     if (t0 + nterm > C.task_cap) return false;
-    const uint64_t p0 = W::alloc(C.path_used, (uint64_t)nterm * stride);
-    if (p0 + (uint64_t)nterm * stride > C.path_cap) {   /* pool full: walk in place */
-      nodefer = 3;
-      for (uint32_t j = lane; j < nterm; j += W::WIDTH) { C.task_comp[t0 + j] = c; C.task_skip[t0 + j] = 1; }
-      return false;
-    }
+    const uint64_t p0 = W::alloc(C.path_used, (uint64_t)nterm * nw);
+    if (p0 + (uint64_t)nterm * nw > C.path_cap) { nodefer = 3; return false; }   /* walk in place */
     auto ccoff = M.ccoff;
+    uint32_t npend = 0;
+    for (uint32_t i = 0; i < ncc; ++i) {
+      const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
+      if (te - tb >= 2) npend += te - tb;
+    }
+    const uint32_t kl = W::uni((uint32_t)C.comp_klass[c]);
+    const uint64_t q0 = C.tq_base[kl] + W::alloc(C.tq_cnt + kl, npend);
+    npend = 0;
     for (uint32_t i = 0; i < ncc; ++i) {
       const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
       const bool skip = te - tb < 2;
@@ -1460,10 +1475,13 @@ struct GtsComponent {
         C.task_comp[t] = c;
         C.task_start[t] = M.term[j];
         C.task_skip[t] = skip ? 1 : 0;
-        C.task_poff[t] = p0 + (uint64_t)j * stride;
+        C.task_roff[t] = p0 + (uint64_t)j * nw;
+        C.task_poff[t] = 0;
         C.task_len[t] = 0;
         C.task_n[t] = 0;
+        if (!skip) C.tq[q0 + npend + (j - tb)] = (uint32_t)t;
       }
+      if (!skip) npend += te - tb;
     }
     /* what the tasks and the select pass read (no-op copies when M already
        points into the global arrays) */
@@ -1486,7 +1504,10 @@ struct GtsComponent {
       C.comp_ncc[c] = ncc;
       C.comp_nterm[c] = nterm;
       C.comp_next_cc[c] = 0;
+      C.comp_ring[2 * (uint64_t)c] = 0; C.comp_ring[2 * (uint64_t)c + 1] = 0;
     }
+    const uint64_t dl = W::alloc(C.ndeferred, 1);
+    if (lane == 0) C.defer_list[dl] = c;
     W::fence();
     return true;
   }
@@ -1498,9 +1519,9 @@ struct GtsComponent {
   {
     const uint32_t lane = W::lane();
     clean = W::uni((uint32_t)C.defer_flag[c]) == 2;
-    const uint64_t po = C.task_poff[t];
     const uint32_t nw = (nv + 31) / 32;
-    reach_bits = C.paths + po + nv;
+    reach_bits = C.paths + C.task_roff[t];
+    no_reference = true;
     for (uint32_t k = lane; k < nw; k += W::WIDTH) reach_bits[k] = 0;
     for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }   /* as makescaffold */
     W::fence();
@@ -1509,14 +1530,20 @@ struct GtsComponent {
     const uint32_t start = W::uni(C.task_start[t]);
     create_walk(start, len, n);
     if (lane == 0) W::or_bits(reach_bits + (start >> 5), 1u << (start & 31));
-    for (uint32_t k = lane; k < n; k += W::WIDTH) C.paths[po + k] = M.cc_best[k];
+    uint64_t po = 0;
+    if (needs_reference) { len = 0; n = GTS_NONE; }   /* select_walks runs the reference search */
+    else if (n) {
+      po = W::alloc(C.path_used, n);
+      if (po + n > C.path_cap) { err = GTS_CERR_WALKQ_OVERFLOW; n = 0; len = 0; }
+      for (uint32_t k = lane; k < n; k += W::WIDTH) C.paths[po + k] = M.cc_best[k];
+    }
     if (lane == 0) {
       C.task_len[t] = len;
       C.task_n[t] = n;
+      C.task_poff[t] = po;
       C.task_skip[t] = 1;
       if (err) C.cerr[c] = err;
       if (nfast) W::count_n(C.stat_fast + c, nfast);
-      if (nslow) W::count_n(C.stat_slow + c, nslow);
     }
     W::fence();
   }
@@ -1525,7 +1552,7 @@ struct GtsComponent {
   static GTS_HD bool task_touches(const GtsCompView &C, uint64_t t, uint32_t nv, const uint32_t *wb)
   {
     const uint32_t lane = W::lane(), nw = (nv + 31) / 32;
-    const uint32_t *rb = C.paths + C.task_poff[t] + nv;
+    const uint32_t *rb = C.paths + C.task_roff[t];
     bool hit = false;
     for (uint32_t base = 0; base < nw && !hit; base += W::WIDTH) {
       const uint32_t k = base + lane;
@@ -1568,6 +1595,30 @@ struct GtsComponent {
       if (revived_any)
         for (uint32_t j = tb; j < te && !stale; ++j) stale = task_touches(C, t0 + j, nv, wb);
       if (stale) break;
+      /* walks the tasks left to the reference search: here, in terminal
+         order, on the global arrays, with one ring per component */
+      for (uint32_t j = tb; j < te; ++j) {
+        if (W::uni(C.task_n[t0 + j]) != GTS_NONE) continue;
+        const GtsCompMem gm = GtsComponent<W, false>::global_mem(C, c);
+        GtsComponent<W, false> prog(C, gm, c);
+        prog.qbase = C.comp_ring[2 * (uint64_t)c]; prog.qcap = C.comp_ring[2 * (uint64_t)c + 1];
+        uint64_t len = 0;
+        uint32_t n = 0;
+        prog.create_walk_reference(W::uni(C.task_start[t0 + j]), len, n);
+        uint64_t po = 0;
+        if (n) {
+          po = W::alloc(C.path_used, n);
+          if (po + n > C.path_cap) { prog.err = GTS_CERR_WALKQ_OVERFLOW; n = 0; len = 0; }
+          for (uint32_t k = lane; k < n; k += W::WIDTH) C.paths[po + k] = prog.M.cc_best[k];
+        }
+        if (lane == 0) {
+          C.comp_ring[2 * (uint64_t)c] = prog.qbase; C.comp_ring[2 * (uint64_t)c + 1] = prog.qcap;
+          C.task_len[t0 + j] = len; C.task_n[t0 + j] = n; C.task_poff[t0 + j] = po;
+          if (prog.err) C.cerr[c] = prog.err;
+          W::count_n(C.stat_slow + c, 1);
+        }
+        W::fence();
+      }
       uint64_t best = 0;
       uint32_t bj = GTS_NONE;
       for (uint32_t j = tb; j < te; ++j) {
@@ -1609,8 +1660,11 @@ struct GtsComponent {
       const uint32_t tb = W::uni(ccoff[k]), te = W::uni(ccoff[k + 1]);
       if (te - tb < 2) continue;
       for (uint32_t j = tb; j < te; ++j) {
-        const bool again = task_touches(C, t0 + j, nv, wb);
-        if (again && lane == 0) C.task_skip[t0 + j] = 0;
+        /* (a walk left to the reference search is made when its cc is due) */
+        if (W::uni(C.task_n[t0 + j]) == GTS_NONE || !task_touches(C, t0 + j, nv, wb)) continue;
+        const uint32_t kl = W::uni((uint32_t)C.comp_klass[c]);
+        const uint64_t q = C.tq_base[kl] + W::alloc(C.tq_cnt + kl, 1);
+        if (lane == 0) { C.task_skip[t0 + j] = 0; C.tq[q] = t0 + j; }
       }
     }
     if (lane == 0) {

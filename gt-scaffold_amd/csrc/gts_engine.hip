@@ -71,7 +71,7 @@ struct GtsgEngine {
   /* options */
   int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
   int64_t walk_pool_entries = 1ll << 26;
-  int64_t defer_min_contigs = 96, walk_path_entries = 1ll << 25;
+  int64_t defer_min_contigs = 96, walk_path_entries = 1ll << 24;
   int64_t fast_walks = 1, lds_components = 1;
   int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
   /* profiling */
@@ -888,25 +888,24 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
    launched once per LDS size class, a workgroup whose task belongs to another
    class leaves at once */
 __global__ void __launch_bounds__(GTS_WAVE)
-k_walk_tasks(GtsCompView C, const uint8_t *comp_klass, uint32_t klass, uint32_t ntasks)
+k_walk_tasks(GtsCompView C, uint32_t klass, uint32_t count)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t t = blockIdx.x;
-  if (t >= ntasks || C.task_skip[t]) return;
+  if (blockIdx.x >= count) return;
+  const uint32_t t = C.tq[C.tq_base[klass] + blockIdx.x];
   const uint32_t c = C.task_comp[t];
-  if (comp_klass[c] != klass || !C.defer_flag[c]) return;
   GtsCompMemT<true> M;
   stage_component(C, c, smem, M, true);
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.walk_task(t);
 }
 __global__ void __launch_bounds__(GTS_WAVE)
-k_select_walks(GtsCompView C, uint32_t *remaining)
+k_select_walks(GtsCompView C, uint32_t ndeferred)
 {
-  const uint32_t c = blockIdx.x;
-  if (c >= C.ncomp || !C.defer_flag[c]) return;
-  const bool more = GtsComponent<GtsWave64, false>::select_walks(C, c, C.wbits + C.comp_off[c] / 32 + c);
-  if (more && threadIdx.x == 0) atomicAdd(remaining, 1u);
+  if (blockIdx.x >= ndeferred) return;
+  const uint32_t c = C.defer_list[blockIdx.x];
+  if (!C.defer_flag[c]) return;
+  GtsComponent<GtsWave64, false>::select_walks(C, c, C.wbits + C.comp_off[c] / 32 + c);
 }
 /* LDS footprint of every component as a descending sort key, and how many
    components fit each size class */
@@ -914,13 +913,14 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 uint32_t *keys, uint32_t *vals, uint32_t ncomp,
                                 const uint8_t *comp_wide, uint8_t *comp_klass,
                                 const uint32_t *klass, uint32_t nklass,
-                                uint32_t *klass_count, unsigned long long *klass_bytes)
+                                uint32_t *klass_count, unsigned long long *klass_bytes,
+                                uint32_t *klass_slots)
 {
   /* counters are summed per workgroup in LDS first: seven global counters hit by
      every component serialise */
-  __shared__ uint32_t s_cnt[GTS_NKLASS + 1];
+  __shared__ uint32_t s_cnt[GTS_NKLASS + 1], s_slots[GTS_NKLASS + 1];
   __shared__ unsigned long long s_bytes[GTS_NKLASS + 1];
-  if (threadIdx.x <= GTS_NKLASS) { s_cnt[threadIdx.x] = 0; s_bytes[threadIdx.x] = 0; }
+  if (threadIdx.x <= GTS_NKLASS) { s_cnt[threadIdx.x] = 0; s_bytes[threadIdx.x] = 0; s_slots[threadIdx.x] = 0; }
   __syncthreads();
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c < ncomp) {
@@ -934,6 +934,7 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
     uint32_t k = 0;
     while (k < nklass && need > klass[k]) ++k;   /* klass ascending; nklass = global */
     comp_klass[c] = (uint8_t)k;
+    atomicAdd(&s_slots[k], cnv);
     atomicAdd(&s_cnt[k], 1u);
     /* bytes the component's program has to touch once: its compact graph and
        vertex records in, vertex states and edge marks out */
@@ -944,7 +945,15 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
   if (threadIdx.x <= GTS_NKLASS && s_cnt[threadIdx.x]) {
     atomicAdd(&klass_count[threadIdx.x], s_cnt[threadIdx.x]);
     atomicAdd(&klass_bytes[threadIdx.x], s_bytes[threadIdx.x]);
+    atomicAdd(&klass_slots[threadIdx.x], s_slots[threadIdx.x]);
   }
+}
+/* start of every class' segment of the pending-task array: a class has at most
+   as many tasks as its components have vertices */
+__global__ void k_task_queue_bases(const uint32_t *klass_slots, uint32_t *tq_base)
+{
+  uint32_t acc = 0;
+  for (int k = 0; k <= GTS_NKLASS; ++k) { tq_base[k] = acc; acc += klass_slots[k]; }
 }
 __global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
                                uint32_t *out /* [0]=overflow, [1]=loop */)
@@ -1475,6 +1484,7 @@ static int run_components(GtsgEngine *e, int mode)
   if (!n) return 0;
   int rc;
   int64_t factor = e->walk_queue_factor, pool_entries = e->walk_pool_entries;
+  int64_t path_entries = e->walk_path_entries;
   int64_t retries = 0;
   /* snapshot for the (rare) walk-queue retry */
   uint8_t *snap_v = nullptr, *snap_e = nullptr;
@@ -1485,7 +1495,7 @@ static int run_components(GtsgEngine *e, int mode)
                        (gts_sort_tmp_elems(n) + 2 * gts_scan_tmp_elems((uint64_t)n + m)) * 8 +
                        (size_t)n + m + (16u << 20);
     /* upper bounds for phase B: slots <= n, compact edges <= m */
-    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64 + 8 + 16 + 48) + (size_t)e->walk_path_entries * 4 + (size_t)m * (4 * 3 + 8 + 2) +
+    const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64 + 8 + 16 + 48) + (size_t)path_entries * 4 + (size_t)n * 32 + (size_t)m * (4 * 3 + 8 + 2) +
                        (size_t)pool_entries * 12 + (size_t)n * 24 + (16u << 20);
     if (!e->pool || e->pool_cap < wsA + wsB) {
       if ((rc = pool_reserve(e, wsA + wsB))) return rc;
@@ -1578,12 +1588,14 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(stat_clean, uint32_t, ncomp);
     PALLOC(comp_klass, uint8_t, (size_t)ncomp + 1); PALLOC(defer_flag, uint8_t, (size_t)ncomp + 1);
     PALLOC(comp_task0, uint32_t, ncomp); PALLOC(comp_ncc, uint32_t, ncomp); PALLOC(comp_nterm, uint32_t, ncomp);
-    const uint64_t task_cap = nslots, path_cap = (uint64_t)e->walk_path_entries;
+    const uint64_t task_cap = nslots, path_cap = (uint64_t)path_entries;
     PALLOC(task_comp, uint32_t, task_cap); PALLOC(task_start, uint32_t, task_cap);
     PALLOC(task_n, uint32_t, task_cap); PALLOC(task_skip, uint8_t, task_cap);
     PALLOC(task_len, uint64_t, task_cap); PALLOC(task_poff, uint64_t, task_cap);
     PALLOC(task_paths, uint32_t, path_cap + 1);
     PALLOC(comp_next_cc, uint32_t, ncomp); PALLOC(wbits, uint32_t, (size_t)nslots / 32 + ncomp + 2);
+    PALLOC(task_roff, uint64_t, task_cap); PALLOC(comp_ring, uint64_t, 2 * (size_t)ncomp);
+    PALLOC(tq, uint32_t, task_cap + 1); PALLOC(defer_list, uint32_t, (size_t)ncomp + 1);
     HIPCHK(hipMemsetAsync(defer_flag, 0, (size_t)ncomp + 1, e->st));
     HIPCHK(hipMemsetAsync(e->d_scalars + 128, 0, 16, e->st));
     PALLOC(s_gorient, uint8_t, nslots); PALLOC(s_topo, uint32_t, nslots); PALLOC(s_tpos, uint32_t, nslots);
@@ -1601,9 +1613,11 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, sizeof klass_h, hipMemcpyHostToDevice, e->st));
     HIPCHK(hipMemsetAsync(klass_count, 0, (GTS_NKLASS + 1) * 4, e->st));
     HIPCHK(hipMemsetAsync(e->d_scalars + 112, 0, (GTS_NKLASS + 1) * 8, e->st));
+    HIPCHK(hipMemsetAsync(e->d_scalars + 136, 0, (170 - 136) * 4, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
            ncomp, comp_wide, comp_klass, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
-           (unsigned long long *)(e->d_scalars + 112));
+           (unsigned long long *)(e->d_scalars + 112), e->d_scalars + 136);
+    LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + 136, e->d_scalars + 144);
     const uint32_t *order;
     {
       int shifts[4] = {0, 8, 16, 24};
@@ -1638,6 +1652,9 @@ static int run_components(GtsgEngine *e, int mode)
     C.task_comp = task_comp; C.task_start = task_start; C.task_n = task_n; C.task_skip = task_skip;
     C.task_len = task_len; C.task_poff = task_poff; C.paths = task_paths;
     C.comp_next_cc = comp_next_cc; C.wbits = wbits;
+    C.task_roff = task_roff; C.comp_ring = comp_ring; C.comp_klass = comp_klass; C.tq = tq;
+    C.tq_base = e->d_scalars + 144; C.tq_cnt = (unsigned long long *)(e->d_scalars + 152);
+    C.defer_list = defer_list; C.ndeferred = (unsigned long long *)(e->d_scalars + 168);
     C.why = (unsigned long long *)(e->d_scalars + 96);
     HIPCHK(hipMemsetAsync(C.why, 0, 64, e->st));
     {
@@ -1678,31 +1695,40 @@ static int run_components(GtsgEngine *e, int mode)
         e->stats[std::string("components_lds_class") + char('0' + k)] = kcount[k];
         first += kcount[k];
       }
-      /* deferred walks: one task per terminal of the large clean components */
-      uint64_t ntasks = 0;
+      /* deferred walks (gts_component.hpp, try_defer): rounds of one workgroup
+         per pending walk, grouped by LDS class, and an in-order select pass */
+      uint64_t ntasks = 0, walks_run = 0;
+      uint32_t rounds = 0;
       if (C.defer_min_nv) {
+        uint64_t pend[GTS_NKLASS + 1], ndef = 0;
+        HIPCHK(hipMemcpyAsync(pend, e->d_scalars + 152, sizeof pend, hipMemcpyDeviceToHost, e->st));
+        HIPCHK(hipMemcpyAsync(&ndef, e->d_scalars + 168, 8, hipMemcpyDeviceToHost, e->st));
         if ((rc = read_u64(e, (uint64_t *)(e->d_scalars + 128), &ntasks))) return rc;
-        if (ntasks > task_cap) ntasks = task_cap;
-        uint32_t rounds = 0;
-        for (uint32_t left = ntasks ? 1 : 0; left; ++rounds) {
+        for (;; ++rounds) {
+          uint64_t total = 0;
+          for (uint32_t k = 0; k < nk; ++k) total += pend[k];
+          if (!total) break;
+          walks_run += total;
           HIPCHK(hipEventRecord(e->ev_fork, e->st));
           for (int k = (int)nk - 1; k >= 0; --k) {
-            if (!kcount[k]) continue;
+            if (!pend[k]) continue;
             hipStream_t ss = e->side[((int)nk - 1 - k) % 3];
             HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
             hipEvent_t _a = nullptr, _b = nullptr;
             if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
-            k_walk_tasks<<<(uint32_t)ntasks, GTS_WAVE, klass_h[k], ss>>>(C, comp_klass, (uint32_t)k, (uint32_t)ntasks);
+            k_walk_tasks<<<(uint32_t)pend[k], GTS_WAVE, klass_h[k], ss>>>(C, (uint32_t)k, (uint32_t)pend[k]);
             if (e->profile) { hipEventRecord(_b, ss); e->pending.push_back({"components_walk_tasks", _a, _b}); }
             HIPCHK(hipEventRecord(e->ev_join[k], ss));
             HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
           }
-          HIPCHK(hipMemsetAsync(e->d_scalars + 132, 0, 4, e->st));
-          LAUNCH("components_select_walks", k_select_walks, ncomp, GTS_WAVE, C, e->d_scalars + 132);
-          if ((rc = read_u32(e, e->d_scalars + 132, &left))) return rc;
+          HIPCHK(hipMemsetAsync(e->d_scalars + 152, 0, sizeof pend, e->st));
+          LAUNCH("components_select_walks", k_select_walks, (uint32_t)ndef, GTS_WAVE, C, (uint32_t)ndef);
+          HIPCHK(hipMemcpyAsync(pend, e->d_scalars + 152, sizeof pend, hipMemcpyDeviceToHost, e->st));
+          if ((rc = sync_stream(e))) return rc;
         }
-        e->stats["walk_task_rounds"] = rounds;
       }
+      e->stats["walk_task_rounds"] = rounds;
+      e->stats["walk_task_runs"] = (int64_t)walks_run;
       e->stats["walk_tasks"] = (int64_t)ntasks;
       e->stats["components_global_mem"] = kcount[nk];
       e->stats["bytes_components_global_mem"] = (int64_t)kbytes[nk];
@@ -1791,7 +1817,7 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(e->vstate, snap_v, n, hipMemcpyDeviceToDevice, e->st));
     if (m) HIPCHK(hipMemcpyAsync(e->state, snap_e, m, hipMemcpyDeviceToDevice, e->st));
     HIPCHK(hipStreamSynchronize(e->st));
-    factor *= 4; pool_entries *= 4;
+    factor *= 4; pool_entries *= 4; path_entries *= 4;
     if (++retries > 6) return fail(e, GTSG_EWALK, "walk queues keep overflowing");
   }
   e->stats["walk_retries"] = retries;

@@ -130,9 +130,10 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      2 = also the three slowest components as "top<r>_*" statistics),
      "fast_walks" (default 1; 0 forces the reference's label-correcting search
      for every walk), "lds_components" (default 1; 0 runs every component
-     from global memory), "defer_min_contigs" (default 96; clean components
-     with at least that many contigs hand their walks to one task per terminal,
-     0 = never), "walk_path_entries" (default 2^25, pool for the tasks' walks) */
+     from global memory), "defer_min_contigs" (default 96; components with at
+     least that many contigs hand their walks to one workgroup per terminal,
+     0 = never), "walk_path_entries" (default 2^24, pool for the tasks' walks;
+     grows by itself like the walk queues) */
 
 /* per-kernel timing collected with hipEvents on the engine's stream while
    option "profile" is 1.  Fills up to cap entries, returns the number of
@@ -147,7 +148,7 @@ void gtsg_reset_kernel_times(GtsgEngine *e);
 /* counters of the last calls: "filter_rounds_p", "filter_rounds_i",
    "components", "max_component", "slots", "compact_edges", "hubs",
    "walk_retries", "fast_walks", "slow_walks", "clean_components",
-   "walk_tasks" */
+   "deferred_components", "walk_tasks", "walk_task_rounds", "walk_task_runs" */
 int64_t gtsg_get_stat(const GtsgEngine *e, const char *name);
 
 #ifdef __cplusplus

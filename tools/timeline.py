@@ -11,7 +11,7 @@ for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = s - end
     name = r["Kernel_Name"].split("(")[0][:48]
-    if (e - s) > 200000 or gap > 200000:
+    if (e - s) > 100000 or gap > 100000:
         print("%9.3f ms  dur %8.3f  gap %8.3f  %s" % ((s - t0) / 1e6, (e - s) / 1e6, gap / 1e6, name))
     end = max(end, e)
 print("total %.3f ms" % ((end - t0) / 1e6))
