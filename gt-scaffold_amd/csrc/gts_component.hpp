@@ -809,57 +809,86 @@ struct GtsComponent {
      the final nodes are those of a FIFO search over the tight arcs, adjacency
      lists in list order.  Labels: queue relaxation with an in-queue flag
      (bounded pops, gives up on negative cycles). */
-  GTS_HD bool walk_cyclic(uint32_t start, uint32_t nr, uint64_t &best_len, uint32_t &best_t)
+  GTS_HD bool walk_cyclic(uint32_t start, uint32_t nr, uint32_t npeeled, uint64_t &best_len,
+                          uint32_t &best_t)
   {
     const uint32_t lane = W::lane();
     auto R = M.queue;
     auto TQ = M.visited;
     auto BQ = M.wterm;
     auto orient = M.st_dir;
-    auto inq = M.tight;
+    auto dirty = M.tight;
+    auto indeg = M.st_v;
+    /* Relaxation order: the topological prefix create_walk_fast peeled, then
+       the states it got stuck on in the order they were reached.  The labels
+       are the fixpoint whatever the order; with this one a sweep settles
+       everything up to the next arc that points backwards. */
+    for (uint32_t base = 0; base < nr; base += W::WIDTH) {
+      const uint32_t k = base + lane;
+      uint32_t v = 0;
+      bool stuck = false;
+      if (k < nr) { v = R[k]; stuck = indeg[v] != 0; }
+      const uint64_t sm = W::ballot(stuck);
+      if (stuck) TQ[npeeled + W::popc_below(sm, lane)] = v;
+      npeeled += W::popc(sm);
+    }
     for (uint32_t k = lane; k < nr; k += W::WIDTH) {
       const uint32_t v = R[k];
       M.distmap[v] = GTS_DIST_UNSET;
-      inq[v] = 0;
+      dirty[v] = 0;
     }
     W::fence();
-    bool inexact = false, bad = false;
-    uint64_t qh2 = 0, qt = 1, pops = 0;
+    if (npeeled != nr) return false;
+    bool inexact = false, bad = false, changed = true;
+    uint64_t pops = 0;
     const uint64_t max_pops = 64ull * nr + 64;
-    TQ[0] = start;
+    dirty[start] = 1;
     W::fence();
-    while (qh2 < qt && !bad) {
-      const uint32_t u = W::uni(TQ[qh2 % nv]);
-      ++qh2;
-      if (++pops > max_pops) { bad = true; break; }
-      inq[u] = 0;
-      const bool du = (W::uni((uint32_t)orient[u]) & 3u) == 2;
-      const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
-      const uint32_t eb = eoff(u), ee = eoff(u + 1);
-      for (uint32_t base = eb; base < ee; base += W::WIDTH) {
-        const uint32_t ce = base + lane;
-        bool push = false;
-        uint32_t v = 0;
-        if (ce < ee && !gts_edge_is_marked(M.cstate[ce]) &&
-            ((M.cflags[ce] & GTS_F_SENSE) != 0) == du) {
-          v = M.cend[ce];
-          const int64_t w = M.cdist[ce];
-          const float cand = u == start ? (float)w : (float)(ndu + w);
-          const float old = M.distmap[v];
-          if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
-          if (old == GTS_DIST_UNSET || old > cand) {
-            M.distmap[v] = cand;
-            M.nd[v] = u == start ? w : (int64_t)cand;
-            push = inq[v] == 0;
-            if (push) inq[v] = 1;
+    while (changed && !bad) {
+      changed = false;
+      for (uint32_t base = 0; base < nr && !bad; base += W::WIDTH) {
+        const uint32_t k = base + lane;
+        uint32_t cv = 0;
+        if (k < nr) cv = TQ[k];
+        /* a vertex handled in this chunk may label a later one of the chunk */
+        uint32_t next_lane = 0;
+        while (!bad) {
+          const uint64_t dm = W::ballot(k < nr && lane >= next_lane && dirty[cv] != 0);
+          if (!dm) break;
+          const uint32_t l = W::ctz(dm);
+          next_lane = l + 1;
+          const uint32_t u = W::bcast(cv, l);
+          if (++pops > max_pops) { bad = true; break; }
+          dirty[u] = 0;
+          const bool du = (W::uni((uint32_t)orient[u]) & 3u) == 2;
+          const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
+          const uint32_t eb = eoff(u), ee = eoff(u + 1);
+          for (uint32_t eb2 = eb; eb2 < ee; eb2 += W::WIDTH) {
+            const uint32_t ce = eb2 + lane;
+            if (ce < ee && !gts_edge_is_marked(M.cstate[ce]) &&
+                ((M.cflags[ce] & GTS_F_SENSE) != 0) == du) {
+              const uint32_t v = M.cend[ce];
+              const int64_t w = M.cdist[ce];
+              const float cand = u == start ? (float)w : (float)(ndu + w);
+              const float old = M.distmap[v];
+              if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
+              if (old == GTS_DIST_UNSET || old > cand) {
+                M.distmap[v] = cand;
+                M.nd[v] = u == start ? w : (int64_t)cand;
+                dirty[v] = 1;
+              }
+            }
+            W::fence();
           }
         }
-        const uint64_t pm = W::ballot(push);
-        if (push) TQ[(qt + W::popc_below(pm, lane)) % nv] = v;
-        qt += W::popc(pm);
-        W::fence();
+      }
+      /* labels that moved behind the sweep: once more */
+      for (uint32_t base = 0; base < nr && !changed; base += W::WIDTH) {
+        const uint32_t k = base + lane;
+        changed = W::ballot(k < nr && dirty[TQ[k]] != 0) != 0;
       }
     }
+    npops += pops;
     if (W::ballot(inexact)) bad = true;
     if (bad) return false;
     /* FIFO search over the tight arcs */
@@ -1065,7 +1094,7 @@ struct GtsComponent {
       if (!bad && processed != nr) {
         /* the reachable states hold a cycle: labels by a queue-based
            relaxation, tie-breaks by a FIFO search over the tight arcs */
-        if (!walk_cyclic(start, nr, best_len, best_t)) { W::count(C.why + 6); bad = true; }
+        if (!walk_cyclic(start, nr, processed, best_len, best_t)) { W::count(C.why + 6); bad = true; }
       }
     }
     if (!bad && best_t != GTS_NONE && best_len > cc_len) {
@@ -1544,6 +1573,8 @@ struct GtsComponent {
       C.task_skip[t] = 1;
       if (err) C.cerr[c] = err;
       if (nfast) W::count_n(C.stat_fast + c, nfast);
+      W::add64(C.tstat + 5 * (uint64_t)c + 2, tfast);
+      W::add64(C.tstat + 5 * (uint64_t)c + 4, npops);
     }
     W::fence();
   }
@@ -1730,6 +1761,7 @@ struct GtsWave1 {
   static GTS_HD void count(unsigned long long *p) { ++*p; }
   static GTS_HD void count_n(uint32_t *p, uint32_t n) { *p += n; }
   static GTS_HD void or_bits(uint32_t *p, uint32_t m) { *p |= m; }
+  static GTS_HD void add64(uint64_t *p, uint64_t n) { *p += n; }
   static GTS_HD uint64_t alloc(unsigned long long *used, uint64_t n)
   { const uint64_t o = *used; *used += n; return o; }
   static GTS_HD uint32_t clz32(uint32_t v) { uint32_t n = 0; while (n < 32 && !(v & (0x80000000u >> n))) ++n; return n; }

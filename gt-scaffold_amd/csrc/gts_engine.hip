@@ -765,6 +765,8 @@ struct GtsWave64 {
   { if (lane() == 0) atomicAdd(p, 1ull); }
   static __device__ __forceinline__ void count_n(uint32_t *p, uint32_t n) { atomicAdd(p, n); }
   static __device__ __forceinline__ void or_bits(uint32_t *p, uint32_t m) { atomicOr(p, m); }
+  static __device__ __forceinline__ void add64(uint64_t *p, uint64_t n)
+  { atomicAdd((unsigned long long *)p, (unsigned long long)n); }
   static __device__ __forceinline__ uint32_t clz32(uint32_t v) { return (uint32_t)__clz((int)v); }
   /* inclusive prefix sum of values < 128: one ballot per bit, the lower-lane
      population count of each ballot weighted by the bit */
