@@ -71,7 +71,7 @@ struct GtsgEngine {
   /* options */
   int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
   int64_t walk_pool_entries = 1ll << 26;
-  int64_t defer_min_contigs = 96, walk_path_entries = 1ll << 24;
+  int64_t defer_min_contigs = 320, walk_path_entries = 1ll << 24;
   int64_t fast_walks = 1, lds_components = 1;
   int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
   /* profiling */
@@ -1693,10 +1693,13 @@ static int run_components(GtsgEngine *e, int mode)
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({kn[mode == GTS_MODE_MAKESCAFFOLD][k], _a, _b}); }
         HIPCHK(hipEventRecord(e->ev_join[k], ss));
-        HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
         e->stats[std::string("components_lds_class") + char('0' + k)] = kcount[k];
         first += kcount[k];
       }
+      /* joins after the last launch: a wait queued earlier would hold back a
+         side stream that shares its hardware queue with this stream */
+      for (uint32_t k = 0; k < nk; ++k)
+        if (kcount[k]) HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
       /* deferred walks (gts_component.hpp, try_defer): rounds of one workgroup
          per pending walk, grouped by LDS class, and an in-order select pass */
       uint64_t ntasks = 0, walks_run = 0;
@@ -1721,8 +1724,9 @@ static int run_components(GtsgEngine *e, int mode)
             k_walk_tasks<<<(uint32_t)pend[k], GTS_WAVE, klass_h[k], ss>>>(C, (uint32_t)k, (uint32_t)pend[k]);
             if (e->profile) { hipEventRecord(_b, ss); e->pending.push_back({"components_walk_tasks", _a, _b}); }
             HIPCHK(hipEventRecord(e->ev_join[k], ss));
-            HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
           }
+          for (uint32_t k = 0; k < nk; ++k)
+            if (pend[k]) HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
           HIPCHK(hipMemsetAsync(e->d_scalars + 152, 0, sizeof pend, e->st));
           LAUNCH("components_select_walks", k_select_walks, (uint32_t)ndef, GTS_WAVE, C, (uint32_t)ndef);
           HIPCHK(hipMemcpyAsync(pend, e->d_scalars + 152, sizeof pend, hipMemcpyDeviceToHost, e->st));
