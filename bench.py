@@ -303,7 +303,8 @@ def main():
                                                   "why_marked_end", "why_two_directions",
                                                   "why_inexact_tie", "why_cycle",
                                                   "why_inexact_length_tie")},
-                       walk_tasks=eng.stat("walk_tasks"), walk_task_runs=eng.stat("walk_task_runs"),
+                       walk_tasks=eng.stat("walk_tasks"), walk_task_rounds=eng.stat("walk_task_rounds"),
+                       walk_task_runs=eng.stat("walk_task_runs"),
                        deferred_components=eng.stat("deferred_components"),
                        slowest_components=[
                            {k: eng.stat("top%d_%s" % (r, k)) for k in

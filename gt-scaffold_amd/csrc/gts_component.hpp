@@ -99,16 +99,17 @@ struct GtsCompView {
   uint64_t *task_len, *task_poff;
   uint32_t *paths;           /* path_cap: pool for the tasks' bitmaps of labelled vertices
                                 (fixed at defer time) and their walks (component-local edges) */
+  uint32_t *comp_next_cc;    /* per deferred component: first cc not yet decided */
   uint64_t *task_roff;       /* task_cap: offset of the task's bitmap in paths */
+  uint64_t *comp_ring;       /* per component: 2 x u64, ring of select_walks' reference searches */
   const uint8_t *comp_klass; /* per component: LDS size class (launch group of its tasks) */
   uint32_t *tq;              /* task_cap: pending tasks, one segment per class */
   const uint32_t *tq_base;   /* per class: start of its segment */
   unsigned long long *tq_cnt;/* per class: pending tasks */
-  uint32_t *defer_list;      /* ncomp: the deferred components, one segment per class */
-  const uint32_t *dq_base;   /* per class: start of its segment */
-  unsigned long long *dq_cnt;/* per class: deferred components */
-  uint32_t *wbits;           /* nslots / 32 + ncomp + 1 words: finish_deferred's bitmap of
-                                component c starts at comp_off[c] / 32 + c */
+  uint32_t *defer_list;      /* ncomp: the deferred components */
+  unsigned long long *ndeferred;
+  uint32_t *wbits;           /* nslots / 32 + ncomp + 1 words: select_walks' bitmap of component c
+                                starts at comp_off[c] / 32 + c */
   uint32_t *stat_fast, *stat_slow;  /* per component: walks by path taken */
   unsigned long long *why;   /* [8] why walks left the linear path: mixed start,
                                 self arc, back at start, marked end, two
@@ -223,7 +224,7 @@ struct GtsComponent {
   bool reuse_cc;        /* makescaffold may use the ccs run() computed */
   uint32_t nodefer;     /* statistics: why try_defer declined */
   uint32_t *reach_bits; /* walk_task: bitmap of the vertices the walk labels */
-  bool no_reference;    /* walk_task: leave a walk that needs the reference search to finish_deferred */
+  bool no_reference;    /* walk_task: leave a walk that needs the reference search to select_walks */
   bool needs_reference;
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
@@ -1469,11 +1470,13 @@ struct GtsComponent {
      a walk computed BEFORE such marks is still the reference's walk as long
      as no revived arc starts at a vertex it labelled.
      The component program therefore stops after its terminal search and
-     publishes one task per terminal; all tasks run in parallel, one wave
-     each, against that published state (walk_task) and record the vertices
-     they label.  finish_deferred then takes the ccs in order, keeps a bitmap
-     of the vertices that gained an arc, and makes again, in place, only the
-     walks that labelled such a vertex. */
+     publishes one task per terminal.  Rounds of (all pending walks in
+     parallel, one wave each) + (select_walks: the ccs in order, one wave per
+     component) follow: select_walks keeps a bitmap of the vertices that
+     gained an arc in this pass, accepts a cc only if none of its walks
+     labelled such a vertex, and otherwise hands the ccs from there on to the
+     next round -- only the walks that did touch such a vertex run again.  The
+     first pending cc of a pass is always accepted, so the rounds end. */
   GTS_HD bool try_defer()
   {
     const uint32_t lane = W::lane();
@@ -1529,8 +1532,10 @@ struct GtsComponent {
       C.comp_task0[c] = (uint32_t)t0;
       C.comp_ncc[c] = ncc;
       C.comp_nterm[c] = nterm;
+      C.comp_next_cc[c] = 0;
+      C.comp_ring[2 * (uint64_t)c] = 0; C.comp_ring[2 * (uint64_t)c + 1] = 0;
     }
-    const uint64_t dl = C.dq_base[kl] + W::alloc(C.dq_cnt + kl, 1);
+    const uint64_t dl = W::alloc(C.ndeferred, 1);
     if (lane == 0) C.defer_list[dl] = c;
     W::fence();
     return true;
@@ -1555,7 +1560,7 @@ struct GtsComponent {
     create_walk(start, len, n);
     if (lane == 0) W::or_bits(reach_bits + (start >> 5), 1u << (start & 31));
     uint64_t po = 0;
-    if (needs_reference) { len = 0; n = GTS_NONE; }   /* finish_deferred makes this walk */
+    if (needs_reference) { len = 0; n = GTS_NONE; }   /* select_walks runs the reference search */
     else if (n) {
       po = W::alloc(C.path_used, n);
       if (po + n > C.path_cap) { err = GTS_CERR_WALKQ_OVERFLOW; n = 0; len = 0; }
@@ -1587,95 +1592,119 @@ struct GtsComponent {
     return hit;
   }
 
-  /* Second half of makescaffold for a deferred component (ref algorithms.c:
-     786-857), on a staged copy of its published state: the ccs in order; a
-     walk whose task result still holds is taken from the task, any other is
-     made here.  wb: scratch bitmap of the vertices that gained an arc. */
-  GTS_HD void finish_deferred(uint32_t *wb)
+  /* One pass over the pending ccs of a deferred component, in order: the
+     lonesome test of a cc with one terminal (algorithms.c:790-807), the first
+     strictly longest walk in terminal order (algorithms.c:823-832) and its
+     marks (algorithms.c:835-848).  Works on the global arrays only; wb is
+     the component's scratch bitmap.  Returns true when ccs are left for
+     another round. */
+  static GTS_HD bool select_walks(const GtsCompView &C, uint32_t c, uint32_t *wb)
   {
     const uint32_t lane = W::lane();
-    const uint32_t nw = (nv + 31) / 32;
-    const uint32_t t0 = C.comp_task0[c];
-    clean = W::uni((uint32_t)C.defer_flag[c]) == 2;
-    ncc = C.comp_ncc[c]; nterm = C.comp_nterm[c];
+    const uint32_t s0 = C.comp_off[c], e0g = C.coff[s0];
+    const uint32_t nv = C.comp_off[c + 1] - s0, nw = (nv + 31) / 32;
+    const uint32_t ncc = C.comp_ncc[c], t0 = C.comp_task0[c];
+    const uint32_t *ccoff = C.ccoff + s0 + c;
     for (uint32_t k = lane; k < nw; k += W::WIDTH) wb[k] = 0;
-    for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }
     W::fence();
-    auto ccoff = M.ccoff;
     bool revived_any = false;
-    uint32_t nredo = 0;
-    for (uint32_t i = 0; i < ncc && !err; ++i) {
+    uint32_t i = W::uni(C.comp_next_cc[c]);
+    for (; i < ncc; ++i) {
       const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
-      if (te - tb == 1) {                    /* algorithms.c:790-807 */
-        const uint32_t v = W::uni(M.term[tb]);
-        const uint32_t eb = eoff(v), ee = eoff(v + 1);
+      if (te - tb == 1) {
+        const uint32_t v = W::uni(C.term[s0 + tb]);
+        const uint32_t eb = W::uni(C.coff[s0 + v]), ee = W::uni(C.coff[s0 + v + 1]);
         bool any_live = false;
         for (uint32_t base = eb; base < ee; base += W::WIDTH) {
           const uint32_t ce = base + lane;
-          any_live |= W::ballot(ce < ee && !gts_edge_is_marked(M.cstate[ce])) != 0;
+          any_live |= W::ballot(ce < ee && !gts_edge_is_marked(C.cstate[ce])) != 0;
         }
-        if (!any_live) M.vst[v] = GIS_SCAFFOLD;
-        W::fence();
+        if (!any_live && lane == 0) C.G.vstate[C.slot_v[s0 + v]] = GIS_SCAFFOLD;
       }
       if (te - tb < 2) continue;
-      uint64_t cc_len = 0;
-      uint32_t cc_n = 0;
-      uint64_t src = ~0ull;   /* task that holds the best walk; ~0: cc_best */
-      for (uint32_t j = tb; j < te && !err; ++j) {
-        const uint64_t t = t0 + j;
-        const uint32_t tn = W::uni(C.task_n[t]);
-        if (tn != GTS_NONE && !(revived_any && task_touches(C, t, nv, wb))) {
-          const uint64_t len = (uint64_t)W::uni64((int64_t)C.task_len[t]);
-          if (len > cc_len) { cc_len = len; cc_n = tn; src = t; }   /* algorithms.c:823-832 */
-        } else {
-          const uint32_t before = cc_n;
-          const uint64_t lbefore = cc_len;
-          ++nredo;
-          if (!create_walk(W::uni(M.term[j]), cc_len, cc_n)) break;
-          if (cc_len != lbefore || cc_n != before) src = ~0ull;
+      bool stale = false;
+      if (revived_any)
+        for (uint32_t j = tb; j < te && !stale; ++j) stale = task_touches(C, t0 + j, nv, wb);
+      if (stale) break;
+      /* walks the tasks left to the reference search: here, in terminal
+         order, on the global arrays, with one ring per component */
+      for (uint32_t j = tb; j < te; ++j) {
+        if (W::uni(C.task_n[t0 + j]) != GTS_NONE) continue;
+        const GtsCompMem gm = GtsComponent<W, false>::global_mem(C, c);
+        GtsComponent<W, false> prog(C, gm, c);
+        prog.qbase = C.comp_ring[2 * (uint64_t)c]; prog.qcap = C.comp_ring[2 * (uint64_t)c + 1];
+        uint64_t len = 0;
+        uint32_t n = 0;
+        prog.create_walk_reference(W::uni(C.task_start[t0 + j]), len, n);
+        uint64_t po = 0;
+        if (n) {
+          po = W::alloc(C.path_used, n);
+          if (po + n > C.path_cap) { prog.err = GTS_CERR_WALKQ_OVERFLOW; n = 0; len = 0; }
+          for (uint32_t k = lane; k < n; k += W::WIDTH) C.paths[po + k] = prog.M.cc_best[k];
         }
-      }
-      if (err) break;
-      if (cc_n > 0) {                        /* algorithms.c:835-848 */
-        const uint64_t po = src == ~0ull ? 0 : C.task_poff[src];
-        bool revived = false;
-        for (uint32_t base = 0; base < cc_n; base += W::WIDTH) {
-          const uint32_t k = base + lane;
-          bool rv = false;
-          if (k < cc_n) {
-            const uint32_t ce = src == ~0ull ? (uint32_t)M.cc_best[k] : C.paths[po + k];
-            const uint32_t p = C.cgpos[e0g + ce], t = C.G.twin[p];
-            M.cstate[ce] = GIS_SCAFFOLD;
-            C.G.state[p] = GIS_SCAFFOLD;
-            C.G.state[t] = GIS_SCAFFOLD;
-            const uint32_t ct = C.cmap[t];
-            const uint32_t ve = M.cend[ce];
-            if (ct != GTS_NONE) {
-              if (gts_edge_is_marked(M.cstate[ct - e0g])) {   /* new arc out of ve */
-                rv = true;
-                W::or_bits(wb + (ve >> 5), 1u << (ve & 31));
-              }
-              M.cstate[ct - e0g] = GIS_SCAFFOLD;
-            }
-            M.vst[ve] = GIS_SCAFFOLD;
-            M.vst[M.cstart[ce]] = GIS_SCAFFOLD;
-          }
-          revived |= W::ballot(rv) != 0;
+        if (lane == 0) {
+          C.comp_ring[2 * (uint64_t)c] = prog.qbase; C.comp_ring[2 * (uint64_t)c + 1] = prog.qcap;
+          C.task_len[t0 + j] = len; C.task_n[t0 + j] = n; C.task_poff[t0 + j] = po;
+          if (prog.err) C.cerr[c] = prog.err;
+          W::count_n(C.stat_slow + c, 1);
         }
-        if (revived) { revived_any = true; clean = false; }
         W::fence();
       }
+      uint64_t best = 0;
+      uint32_t bj = GTS_NONE;
+      for (uint32_t j = tb; j < te; ++j) {
+        const uint64_t len = (uint64_t)W::uni64((int64_t)C.task_len[t0 + j]);
+        if (len > best) { best = len; bj = j; }
+      }
+      if (bj == GTS_NONE) continue;
+      const uint32_t n = W::uni(C.task_n[t0 + bj]);
+      const uint64_t po = C.task_poff[t0 + bj];
+      bool revived = false;
+      for (uint32_t base = 0; base < n; base += W::WIDTH) {
+        const uint32_t k = base + lane;
+        bool rv = false;
+        if (k < n) {
+          const uint32_t ce = C.paths[po + k];
+          const uint32_t p = C.cgpos[e0g + ce], t = C.G.twin[p];
+          C.G.state[p] = GIS_SCAFFOLD;
+          C.G.state[t] = GIS_SCAFFOLD;
+          C.cstate[e0g + ce] = GIS_SCAFFOLD;
+          const uint32_t ct = C.cmap[t];
+          const uint32_t ve = C.cend[e0g + ce];
+          if (ct != GTS_NONE) {
+            if (gts_edge_is_marked(C.cstate[ct])) {   /* new arc out of ve */
+              rv = true;
+              W::or_bits(wb + (ve >> 5), 1u << (ve & 31));
+            }
+            C.cstate[ct] = GIS_SCAFFOLD;
+          }
+          C.G.vstate[C.slot_v[s0 + ve]] = GIS_SCAFFOLD;
+          C.G.vstate[C.slot_v[s0 + C.cstart[e0g + ce]]] = GIS_SCAFFOLD;
+        }
+        revived |= W::ballot(rv) != 0;
+      }
+      revived_any |= revived;
+      W::fence();
     }
-    for (uint32_t s = lane; s < nv; s += W::WIDTH) C.G.vstate[C.slot_v[s0 + s]] = M.vst[s];
+    /* walks of the ccs left that labelled a vertex with a new arc run again */
+    for (uint32_t k = i; k < ncc; ++k) {
+      const uint32_t tb = W::uni(ccoff[k]), te = W::uni(ccoff[k + 1]);
+      if (te - tb < 2) continue;
+      for (uint32_t j = tb; j < te; ++j) {
+        /* (a walk left to the reference search is made when its cc is due) */
+        if (W::uni(C.task_n[t0 + j]) == GTS_NONE || !task_touches(C, t0 + j, nv, wb)) continue;
+        const uint32_t kl = W::uni((uint32_t)C.comp_klass[c]);
+        const uint64_t q = C.tq_base[kl] + W::alloc(C.tq_cnt + kl, 1);
+        if (lane == 0) { C.task_skip[t0 + j] = 0; C.tq[q] = t0 + j; }
+      }
+    }
     if (lane == 0) {
-      if (err) C.cerr[c] = err;
-      if (nfast) W::count_n(C.stat_fast + c, nfast);
-      if (nslow) W::count_n(C.stat_slow + c, nslow);
-      W::add64(C.tstat + 5 * (uint64_t)c + 1, nredo);
-      W::add64(C.tstat + 5 * (uint64_t)c + 2, tfast);
-      W::add64(C.tstat + 5 * (uint64_t)c + 3, tslow);
+      C.comp_next_cc[c] = i;
+      /* new arcs: the sweep order of a clean component is void */
+      C.defer_flag[c] = i == ncc ? 0 : (revived_any ? 1 : C.defer_flag[c]);
     }
     W::fence();
+    return i < ncc;
   }
 
   GTS_HD void run(int mode)

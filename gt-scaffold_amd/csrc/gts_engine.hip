@@ -71,7 +71,6 @@ struct GtsgEngine {
   /* options */
   int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
   int64_t walk_pool_entries = 1ll << 26;
-  int64_t class_streams = 3;
   int64_t defer_min_contigs = 320, walk_path_entries = 1ll << 24;
   int64_t fast_walks = 1, lds_components = 1;
   int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
@@ -253,42 +252,38 @@ __global__ void k_pair_keys(const uint32_t *root, const uint32_t *ctg,
   if (k >= nrec) return;
   uint32_t a = root[k], b = ctg[k];
   uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-  /* bit 63 (contig ids stay below 2^31, no sorting pass looks at it): the
-     record is listed from the smaller contig */
-  keys[k] = ((uint64_t)hi << 32) | lo | (a <= b ? 1ull << 63 : 0ull);
+  keys[k] = ((uint64_t)hi << 32) | lo;
   vals[k] = (uint32_t)k;
 }
 
-/* One thread per sorted position.  Records of one contig pair are adjacent,
-   in file order: the first creates both edges, a later record listed from the
-   same root replaces the estimate of "its" direction when its std_dev is
-   strictly larger (ref parser.c:359-366, graph.c:219-235).  Nearly every pair
-   is listed once, so the per-record results start out as "creator, both
-   directions from this record" (is_creator = 1, winners = GTS_NONE, set by
-   the caller) and only the records of repeated pairs are touched here. */
+/* One thread per sorted position; the head of a key segment folds the
+   segment (records of one contig pair in file order): the first record
+   creates both edges, a later record listed from the same root replaces the
+   estimate of "its" direction when its std_dev is strictly larger
+   (ref parser.c:359-366, graph.c:219-235). */
 __global__ void k_pair_segments(const uint64_t *keys, const uint32_t *recs,
-                                const float *sd, uint32_t *is_creator,
-                                uint32_t *fwd_win, uint32_t *bwd_win, uint64_t nrec)
+                                const uint32_t *root, const float *sd,
+                                uint32_t *is_creator, uint32_t *fwd_win,
+                                uint32_t *bwd_win, uint64_t nrec)
 {
-  const uint64_t PAIR = ~(1ull << 63);
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrec) return;
   const uint64_t key = keys[i];
-  if (i > 0 && ((keys[i - 1] ^ key) & PAIR) == 0) { is_creator[recs[i]] = 0; return; }
-  if (i + 1 >= nrec || ((keys[i + 1] ^ key) & PAIR) != 0) return;
+  if (i > 0 && keys[i - 1] == key) return;
   const uint32_t k0 = recs[i];
-  const bool selfloop = (uint32_t)(key >> 32 & 0x7FFFFFFFu) == (uint32_t)key;
+  const uint32_t r0 = root[k0];
+  const bool selfloop = (uint32_t)(key >> 32) == (uint32_t)key;
   uint32_t fw = k0, bw = k0;
   float fsd = sd[k0], bsd = fsd;
-  for (uint64_t j = i + 1; j < nrec; ++j) {
-    const uint64_t kj = keys[j];
-    if (((kj ^ key) & PAIR) != 0) break;
+  for (uint64_t j = i + 1; j < nrec && keys[j] == key; ++j) {
     const uint32_t k = recs[j];
     const float s = sd[k];
-    if (selfloop || ((kj ^ key) >> 63) == 0) { if (fsd < s) { fsd = s; fw = k; } }   /* same root */
+    if (selfloop || root[k] == r0) { if (fsd < s) { fsd = s; fw = k; } }
     else { if (bsd < s) { bsd = s; bw = k; } }
   }
-  if (fw != k0 || bw != k0) { fwd_win[k0] = fw; bwd_win[k0] = bw; }
+  is_creator[k0] = 1;
+  fwd_win[k0] = fw;
+  bwd_win[k0] = bw;
 }
 
 struct __attribute__((aligned(32))) GtsEdgeRec {
@@ -311,8 +306,7 @@ __global__ void k_emit_edges(const uint32_t *is_creator, const uint32_t *jidx,
   if (k >= nrec || !is_creator[k]) return;
   const uint64_t e0 = 2ull * jidx[k];
   const uint32_t r = root[k], c = ctg[k];
-  uint32_t fw = fwd_win[k], bw = bwd_win[k];
-  if (fw == GTS_NONE) { fw = (uint32_t)k; bw = (uint32_t)k; }   /* pair listed once */
+  const uint32_t fw = fwd_win[k], bw = bwd_win[k];
   GtsEdgeRec a, b;
   a.dist = dist[fw]; a.npairs = npairs ? npairs[fw] : 0; a.end = c;
   a.sd = sd[fw]; a.flags = flags[fw] & 3u; a.pad = 0;
@@ -870,11 +864,8 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
     M.lastpop[i] = 0; M.distmap[i] = GTS_DIST_UNSET; M.st_dir[i] = 0; M.tight[i] = 0;
     if (with_analysis) {
       M.gorient[i] = G0.gorient[i]; M.topo[i] = (idx_t)G0.topo[i]; M.tpos[i] = (idx_t)G0.tpos[i];
-      M.term[i] = (idx_t)G0.term[i];
     }
   }
-  if (with_analysis)
-    for (uint32_t i = lane; i <= nv; i += GTS_WAVE) M.ccoff[i] = (idx_t)G0.ccoff[i];
   for (uint32_t i = lane; i < ne; i += GTS_WAVE) {
     cstart[i] = (idx_t)G0.cstart[i]; cend[i] = (idx_t)G0.cend[i]; cdist[i] = (int32_t)G0.cdist[i];
     M.cflags[i] = G0.cflags[i]; M.cstate[i] = G0.cstate[i];
@@ -910,18 +901,13 @@ k_walk_tasks(GtsCompView C, uint32_t klass, uint32_t count)
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.walk_task(t);
 }
-/* second half of makescaffold for the deferred components of one LDS class
-   (gts_component.hpp, finish_deferred) */
 __global__ void __launch_bounds__(GTS_WAVE)
-k_finish_deferred(GtsCompView C, uint32_t klass, uint32_t count)
+k_select_walks(GtsCompView C, uint32_t ndeferred)
 {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (blockIdx.x >= count) return;
-  const uint32_t c = C.defer_list[C.dq_base[klass] + blockIdx.x];
-  GtsCompMemT<true> M;
-  stage_component(C, c, smem, M, true);
-  GtsComponent<GtsWave64, true> prog(C, M, c);
-  prog.finish_deferred(C.wbits + C.comp_off[c] / 32 + c);
+  if (blockIdx.x >= ndeferred) return;
+  const uint32_t c = C.defer_list[blockIdx.x];
+  if (!C.defer_flag[c]) return;
+  GtsComponent<GtsWave64, false>::select_walks(C, c, C.wbits + C.comp_off[c] / 32 + c);
 }
 /* LDS footprint of every component as a descending sort key, and how many
    components fit each size class */
@@ -966,14 +952,10 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
 }
 /* start of every class' segment of the pending-task array: a class has at most
    as many tasks as its components have vertices */
-__global__ void k_task_queue_bases(const uint32_t *klass_slots, const uint32_t *klass_count,
-                                   uint32_t *tq_base, uint32_t *dq_base)
+__global__ void k_task_queue_bases(const uint32_t *klass_slots, uint32_t *tq_base)
 {
-  uint32_t acc = 0, dacc = 0;
-  for (int k = 0; k <= GTS_NKLASS; ++k) {
-    tq_base[k] = acc; acc += klass_slots[k];
-    dq_base[k] = dacc; dacc += klass_count[k];
-  }
+  uint32_t acc = 0;
+  for (int k = 0; k <= GTS_NKLASS; ++k) { tq_base[k] = acc; acc += klass_slots[k]; }
 }
 __global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
                                uint32_t *out /* [0]=overflow, [1]=loop */)
@@ -1105,10 +1087,6 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
       delete e; return GTSG_EHIP;
     }
   if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { delete e; return GTSG_EHIP; }
-  if (hipFuncSetAttribute((const void *)k_finish_deferred,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
-    delete e; return GTSG_EHIP;
-  }
   if (hipFuncSetAttribute((const void *)k_walk_tasks,
                           hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
     delete e; return GTSG_EHIP;
@@ -1165,7 +1143,6 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "fast_walks")) e->fast_walks = value != 0;
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
-  else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NKLASS) e->class_streams = value;
   else if (!strcmp(name, "walk_path_entries") && value >= 1) e->walk_path_entries = value;
   else if (!strcmp(name, "profile")) e->profile = (int)value;
   else return fail(e, GTSG_EINVAL, "unknown option %s", name);
@@ -1262,10 +1239,9 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
     PALLOC(t_jidx, uint32_t, nrec);
     PALLOC(sctmp, uint32_t, gts_scan_tmp_elems(nrec));
     fwd = t_fwd; bwd = t_bwd; jidx = t_jidx;
-    LAUNCH("fill", k_fill<uint32_t>, nblk(nrec), GTS_BLOCK, is_creator, 1u, (uint64_t)nrec);
-    HIPCHK(hipMemsetAsync(fwd, 0xFF, nrec * 4, e->st));
-    LAUNCH("build_pair_segments", k_pair_segments, nblk(nrec), GTS_BLOCK, ks, vs, d_sd,
-           is_creator, fwd, bwd, nrec);
+    HIPCHK(hipMemsetAsync(is_creator, 0, nrec * 4, e->st));
+    LAUNCH("build_pair_segments", k_pair_segments, nblk(nrec), GTS_BLOCK, ks, vs, d_root,
+           d_sd, is_creator, fwd, bwd, nrec);
     { ProfScope ps(e, "build_scan_creators");
       gts_exscan<uint32_t, uint32_t>(is_creator, jidx, nrec, sctmp, e->d_scalars, e->st); }
     if ((rc = read_u32(e, e->d_scalars, &npairs_created))) return rc;
@@ -1619,8 +1595,8 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(task_n, uint32_t, task_cap); PALLOC(task_skip, uint8_t, task_cap);
     PALLOC(task_len, uint64_t, task_cap); PALLOC(task_poff, uint64_t, task_cap);
     PALLOC(task_paths, uint32_t, path_cap + 1);
-    PALLOC(wbits, uint32_t, (size_t)nslots / 32 + ncomp + 2);
-    PALLOC(task_roff, uint64_t, task_cap);
+    PALLOC(comp_next_cc, uint32_t, ncomp); PALLOC(wbits, uint32_t, (size_t)nslots / 32 + ncomp + 2);
+    PALLOC(task_roff, uint64_t, task_cap); PALLOC(comp_ring, uint64_t, 2 * (size_t)ncomp);
     PALLOC(tq, uint32_t, task_cap + 1); PALLOC(defer_list, uint32_t, (size_t)ncomp + 1);
     HIPCHK(hipMemsetAsync(defer_flag, 0, (size_t)ncomp + 1, e->st));
     HIPCHK(hipMemsetAsync(e->d_scalars + 128, 0, 16, e->st));
@@ -1639,12 +1615,11 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, sizeof klass_h, hipMemcpyHostToDevice, e->st));
     HIPCHK(hipMemsetAsync(klass_count, 0, (GTS_NKLASS + 1) * 4, e->st));
     HIPCHK(hipMemsetAsync(e->d_scalars + 112, 0, (GTS_NKLASS + 1) * 8, e->st));
-    HIPCHK(hipMemsetAsync(e->d_scalars + 136, 0, (192 - 136) * 4, e->st));
+    HIPCHK(hipMemsetAsync(e->d_scalars + 136, 0, (170 - 136) * 4, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
            ncomp, comp_wide, comp_klass, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
            (unsigned long long *)(e->d_scalars + 112), e->d_scalars + 136);
-    LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + 136, klass_count,
-           e->d_scalars + 144, e->d_scalars + 184);
+    LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + 136, e->d_scalars + 144);
     const uint32_t *order;
     {
       int shifts[4] = {0, 8, 16, 24};
@@ -1678,11 +1653,10 @@ static int run_components(GtsgEngine *e, int mode)
     C.task_cap = task_cap; C.path_cap = path_cap;
     C.task_comp = task_comp; C.task_start = task_start; C.task_n = task_n; C.task_skip = task_skip;
     C.task_len = task_len; C.task_poff = task_poff; C.paths = task_paths;
-    C.wbits = wbits;
-    C.task_roff = task_roff; C.comp_klass = comp_klass; C.tq = tq;
+    C.comp_next_cc = comp_next_cc; C.wbits = wbits;
+    C.task_roff = task_roff; C.comp_ring = comp_ring; C.comp_klass = comp_klass; C.tq = tq;
     C.tq_base = e->d_scalars + 144; C.tq_cnt = (unsigned long long *)(e->d_scalars + 152);
-    C.defer_list = defer_list; C.dq_base = e->d_scalars + 184;
-    C.dq_cnt = (unsigned long long *)(e->d_scalars + 168);
+    C.defer_list = defer_list; C.ndeferred = (unsigned long long *)(e->d_scalars + 168);
     C.why = (unsigned long long *)(e->d_scalars + 96);
     HIPCHK(hipMemsetAsync(C.why, 0, 64, e->st));
     {
@@ -1711,7 +1685,7 @@ static int run_components(GtsgEngine *e, int mode)
             {"components_makescaffold_lds4k", "components_makescaffold_lds8k",
              "components_makescaffold_lds16k", "components_makescaffold_lds32k",
              "components_makescaffold_lds64k", "components_makescaffold_lds160k"}};
-        hipStream_t ss = e->side[((int)nk - 1 - k) % (int)e->class_streams];
+        hipStream_t ss = e->side[((int)nk - 1 - k) % 3];
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
@@ -1726,39 +1700,40 @@ static int run_components(GtsgEngine *e, int mode)
          side stream that shares its hardware queue with this stream */
       for (uint32_t k = 0; k < nk; ++k)
         if (kcount[k]) HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
-      /* deferred walks (gts_component.hpp, try_defer): one workgroup per walk,
-         then one per deferred component that decides the ccs in order */
+      /* deferred walks (gts_component.hpp, try_defer): rounds of one workgroup
+         per pending walk, grouped by LDS class, and an in-order select pass */
       uint64_t ntasks = 0, walks_run = 0;
+      uint32_t rounds = 0;
       if (C.defer_min_nv) {
-        uint64_t pend[2 * (GTS_NKLASS + 1) + 2];   /* tq_cnt[7], pad, dq_cnt[7] */
-        HIPCHK(hipMemcpyAsync(pend, e->d_scalars + 152, (182 - 152) * 4, hipMemcpyDeviceToHost, e->st));
+        uint64_t pend[GTS_NKLASS + 1], ndef = 0;
+        HIPCHK(hipMemcpyAsync(pend, e->d_scalars + 152, sizeof pend, hipMemcpyDeviceToHost, e->st));
+        HIPCHK(hipMemcpyAsync(&ndef, e->d_scalars + 168, 8, hipMemcpyDeviceToHost, e->st));
         if ((rc = read_u64(e, (uint64_t *)(e->d_scalars + 128), &ntasks))) return rc;
-        const uint64_t *ndef = pend + 8;
-        for (int phase = 0; phase < 2; ++phase) {
-          const uint64_t *cnt = phase ? ndef : pend;
+        for (;; ++rounds) {
           uint64_t total = 0;
-          for (uint32_t k = 0; k < nk; ++k) total += cnt[k];
+          for (uint32_t k = 0; k < nk; ++k) total += pend[k];
           if (!total) break;
-          if (!phase) walks_run = total;
+          walks_run += total;
           HIPCHK(hipEventRecord(e->ev_fork, e->st));
           for (int k = (int)nk - 1; k >= 0; --k) {
-            if (!cnt[k]) continue;
-            hipStream_t ss = e->side[((int)nk - 1 - k) % (int)e->class_streams];
+            if (!pend[k]) continue;
+            hipStream_t ss = e->side[((int)nk - 1 - k) % 3];
             HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
             hipEvent_t _a = nullptr, _b = nullptr;
             if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
-            if (!phase)
-              k_walk_tasks<<<(uint32_t)cnt[k], GTS_WAVE, klass_h[k], ss>>>(C, (uint32_t)k, (uint32_t)cnt[k]);
-            else
-              k_finish_deferred<<<(uint32_t)cnt[k], GTS_WAVE, klass_h[k], ss>>>(C, (uint32_t)k, (uint32_t)cnt[k]);
-            if (e->profile) { hipEventRecord(_b, ss);
-                              e->pending.push_back({phase ? "components_finish_deferred" : "components_walk_tasks", _a, _b}); }
+            k_walk_tasks<<<(uint32_t)pend[k], GTS_WAVE, klass_h[k], ss>>>(C, (uint32_t)k, (uint32_t)pend[k]);
+            if (e->profile) { hipEventRecord(_b, ss); e->pending.push_back({"components_walk_tasks", _a, _b}); }
             HIPCHK(hipEventRecord(e->ev_join[k], ss));
           }
           for (uint32_t k = 0; k < nk; ++k)
-            if (cnt[k]) HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
+            if (pend[k]) HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
+          HIPCHK(hipMemsetAsync(e->d_scalars + 152, 0, sizeof pend, e->st));
+          LAUNCH("components_select_walks", k_select_walks, (uint32_t)ndef, GTS_WAVE, C, (uint32_t)ndef);
+          HIPCHK(hipMemcpyAsync(pend, e->d_scalars + 152, sizeof pend, hipMemcpyDeviceToHost, e->st));
+          if ((rc = sync_stream(e))) return rc;
         }
       }
+      e->stats["walk_task_rounds"] = rounds;
       e->stats["walk_task_runs"] = (int64_t)walks_run;
       e->stats["walk_tasks"] = (int64_t)ntasks;
       e->stats["components_global_mem"] = kcount[nk];

@@ -118,7 +118,7 @@ class HostSimGraph:
         self.ncomp, self.maxcomp = nc.value, mc.value
         self.fast_walks, self.slow_walks, self.clean_components = nf.value, ns.value, ncl.value
         self.deferred_components = ndf.value
-        self.walks_made_again = nrd.value
+        self.walk_task_rounds = nrd.value
         return nerr
 
     def removecycles(self, **kw):

@@ -251,43 +251,40 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   C.task_comp = task_comp.data(); C.task_start = task_start.data(); C.task_n = task_n.data();
   C.task_skip = task_skip.data(); C.task_len = task_len.data(); C.task_poff = task_poff.data();
   C.paths = paths.data();
-  std::vector<uint32_t> wbits(S / 32 + ncomp + 2, 0);
-  C.wbits = wbits.data();
+  std::vector<uint32_t> comp_next_cc(ncomp ? ncomp : 1, 0), wbits(S / 32 + ncomp + 2, 0);
+  C.comp_next_cc = comp_next_cc.data(); C.wbits = wbits.data();
   /* one class in the harness */
-  std::vector<uint64_t> task_roff(S);
+  std::vector<uint64_t> task_roff(S), comp_ring(2 * (size_t)(ncomp ? ncomp : 1), 0);
   std::vector<uint8_t> comp_klass(ncomp ? ncomp : 1, 0);
   std::vector<uint32_t> tq(S + 1), defer_list(ncomp ? ncomp : 1);
-  uint32_t tq_base[1] = {0}, dq_base[1] = {0};
-  unsigned long long tq_cnt[1] = {0}, dq_cnt[1] = {0};
-  C.task_roff = task_roff.data(); C.comp_klass = comp_klass.data();
+  uint32_t tq_base[1] = {0};
+  unsigned long long tq_cnt[1] = {0}, ndeferred = 0;
+  C.task_roff = task_roff.data(); C.comp_ring = comp_ring.data(); C.comp_klass = comp_klass.data();
   C.tq = tq.data(); C.tq_base = tq_base; C.tq_cnt = tq_cnt; C.defer_list = defer_list.data();
-  C.dq_base = dq_base; C.dq_cnt = dq_cnt;
+  C.ndeferred = &ndeferred;
   uint32_t nerr = 0;
   for (uint32_t c = 0; c < ncomp; c++) {
     GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
     GtsComponent<GtsWave1> prog(C, mem, c);
     prog.run(mode);
   }
-  const uint64_t ndefer = dq_cnt[0];
-  for (uint64_t q = 0; q < tq_cnt[0]; q++) {
-    const uint32_t t = tq[q], c = task_comp[t];
-    GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
-    GtsComponent<GtsWave1> prog(C, mem, c);
-    wq_used = 0;   /* serial harness: the ring of the previous program is free again */
-    prog.walk_task(t);
-  }
-  uint64_t redone = 0;
-  for (uint64_t d = 0; d < ndefer; d++) {
-    const uint32_t c = defer_list[d];
-    GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
-    GtsComponent<GtsWave1> prog(C, mem, c);
-    wq_used = 0;
-    const uint64_t before = tstat[5 * (size_t)c + 1];
-    prog.finish_deferred(wbits.data() + comp_off[c] / 32 + c);
-    redone += tstat[5 * (size_t)c + 1] - before;
+  uint64_t ndefer = ndeferred, rounds = 0;
+  for (;; rounds++) {
+    if (!tq_cnt[0]) break;
+    for (uint64_t q = 0; q < tq_cnt[0]; q++) {
+      const uint32_t t = tq[q], c = task_comp[t];
+      GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
+      GtsComponent<GtsWave1> prog(C, mem, c);
+      prog.walk_task(t);
+    }
+    tq_cnt[0] = 0;
+    for (uint64_t d = 0; d < ndeferred; d++) {
+      const uint32_t c = defer_list[d];
+      if (defer_flag[c]) GtsComponent<GtsWave1>::select_walks(C, c, wbits.data() + comp_off[c] / 32 + c);
+    }
   }
   for (uint32_t c = 0; c < ncomp; c++) if (cerr[c]) nerr++;
-  if (out_rounds) *out_rounds = redone;
+  if (out_rounds) *out_rounds = rounds;
   if (out_deferred) *out_deferred = ndefer;
   uint64_t tf = 0, ts = 0;
   for (uint32_t c = 0; c < ncomp; c++) { tf += sf[c]; ts += ss[c]; }

@@ -130,8 +130,8 @@ def test_cyclic_state_graphs_take_the_queue_relaxation_path(seed):
 @pytest.mark.parametrize("seed", range(8))
 def test_deferred_walks_give_the_same_scaffolds(seed):
     # large components hand their walks to separate tasks (one per terminal) and
-    # a finishing pass that takes the ccs in order and makes again the walks a
-    # revived twin could have changed.  Forced here for every component
+    # a select pass that takes the ccs in order; walks that a revived twin could
+    # have changed run again in the next round.  Forced here for every component
     # with at least 2 vertices, clean or not (odd seeds: inversions, relisted
     # pairs; seeds 4-7: the benchmark's link density)
     kw = dict(p_chimeric=0.05, p_inversion=1.0 * (seed % 2), p_bubble=0.04, p_relist=0.05 * (seed % 2))
@@ -143,7 +143,7 @@ def test_deferred_walks_give_the_same_scaffolds(seed):
     og.mark_repeats(); hs.mark_repeats(); og.filter(); hs.filter()
     og.makescaffold(True)
     assert hs.makescaffold(fast_walks=1, defer_min_nv=2) == 0
-    assert hs.deferred_components > 10 and hs.walks_made_again >= 1
+    assert hs.deferred_components > 10 and hs.walk_task_rounds >= 1
     if seed == 1:
         assert hs.slow_walks > 0   # tasks that fall back to the reference search
     assert np.array_equal(og.vertex_states(), hs.vertex_states())
