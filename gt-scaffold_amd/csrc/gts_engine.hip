@@ -252,38 +252,43 @@ __global__ void k_pair_keys(const uint32_t *root, const uint32_t *ctg,
   if (k >= nrec) return;
   uint32_t a = root[k], b = ctg[k];
   uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-  keys[k] = ((uint64_t)hi << 32) | lo;
+  /* bit 63 (contig ids stay below 2^31, no sorting pass looks at it): the
+     record is listed from the smaller contig */
+  keys[k] = ((uint64_t)hi << 32) | lo | (a <= b ? 1ull << 63 : 0ull);
   vals[k] = (uint32_t)k;
 }
 
-/* One thread per sorted position; the head of a key segment folds the
-   segment (records of one contig pair in file order): the first record
-   creates both edges, a later record listed from the same root replaces the
-   estimate of "its" direction when its std_dev is strictly larger
-   (ref parser.c:359-366, graph.c:219-235). */
+/* One thread per sorted position.  Records of one contig pair are adjacent,
+   in file order: the first creates both edges, a later record listed from the
+   same root replaces the estimate of "its" direction when its std_dev is
+   strictly larger (ref parser.c:359-366, graph.c:219-235).  The per-record
+   results start out as "creator, both directions from this record"
+   (is_creator = 1, winners = GTS_NONE, set by the caller); only later records
+   of a pair and creators that lose a direction are written here, and which
+   root a record was listed from is read off bit 63 of its key. */
 __global__ void k_pair_segments(const uint64_t *keys, const uint32_t *recs,
-                                const uint32_t *root, const float *sd,
-                                uint32_t *is_creator, uint32_t *fwd_win,
-                                uint32_t *bwd_win, uint64_t nrec)
+                                const float *sd, uint32_t *is_creator,
+                                uint32_t *fwd_win, uint32_t *bwd_win, uint64_t nrec)
 {
+  const uint64_t PAIR = ~(1ull << 63);
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrec) return;
   const uint64_t key = keys[i];
-  if (i > 0 && keys[i - 1] == key) return;
+  if (i > 0 && ((keys[i - 1] ^ key) & PAIR) == 0) { is_creator[recs[i]] = 0; return; }
+  if (i + 1 >= nrec || ((keys[i + 1] ^ key) & PAIR) != 0) return;
   const uint32_t k0 = recs[i];
-  const uint32_t r0 = root[k0];
-  const bool selfloop = (uint32_t)(key >> 32) == (uint32_t)key;
+  const bool selfloop = (uint32_t)(key >> 32 & 0x7FFFFFFFu) == (uint32_t)key;
   uint32_t fw = k0, bw = k0;
   float fsd = sd[k0], bsd = fsd;
-  for (uint64_t j = i + 1; j < nrec && keys[j] == key; ++j) {
+  for (uint64_t j = i + 1; j < nrec; ++j) {
+    const uint64_t kj = keys[j];
+    if (((kj ^ key) & PAIR) != 0) break;
     const uint32_t k = recs[j];
     const float s = sd[k];
-    if (selfloop || root[k] == r0) { if (fsd < s) { fsd = s; fw = k; } }
+    if (selfloop || ((kj ^ key) >> 63) == 0) { if (fsd < s) { fsd = s; fw = k; } }   /* same root */
     else { if (bsd < s) { bsd = s; bw = k; } }
   }
-  is_creator[k0] = 1;
-  fwd_win[k0] = fw;
-  bwd_win[k0] = bw;
+  if (fw != k0 || bw != k0) { fwd_win[k0] = fw; bwd_win[k0] = bw; }
 }
 
 struct __attribute__((aligned(32))) GtsEdgeRec {
@@ -306,7 +311,8 @@ __global__ void k_emit_edges(const uint32_t *is_creator, const uint32_t *jidx,
   if (k >= nrec || !is_creator[k]) return;
   const uint64_t e0 = 2ull * jidx[k];
   const uint32_t r = root[k], c = ctg[k];
-  const uint32_t fw = fwd_win[k], bw = bwd_win[k];
+  uint32_t fw = fwd_win[k], bw = bwd_win[k];
+  if (fw == GTS_NONE) { fw = (uint32_t)k; bw = (uint32_t)k; }   /* nothing replaced */
   GtsEdgeRec a, b;
   a.dist = dist[fw]; a.npairs = npairs ? npairs[fw] : 0; a.end = c;
   a.sd = sd[fw]; a.flags = flags[fw] & 3u; a.pad = 0;
@@ -1239,9 +1245,10 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
     PALLOC(t_jidx, uint32_t, nrec);
     PALLOC(sctmp, uint32_t, gts_scan_tmp_elems(nrec));
     fwd = t_fwd; bwd = t_bwd; jidx = t_jidx;
-    HIPCHK(hipMemsetAsync(is_creator, 0, nrec * 4, e->st));
-    LAUNCH("build_pair_segments", k_pair_segments, nblk(nrec), GTS_BLOCK, ks, vs, d_root,
-           d_sd, is_creator, fwd, bwd, nrec);
+    LAUNCH("fill", k_fill<uint32_t>, nblk(nrec), GTS_BLOCK, is_creator, 1u, (uint64_t)nrec);
+    HIPCHK(hipMemsetAsync(fwd, 0xFF, nrec * 4, e->st));
+    LAUNCH("build_pair_segments", k_pair_segments, nblk(nrec), GTS_BLOCK, ks, vs, d_sd,
+           is_creator, fwd, bwd, nrec);
     { ProfScope ps(e, "build_scan_creators");
       gts_exscan<uint32_t, uint32_t>(is_creator, jidx, nrec, sctmp, e->d_scalars, e->st); }
     if ((rc = read_u32(e, e->d_scalars, &npairs_created))) return rc;
