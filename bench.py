@@ -36,6 +36,10 @@ CUTS = dict(copy_num_cutoff=0.3, astat_cutoff=20.0, pcutoff=0.01, cncutoff=1.5, 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 
 
+# dynamic LDS of the component launches (gts_engine.hip, gts_klass_bytes)
+LDS_CLASSES_KB = (4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 160)
+
+
 def algorithmic_bytes(name, n, m, nrec, eng):
     """Algorithmic HBM bytes of ONE launch of a kernel ('Kernels'):
     every input element read once, every output element written once."""
@@ -47,7 +51,7 @@ def algorithmic_bytes(name, n, m, nrec, eng):
         "build_sort_pairs": 2 * vb * nrec * (8 + (8 + 4) + (8 + 4)),
         "build_sort_csr": vb * m * (4 + (4 + 4) + (4 + 4)),
         "build_pair_keys": nrec * (8 + 12),
-        "build_pair_segments": nrec * (12 + 4 + 4),
+        "build_pair_segments": nrec * (12 + 4 + 2),
         "build_emit_edges": nrec * 8 + m * (29 + 36),
         "build_gather_csr": m * (4 + 32 + 30),
         "build_twins": m * 12,
@@ -61,8 +65,8 @@ def algorithmic_bytes(name, n, m, nrec, eng):
     # component programs: the compact graph + vertex records of the components
     # the launch handles, read once; states and marks written once
     klass = {"components_makescaffold": "bytes_components_global_mem"}
-    for i, tag in enumerate(("4k", "8k", "16k", "32k", "64k", "160k")):
-        klass["components_makescaffold_lds" + tag] = "bytes_components_lds_class%d" % i
+    for i, kb in enumerate(LDS_CLASSES_KB):
+        klass["components_makescaffold_lds%dk" % kb] = "bytes_components_lds_class%d" % i
     if name in klass:
         return max(eng.stat(klass[name]), 0)
     return table.get(name)
@@ -292,7 +296,8 @@ def main():
                    component_kernel=dict(
                        walks_fast=eng.stat("fast_walks"), walks_reference=eng.stat("slow_walks"),
                        clean_components=eng.stat("clean_components"),
-                       components_per_lds_class=[eng.stat("components_lds_class%d" % i) for i in range(6)],
+                       components_per_lds_class={"%dk" % kb: eng.stat("components_lds_class%d" % i)
+                                                 for i, kb in enumerate(LDS_CLASSES_KB)},
                        components_global_mem=eng.stat("components_global_mem"),
                        **{k: eng.stat(k) for k in
                           ("us_sum_removecycles", "us_max_removecycles", "us_sum_makescaffold_other",

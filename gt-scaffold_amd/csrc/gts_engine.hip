@@ -26,7 +26,19 @@
 #include <string>
 #include <vector>
 
-#define GTS_NKLASS 6
+#define GTS_NKLASS 11
+/* LDS size classes of the component launches (bytes of dynamic LDS) */
+static const uint32_t gts_klass_bytes[GTS_NKLASS] = {4096, 6144, 8192, 12288, 16384, 24576, 32768,
+                                                    49152, 65536, 98304, 163840};
+#define GTS_NSTREAMS 6
+/* device scalars of the class bookkeeping (u32 index into d_scalars, 16 entries each) */
+#define GTS_S_KSIZE 256
+#define GTS_S_KCOUNT 272
+#define GTS_S_KBYTES 288   /* u64 */
+#define GTS_S_KSLOTS 320
+#define GTS_S_TQBASE 336
+#define GTS_S_TQCNT 352    /* u64 */
+#define GTS_S_NDEF 384     /* u64 */
 
 #include "../../include/gt_scaffold_hip.h"
 #include "gts_amb_host.h"
@@ -42,7 +54,7 @@ struct GtsgEngine {
   int device = 0;
   hipStream_t st = nullptr;
   bool own_stream = false;
-  hipStream_t side[GTS_NKLASS] = {};  /* class launches */
+  hipStream_t side[GTS_NSTREAMS] = {};  /* class launches */
   hipEvent_t ev_fork = nullptr, ev_join[GTS_NKLASS] = {};
   std::string err;
   /* vertices */
@@ -71,6 +83,7 @@ struct GtsgEngine {
   /* options */
   int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
   int64_t walk_pool_entries = 1ll << 26;
+  int64_t class_streams = GTS_NSTREAMS;
   int64_t defer_min_contigs = 320, walk_path_entries = 1ll << 24;
   int64_t fast_walks = 1, lds_components = 1;
   int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
@@ -1086,12 +1099,11 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
     if (hipStreamCreate(&e->st) != hipSuccess) { delete e; return GTSG_EHIP; }
     e->own_stream = true;
   }
-  if (hipMalloc((void **)&e->d_scalars, 1024) != hipSuccess) { delete e; return GTSG_ENOMEM; }
+  if (hipMalloc((void **)&e->d_scalars, 4096) != hipSuccess) { delete e; return GTSG_ENOMEM; }
+  for (int k = 0; k < GTS_NSTREAMS; ++k)
+    if (hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking) != hipSuccess) { delete e; return GTSG_EHIP; }
   for (int k = 0; k < GTS_NKLASS; ++k)
-    if (hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming) != hipSuccess) {
-      delete e; return GTSG_EHIP;
-    }
+    if (hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete e; return GTSG_EHIP; }
   if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { delete e; return GTSG_EHIP; }
   if (hipFuncSetAttribute((const void *)k_walk_tasks,
                           hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
@@ -1128,10 +1140,8 @@ void gtsg_destroy(GtsgEngine *e)
   void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->pool, e->d_scalars};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto ev : e->free_events) hipEventDestroy(ev);
-  for (int k = 0; k < GTS_NKLASS; ++k) {
-    if (e->side[k]) hipStreamDestroy(e->side[k]);
-    if (e->ev_join[k]) hipEventDestroy(e->ev_join[k]);
-  }
+  for (int k = 0; k < GTS_NSTREAMS; ++k) if (e->side[k]) hipStreamDestroy(e->side[k]);
+  for (int k = 0; k < GTS_NKLASS; ++k) if (e->ev_join[k]) hipEventDestroy(e->ev_join[k]);
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->own_stream) hipStreamDestroy(e->st);
   delete e;
@@ -1149,6 +1159,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "fast_walks")) e->fast_walks = value != 0;
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
+  else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NSTREAMS) e->class_streams = value;
   else if (!strcmp(name, "walk_path_entries") && value >= 1) e->walk_path_entries = value;
   else if (!strcmp(name, "profile")) e->profile = (int)value;
   else return fail(e, GTSG_EINVAL, "unknown option %s", name);
@@ -1617,16 +1628,14 @@ static int run_components(GtsgEngine *e, int mode)
     LAUNCH("fill", k_fill<float>, nblk(nslots), GTS_BLOCK, s_distmap, GTS_DIST_UNSET,
            (uint64_t)nslots);
     /* components by decreasing LDS footprint; size classes of the LDS launches */
-    static const uint32_t klass_h[GTS_NKLASS] = {4096, 8192, 16384, 32768, 65536, 163840};
-    uint32_t *klass_d = e->d_scalars + 64, *klass_count = e->d_scalars + 72;
-    HIPCHK(hipMemcpyAsync(klass_d, klass_h, sizeof klass_h, hipMemcpyHostToDevice, e->st));
-    HIPCHK(hipMemsetAsync(klass_count, 0, (GTS_NKLASS + 1) * 4, e->st));
-    HIPCHK(hipMemsetAsync(e->d_scalars + 112, 0, (GTS_NKLASS + 1) * 8, e->st));
-    HIPCHK(hipMemsetAsync(e->d_scalars + 136, 0, (170 - 136) * 4, e->st));
+    const uint32_t *klass_h = gts_klass_bytes;
+    uint32_t *klass_d = e->d_scalars + GTS_S_KSIZE, *klass_count = e->d_scalars + GTS_S_KCOUNT;
+    HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_KSIZE, 0, (GTS_S_NDEF + 2 - GTS_S_KSIZE) * 4, e->st));
+    HIPCHK(hipMemcpyAsync(klass_d, klass_h, sizeof gts_klass_bytes, hipMemcpyHostToDevice, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
            ncomp, comp_wide, comp_klass, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
-           (unsigned long long *)(e->d_scalars + 112), e->d_scalars + 136);
-    LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + 136, e->d_scalars + 144);
+           (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS);
+    LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + GTS_S_KSLOTS, e->d_scalars + GTS_S_TQBASE);
     const uint32_t *order;
     {
       int shifts[4] = {0, 8, 16, 24};
@@ -1636,7 +1645,7 @@ static int run_components(GtsgEngine *e, int mode)
     uint32_t kcount[GTS_NKLASS + 1];
     uint64_t kbytes[GTS_NKLASS + 1];
     HIPCHK(hipMemcpyAsync(kcount, klass_count, sizeof kcount, hipMemcpyDeviceToHost, e->st));
-    HIPCHK(hipMemcpyAsync(kbytes, e->d_scalars + 112, sizeof kbytes, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(kbytes, e->d_scalars + GTS_S_KBYTES, sizeof kbytes, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
     HIPCHK(hipMemsetAsync(e->d_scalars + 12, 0, 16, e->st));
     LAUNCH("comp_max_size", k_max_u32_diff, nblk(ncomp), GTS_BLOCK, comp_off, ncomp,
@@ -1662,8 +1671,8 @@ static int run_components(GtsgEngine *e, int mode)
     C.task_len = task_len; C.task_poff = task_poff; C.paths = task_paths;
     C.comp_next_cc = comp_next_cc; C.wbits = wbits;
     C.task_roff = task_roff; C.comp_ring = comp_ring; C.comp_klass = comp_klass; C.tq = tq;
-    C.tq_base = e->d_scalars + 144; C.tq_cnt = (unsigned long long *)(e->d_scalars + 152);
-    C.defer_list = defer_list; C.ndeferred = (unsigned long long *)(e->d_scalars + 168);
+    C.tq_base = e->d_scalars + GTS_S_TQBASE; C.tq_cnt = (unsigned long long *)(e->d_scalars + GTS_S_TQCNT);
+    C.defer_list = defer_list; C.ndeferred = (unsigned long long *)(e->d_scalars + GTS_S_NDEF);
     C.why = (unsigned long long *)(e->d_scalars + 96);
     HIPCHK(hipMemsetAsync(C.why, 0, 64, e->st));
     {
@@ -1680,27 +1689,26 @@ static int run_components(GtsgEngine *e, int mode)
         first += kcount[nk];
       }
       /* the size classes are independent: fork them onto side streams so the
-         launches overlap (each has its own tail), join before the statistics.
-         Three streams only: the runtime serves a process with four hardware
-         queues, a fourth concurrent stream waits for one of the others. */
+         launches overlap (each has its own tail and, being bound by its LDS
+         footprint, leaves room for workgroups of the other classes); join
+         before the statistics.  The runtime serves a process with four
+         hardware queues: about four launches are in flight at a time. */
       for (int k = (int)nk - 1; k >= 0; --k) {
         if (!kcount[k]) continue;
-        static const char *const kn[2][GTS_NKLASS] = {
-            {"components_removecycles_lds4k", "components_removecycles_lds8k",
-             "components_removecycles_lds16k", "components_removecycles_lds32k",
-             "components_removecycles_lds64k", "components_removecycles_lds160k"},
-            {"components_makescaffold_lds4k", "components_makescaffold_lds8k",
-             "components_makescaffold_lds16k", "components_makescaffold_lds32k",
-             "components_makescaffold_lds64k", "components_makescaffold_lds160k"}};
-        hipStream_t ss = e->side[((int)nk - 1 - k) % 3];
+        static std::string kn[2][GTS_NKLASS];   /* event names live as long as the library */
+        if (kn[0][k].empty()) {
+          kn[0][k] = "components_removecycles_lds" + std::to_string(klass_h[k] / 1024) + "k";
+          kn[1][k] = "components_makescaffold_lds" + std::to_string(klass_h[k] / 1024) + "k";
+        }
+        hipStream_t ss = e->side[((int)nk - 1 - k) % (int)e->class_streams];
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
         k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode);
         if (e->profile) { hipEventRecord(_b, ss);
-                          e->pending.push_back({kn[mode == GTS_MODE_MAKESCAFFOLD][k], _a, _b}); }
+                          e->pending.push_back({kn[mode == GTS_MODE_MAKESCAFFOLD][k].c_str(), _a, _b}); }
         HIPCHK(hipEventRecord(e->ev_join[k], ss));
-        e->stats[std::string("components_lds_class") + char('0' + k)] = kcount[k];
+        e->stats["components_lds_class" + std::to_string(k)] = kcount[k];
         first += kcount[k];
       }
       /* joins after the last launch: a wait queued earlier would hold back a
@@ -1713,8 +1721,8 @@ static int run_components(GtsgEngine *e, int mode)
       uint32_t rounds = 0;
       if (C.defer_min_nv) {
         uint64_t pend[GTS_NKLASS + 1], ndef = 0;
-        HIPCHK(hipMemcpyAsync(pend, e->d_scalars + 152, sizeof pend, hipMemcpyDeviceToHost, e->st));
-        HIPCHK(hipMemcpyAsync(&ndef, e->d_scalars + 168, 8, hipMemcpyDeviceToHost, e->st));
+        HIPCHK(hipMemcpyAsync(pend, e->d_scalars + GTS_S_TQCNT, sizeof pend, hipMemcpyDeviceToHost, e->st));
+        HIPCHK(hipMemcpyAsync(&ndef, e->d_scalars + GTS_S_NDEF, 8, hipMemcpyDeviceToHost, e->st));
         if ((rc = read_u64(e, (uint64_t *)(e->d_scalars + 128), &ntasks))) return rc;
         for (;; ++rounds) {
           uint64_t total = 0;
@@ -1724,7 +1732,7 @@ static int run_components(GtsgEngine *e, int mode)
           HIPCHK(hipEventRecord(e->ev_fork, e->st));
           for (int k = (int)nk - 1; k >= 0; --k) {
             if (!pend[k]) continue;
-            hipStream_t ss = e->side[((int)nk - 1 - k) % 3];
+            hipStream_t ss = e->side[((int)nk - 1 - k) % (int)e->class_streams];
             HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
             hipEvent_t _a = nullptr, _b = nullptr;
             if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
@@ -1734,9 +1742,9 @@ static int run_components(GtsgEngine *e, int mode)
           }
           for (uint32_t k = 0; k < nk; ++k)
             if (pend[k]) HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
-          HIPCHK(hipMemsetAsync(e->d_scalars + 152, 0, sizeof pend, e->st));
+          HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_TQCNT, 0, sizeof pend, e->st));
           LAUNCH("components_select_walks", k_select_walks, (uint32_t)ndef, GTS_WAVE, C, (uint32_t)ndef);
-          HIPCHK(hipMemcpyAsync(pend, e->d_scalars + 152, sizeof pend, hipMemcpyDeviceToHost, e->st));
+          HIPCHK(hipMemcpyAsync(pend, e->d_scalars + GTS_S_TQCNT, sizeof pend, hipMemcpyDeviceToHost, e->st));
           if ((rc = sync_stream(e))) return rc;
         }
       }
@@ -1746,7 +1754,7 @@ static int run_components(GtsgEngine *e, int mode)
       e->stats["components_global_mem"] = kcount[nk];
       e->stats["bytes_components_global_mem"] = (int64_t)kbytes[nk];
       for (uint32_t k = 0; k < nk; ++k)
-        e->stats[std::string("bytes_components_lds_class") + char('0' + k)] = (int64_t)kbytes[k];
+        e->stats["bytes_components_lds_class" + std::to_string(k)] = (int64_t)kbytes[k];
     }
     LAUNCH("comp_count_errors", k_count_errors, nblk(ncomp), GTS_BLOCK, cerr, ncomp,
            e->d_scalars + 12);

@@ -132,7 +132,8 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      for every walk), "lds_components" (default 1; 0 runs every component
      from global memory), "defer_min_contigs" (default 320; components with at
      least that many contigs hand their walks to one workgroup per terminal,
-     0 = never), "walk_path_entries" (default 2^24, pool for the tasks' walks;
+     0 = never), "class_streams" (default 6: side streams the LDS size classes
+     are launched on), "walk_path_entries" (default 2^24, pool for the tasks' walks;
      grows by itself like the walk queues) */
 
 /* per-kernel timing collected with hipEvents on the engine's stream while
