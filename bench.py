@@ -69,6 +69,8 @@ def algorithmic_bytes(name, n, m, nrec, eng):
         klass["components_makescaffold_lds%dk" % kb] = "bytes_components_lds_class%d" % i
     if name in klass:
         return max(eng.stat(klass[name]), 0)
+    if name == "components_walk_tasks":   # every task stages its component once; per launch
+        return eng.stat("bytes_walk_tasks") / max(1, eng.stat("walk_task_launches"))
     return table.get(name)
 
 

@@ -93,6 +93,7 @@ struct GtsCompView {
   uint8_t *defer_flag;       /* ncomp */
   uint32_t *comp_task0, *comp_ncc, *comp_nterm;   /* ncomp */
   unsigned long long *ntasks, *path_used;         /* device counters */
+  unsigned long long *task_bytes;                 /* statistics: bytes the walk tasks staged */
   uint64_t task_cap, path_cap;
   uint32_t *task_comp, *task_start, *task_n;      /* task_cap */
   uint8_t *task_skip;
@@ -1575,6 +1576,7 @@ struct GtsComponent {
       if (nfast) W::count_n(C.stat_fast + c, nfast);
       W::add64(C.tstat + 5 * (uint64_t)c + 2, tfast);
       W::add64(C.tstat + 5 * (uint64_t)c + 4, npops);
+      W::add64((uint64_t *)C.task_bytes, (uint64_t)M.ne * 19 + (uint64_t)nv * 27);
     }
     W::fence();
   }

@@ -427,9 +427,20 @@ struct GtsEdgeAccLds {
   __device__ __forceinline__ bool marked(uint32_t i) const { return (f[i] & 0x80u) != 0; }
 };
 
+/* what the pair passes gather per edge from the end vertex, in one 16-byte
+   record (two separate arrays cost two sectors per edge) */
+struct __attribute__((aligned(16))) GtsVAttr { int64_t len; float cn; uint32_t pad; };
+__global__ void k_pack_vattr(const int64_t *seq_len, const float *copy_num, GtsVAttr *va, uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  GtsVAttr a; a.len = seq_len[v]; a.cn = copy_num[v]; a.pad = 0;
+  va[v] = a;
+}
+
 __global__ void __launch_bounds__(GTS_BLOCK)
-k_filter_pairs(GtsGraphView G, GtsFilterParams P, uint8_t *prop, uint8_t *vinfo,
-               uint32_t hub_degree)
+k_filter_pairs(GtsGraphView G, GtsFilterParams P, const GtsVAttr *va, uint8_t *prop,
+               uint8_t *vinfo, uint32_t hub_degree)
 {
   __shared__ int32_t s_d[GTS_FP_CAP], s_l[GTS_FP_CAP];
   __shared__ float s_s[GTS_FP_CAP], s_c[GTS_FP_CAP];
@@ -443,10 +454,11 @@ k_filter_pairs(GtsGraphView G, GtsFilterParams P, uint8_t *prop, uint8_t *vinfo,
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < ns; i += GTS_BLOCK) {
     const uint32_t p = e0 + i, x = G.end[p];
-    const int64_t d = G.dist[p], l = G.seq_len[x];
+    const GtsVAttr a = va[x];
+    const int64_t d = G.dist[p], l = a.len;
     if (d != (int32_t)d || l != (int32_t)l) s_wide = 1;
     s_d[i] = (int32_t)d; s_s[i] = G.sd[p]; s_f[i] = G.flags[p];
-    s_c[i] = G.copy_num[x]; s_l[i] = (int32_t)l;
+    s_c[i] = a.cn; s_l[i] = (int32_t)l;
   }
   __syncthreads();
   if (s_wide) ns = 0;
@@ -504,7 +516,7 @@ __global__ void k_filter_tpoly(GtsGraphView G, const uint32_t *estart,
   atomicMin(&tpoly[v], u);
 }
 __global__ void __launch_bounds__(GTS_BLOCK)
-k_filter_ovf_init(GtsGraphView G, GtsFilterParams P, const uint32_t *estart,
+k_filter_ovf_init(GtsGraphView G, GtsFilterParams P, const GtsVAttr *va, const uint32_t *estart,
                   const uint8_t *vinfo, const uint32_t *tpoly, uint8_t *ovf,
                   int zero_ovf, uint32_t hub_degree)
 {
@@ -539,7 +551,7 @@ k_filter_ovf_init(GtsGraphView G, GtsFilterParams P, const uint32_t *estart,
     for (uint32_t i = threadIdx.x; i < ns; i += GTS_BLOCK) {
       const uint32_t p = e0 + i, x = G.end[p];
       const bool mk = gts_edge_is_marked(G.state[p]) || tpoly[x] <= estart[p];
-      const int64_t d = G.dist[p], l = G.seq_len[x];
+      const int64_t d = G.dist[p], l = va[x].len;
       if (d != (int32_t)d || l != (int32_t)l) s_wide = 1;
       s_d[i] = (int32_t)d; s_l[i] = (int32_t)l;
       s_f[i] = (uint8_t)((G.flags[p] & 3u) | (mk ? 0x80u : 0u));
@@ -640,7 +652,9 @@ __global__ void k_live_union(GtsGraphView G, const uint32_t *estart,
   const bool lv = !gts_edge_is_marked(G.state[p]) &&
                   !gts_vertex_is_marked(G.vstate[a]) &&
                   !gts_vertex_is_marked(G.vstate[b]);
-  live[p] = lv ? 1 : 0;
+  /* bit 7: live; low bits: the edge's flags, so that k_compact_fill gets both
+     about the twin from one gather */
+  live[p] = (uint8_t)((G.flags[p] & 3u) | (lv ? 0x80u : 0u));
   if (!lv) return;
   touched[a] = 1; touched[b] = 1;
   uint32_t x = a, y = b;
@@ -717,7 +731,7 @@ __global__ void k_compact_flags(const uint8_t *live, const uint32_t *twin,
                                 uint32_t *incl, uint32_t m)
 {
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < m) incl[p] = (live[p] || live[twin[p]]) ? 1u : 0u;
+  if (p < m) incl[p] = ((live[p] | live[twin[p]]) & 0x80u) ? 1u : 0u;
 }
 __global__ void k_compact_count(const uint32_t *row, const uint32_t *ipos,
                                 const uint32_t *slot_v, uint32_t *cnt,
@@ -741,14 +755,14 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart, const uin
   if (!incl[p]) { cmap[p] = GTS_NONE; return; }
   const uint32_t a = estart[p], s = slot_of[a], base = slot_base[s];
   const uint32_t k = coff[s] + (ipos[p] - ipos[G.row[a]]);
-  const uint8_t f = G.flags[p], ft = G.flags[G.twin[p]];
+  const uint8_t f = G.flags[p], ft = live[G.twin[p]];   /* twin: flags + live bit */
   const bool uturn = ((ft & GTS_F_SENSE) != 0) == gts_next_dir(f);
   cstart[k] = s - base; cend[k] = slot_of[G.end[p]] - base;
   const int64_t d = G.dist[p];
   if (d != (int32_t)d) comp_wide[slot_comp[s]] = 1;
   cdist[k] = d;
   cflags[k] = (uint8_t)((f & 3u) | (uturn ? GTS_F_UTURN : 0u) |
-                        (live[G.twin[p]] ? GTS_F_TWINLIVE : 0u));
+                        ((ft & 0x80u) ? GTS_F_TWINLIVE : 0u));
   cgpos[k] = (uint32_t)p; cstate[k] = G.state[p];
   cmap[p] = k;
 }
@@ -1348,7 +1362,7 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   e->filter_open = false;
   if (!n) return 0;
   int rc;
-  if ((rc = pool_reserve(e, (size_t)m * 2 + (size_t)n * 24 + (8u << 20)))) return rc;
+  if ((rc = pool_reserve(e, (size_t)m * 2 + (size_t)n * 40 + (8u << 20)))) return rc;
   GtsGraphView G = view_of(e);
   GtsFilterParams P;
   P.amb = gts_amb_thresholds(pcutoff);
@@ -1359,8 +1373,10 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   PALLOC(vinfo, uint8_t, n); PALLOC(ovf, uint8_t, n);
   PALLOC(tpoly, uint32_t, n); PALLOC(lasthit, uint32_t, 2 * (size_t)n);
   uint32_t *pending = e->d_scalars + 4;
+  PALLOC(vattr, GtsVAttr, n);
   HIPCHK(hipMemsetAsync(prop, 0, (size_t)m + 1, e->st));
-  LAUNCH("filter_pairs", k_filter_pairs, nblk(n), GTS_BLOCK, G, P, prop, vinfo,
+  LAUNCH("filter_pack_vattr", k_pack_vattr, nblk(n), GTS_BLOCK, e->seq_len, e->copy_num, vattr, n);
+  LAUNCH("filter_pairs", k_filter_pairs, nblk(n), GTS_BLOCK, G, P, vattr, prop, vinfo,
          (uint32_t)e->hub_degree);
   if (e->nhub)
     LAUNCH("filter_pairs_hub", k_filter_pairs_hub, nblk((uint64_t)e->nhub * GTS_WAVE),
@@ -1377,7 +1393,7 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   }
   HIPCHK(hipMemsetAsync(tpoly, 0xFF, (size_t)n * 4, e->st));
   if (m) LAUNCH("filter_tpoly", k_filter_tpoly, nblk(m), GTS_BLOCK, G, e->estart, prop, vinfo, tpoly);
-  LAUNCH("filter_ovf_init", k_filter_ovf_init, nblk(n), GTS_BLOCK, G, P, e->estart, vinfo, tpoly,
+  LAUNCH("filter_ovf_init", k_filter_ovf_init, nblk(n), GTS_BLOCK, G, P, vattr, e->estart, vinfo, tpoly,
          ovf, zero_ovf, (uint32_t)e->hub_degree);
   if (e->nhub && !zero_ovf)
     LAUNCH("filter_ovf_init_hub", k_filter_ovf_init_hub,
@@ -1630,7 +1646,7 @@ static int run_components(GtsgEngine *e, int mode)
     /* components by decreasing LDS footprint; size classes of the LDS launches */
     const uint32_t *klass_h = gts_klass_bytes;
     uint32_t *klass_d = e->d_scalars + GTS_S_KSIZE, *klass_count = e->d_scalars + GTS_S_KCOUNT;
-    HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_KSIZE, 0, (GTS_S_NDEF + 2 - GTS_S_KSIZE) * 4, e->st));
+    HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_KSIZE, 0, (GTS_S_NDEF + 4 - GTS_S_KSIZE) * 4, e->st));
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, sizeof gts_klass_bytes, hipMemcpyHostToDevice, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
            ncomp, comp_wide, comp_klass, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
@@ -1666,6 +1682,7 @@ static int run_components(GtsgEngine *e, int mode)
     C.defer_min_nv = mode == GTS_MODE_MAKESCAFFOLD && e->lds_components ? (uint32_t)e->defer_min_contigs : 0u;
     C.defer_flag = defer_flag; C.comp_task0 = comp_task0; C.comp_ncc = comp_ncc; C.comp_nterm = comp_nterm;
     C.ntasks = (unsigned long long *)(e->d_scalars + 128); C.path_used = (unsigned long long *)(e->d_scalars + 130);
+    C.task_bytes = (unsigned long long *)(e->d_scalars + GTS_S_NDEF + 2);
     C.task_cap = task_cap; C.path_cap = path_cap;
     C.task_comp = task_comp; C.task_start = task_start; C.task_n = task_n; C.task_skip = task_skip;
     C.task_len = task_len; C.task_poff = task_poff; C.paths = task_paths;
@@ -1717,7 +1734,7 @@ static int run_components(GtsgEngine *e, int mode)
         if (kcount[k]) HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
       /* deferred walks (gts_component.hpp, try_defer): rounds of one workgroup
          per pending walk, grouped by LDS class, and an in-order select pass */
-      uint64_t ntasks = 0, walks_run = 0;
+      uint64_t ntasks = 0, walks_run = 0, task_launches = 0;
       uint32_t rounds = 0;
       if (C.defer_min_nv) {
         uint64_t pend[GTS_NKLASS + 1], ndef = 0;
@@ -1729,6 +1746,7 @@ static int run_components(GtsgEngine *e, int mode)
           for (uint32_t k = 0; k < nk; ++k) total += pend[k];
           if (!total) break;
           walks_run += total;
+          for (uint32_t k = 0; k < nk; ++k) task_launches += pend[k] != 0;
           HIPCHK(hipEventRecord(e->ev_fork, e->st));
           for (int k = (int)nk - 1; k >= 0; --k) {
             if (!pend[k]) continue;
@@ -1749,6 +1767,12 @@ static int run_components(GtsgEngine *e, int mode)
         }
       }
       e->stats["walk_task_rounds"] = rounds;
+      e->stats["walk_task_launches"] = (int64_t)task_launches;
+      {
+        uint64_t tb = 0;
+        if ((rc = read_u64(e, (uint64_t *)(e->d_scalars + GTS_S_NDEF + 2), &tb))) return rc;
+        e->stats["bytes_walk_tasks"] = (int64_t)tb;
+      }
       e->stats["walk_task_runs"] = (int64_t)walks_run;
       e->stats["walk_tasks"] = (int64_t)ntasks;
       e->stats["components_global_mem"] = kcount[nk];

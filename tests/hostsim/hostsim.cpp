@@ -247,6 +247,8 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   unsigned long long ntasks = 0, path_used = 0;
   C.defer_min_nv = defer_min_nv; C.defer_flag = defer_flag.data();
   C.comp_task0 = comp_task0.data(); C.comp_ncc = comp_ncc.data(); C.comp_nterm = comp_nterm.data();
+  unsigned long long task_bytes = 0;
+  C.task_bytes = &task_bytes;
   C.ntasks = &ntasks; C.path_used = &path_used; C.task_cap = S; C.path_cap = path_cap;
   C.task_comp = task_comp.data(); C.task_start = task_start.data(); C.task_n = task_n.data();
   C.task_skip = task_skip.data(); C.task_len = task_len.data(); C.task_poff = task_poff.data();

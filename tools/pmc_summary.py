@@ -19,14 +19,10 @@ import os
 import sys
 from collections import defaultdict
 
-LDS_CLASS = {4096: "lds4k", 8192: "lds8k", 16384: "lds16k", 32768: "lds32k", 65536: "lds64k",
-             163840: "lds160k"}
-
-
 def short(name, lds):
     base = name.split("(")[0].replace("void ", "").strip()
-    if base == "k_components_lds":
-        return "k_components_lds[%s]" % LDS_CLASS.get(int(lds), str(lds))
+    if base in ("k_components_lds", "k_walk_tasks"):
+        return "%s[lds%dk]" % (base, int(lds) // 1024)
     return base
 
 
