@@ -84,6 +84,7 @@ struct GtsgEngine {
   int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
   int64_t walk_pool_entries = 1ll << 26;
   int64_t class_streams = GTS_NSTREAMS;
+  int64_t mixed_task_limit = 512;
   int64_t defer_min_contigs = 320, walk_path_entries = 1ll << 24;
   int64_t fast_walks = 1, lds_components = 1;
   int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
@@ -934,6 +935,23 @@ k_walk_tasks(GtsCompView C, uint32_t klass, uint32_t count)
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.walk_task(t);
 }
+/* the same for the pending tasks of all classes in one launch (few tasks: the
+   rounds after the first), with the LDS of the largest class among them */
+struct GtsTaskPrefix { uint32_t pre[GTS_NKLASS + 1]; };
+__global__ void __launch_bounds__(GTS_WAVE)
+k_walk_tasks_mixed(GtsCompView C, GtsTaskPrefix P)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x >= P.pre[GTS_NKLASS]) return;
+  uint32_t k = 0;
+  while (blockIdx.x >= P.pre[k + 1]) ++k;
+  const uint32_t t = C.tq[C.tq_base[k] + blockIdx.x - P.pre[k]];
+  const uint32_t c = C.task_comp[t];
+  GtsCompMemT<true> M;
+  stage_component(C, c, smem, M, true);
+  GtsComponent<GtsWave64, true> prog(C, M, c);
+  prog.walk_task(t);
+}
 __global__ void __launch_bounds__(GTS_WAVE)
 k_select_walks(GtsCompView C, uint32_t ndeferred)
 {
@@ -1119,6 +1137,10 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
   for (int k = 0; k < GTS_NKLASS; ++k)
     if (hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete e; return GTSG_EHIP; }
   if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { delete e; return GTSG_EHIP; }
+  if (hipFuncSetAttribute((const void *)k_walk_tasks_mixed,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
+    delete e; return GTSG_EHIP;
+  }
   if (hipFuncSetAttribute((const void *)k_walk_tasks,
                           hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
     delete e; return GTSG_EHIP;
@@ -1174,6 +1196,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
   else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NSTREAMS) e->class_streams = value;
+  else if (!strcmp(name, "mixed_task_limit") && value >= 0) e->mixed_task_limit = value;
   else if (!strcmp(name, "walk_path_entries") && value >= 1) e->walk_path_entries = value;
   else if (!strcmp(name, "profile")) e->profile = (int)value;
   else return fail(e, GTSG_EINVAL, "unknown option %s", name);
@@ -1746,6 +1769,22 @@ static int run_components(GtsgEngine *e, int mode)
           for (uint32_t k = 0; k < nk; ++k) total += pend[k];
           if (!total) break;
           walks_run += total;
+          if (total <= (uint64_t)e->mixed_task_limit) {
+            /* few walks: one launch, no waiting for a queue per class */
+            GtsTaskPrefix P;
+            uint32_t acc = 0, kmax = 0;
+            for (uint32_t k = 0; k < GTS_NKLASS; ++k) {
+              P.pre[k] = acc;
+              if (k < nk && pend[k]) { acc += (uint32_t)pend[k]; kmax = k; }
+            }
+            P.pre[GTS_NKLASS] = acc;
+            ++task_launches;
+            hipEvent_t _a = nullptr, _b = nullptr;
+            if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, e->st); }
+            k_walk_tasks_mixed<<<acc, GTS_WAVE, klass_h[kmax], e->st>>>(C, P);
+            if (e->profile) { hipEventRecord(_b, e->st); e->pending.push_back({"components_walk_tasks", _a, _b}); }
+            for (uint32_t k = 0; k < nk; ++k) pend[k] = 0;   /* nothing to join */
+          }
           for (uint32_t k = 0; k < nk; ++k) task_launches += pend[k] != 0;
           HIPCHK(hipEventRecord(e->ev_fork, e->st));
           for (int k = (int)nk - 1; k >= 0; --k) {
