@@ -100,7 +100,7 @@ def recorded_traffic(name):
         return None
     d = json.load(open(path))
     if name.startswith("components_"):
-        ks = [k for k in d if k.startswith("k_components")]
+        ks = [k for k in d if k.startswith("k_walk_tasks" if "walk_tasks" in name else "k_components")]
         tot = sum((d[k]["fetch_bytes_per_launch_raw"] + d[k]["write_bytes_per_launch"]) * d[k]["launches"] for k in ks)
         n = sum(d[k]["launches"] for k in ks)
         return tot / n if n else None      # average over the size-class launches
