@@ -1548,7 +1548,10 @@ struct GtsComponent {
   GTS_HD void walk_task(uint64_t t)
   {
     const uint32_t lane = W::lane();
-    clean = W::uni((uint32_t)C.defer_flag[c]) == 2;
+    /* 2: clean; 3: strands assigned but new arcs since the last peeling --
+       the order is recomputed here (one pass, then every walk is one sweep) */
+    const uint32_t df = W::uni((uint32_t)C.defer_flag[c]);
+    clean = df == 2 || (df == 3 && peel());
     const uint32_t nw = (nv + 31) / 32;
     reach_bits = C.paths + C.task_roff[t];
     no_reference = true;
@@ -1702,8 +1705,9 @@ struct GtsComponent {
     }
     if (lane == 0) {
       C.comp_next_cc[c] = i;
-      /* new arcs: the sweep order of a clean component is void */
-      C.defer_flag[c] = i == ncc ? 0 : (revived_any ? 1 : C.defer_flag[c]);
+      /* new arcs: the sweep order of a clean component is void (the strands hold) */
+      const uint8_t df = C.defer_flag[c];
+      C.defer_flag[c] = i == ncc ? 0 : (revived_any && df == 2 ? 3 : df);
     }
     W::fence();
     return i < ncc;

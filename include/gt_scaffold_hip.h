@@ -133,7 +133,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      from global memory), "defer_min_contigs" (default 320; components with at
      least that many contigs hand their walks to one workgroup per terminal,
      0 = never), "class_streams" (default 6: side streams the LDS size classes
-     are launched on), "mixed_task_limit" (default 512: a round with at most
+     are launched on), "mixed_task_limit" (default 256: a round with at most
      that many pending walks is one launch for all classes), "walk_path_entries" (default 2^24, pool for the tasks' walks;
      grows by itself like the walk queues) */
 
