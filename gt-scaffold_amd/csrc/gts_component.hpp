@@ -269,42 +269,65 @@ struct GtsComponent {
     W::fence();
     auto ccoff = M.ccoff;
     nterm = 0; ncc = 0;
-    for (uint32_t s = 0; s < nv; ++s) {
-      const uint8_t st = (uint8_t)W::uni(M.vst[s]);
-      if (gts_vertex_is_marked(st) || st == GIS_VISITED) continue;
-      M.vst[s] = GIS_PROCESSED;
-      M.queue[0] = s;
-      ccoff[ncc++] = nterm;
-      W::fence();
-      uint32_t bh = 0, bn = 1;
-      while (bh < bn) {
-        const uint32_t cur = W::uni(M.queue[bh]);
-        ++bh;
-        const uint32_t eb = eoff(cur), ee = eoff(cur + 1);
-        bool has_s = false, has_a = false;
-        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
-          const uint32_t ce = base + lane;
-          bool live = false, sense = false, unv = false;
-          uint32_t nb = 0;
-          if (ce < ee) {
-            live = !gts_edge_is_marked(M.cstate[ce]);
-            sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
-            nb = M.cend[ce];
-            unv = live && M.vst[nb] == GIS_UNVISITED;
-          }
-          has_s |= W::ballot(live && sense) != 0;
-          has_a |= W::ballot(live && !sense) != 0;
-          const uint64_t mask = W::ballot(unv);
-          if (unv) {
-            M.queue[bn + W::popc_below(mask, lane)] = nb;
-            M.vst[nb] = GIS_PROCESSED;
-          }
-          bn += W::popc(mask);
-          W::fence();
+    /* Start vertices in index order: a chunk of states is looked at by all
+       lanes at once and again after every search (which visits vertices of
+       the chunk).  Inside a search the known part of the queue is read a
+       chunk at a time together with the list bounds of its vertices, so the
+       per-vertex chain is "edges, neighbour states" only. */
+    for (uint32_t base0 = 0; base0 < nv; base0 += W::WIDTH) {
+      uint32_t next_lane = 0;
+      for (;;) {
+        bool cand = false;
+        if (base0 + lane < nv && lane >= next_lane) {
+          const uint8_t st = M.vst[base0 + lane];
+          cand = !gts_vertex_is_marked(st) && st != GIS_VISITED;
         }
-        if (!(has_s && has_a)) M.term[nterm++] = cur;
-        M.vst[cur] = GIS_VISITED;
+        const uint64_t cm = W::ballot(cand);
+        if (!cm) break;
+        const uint32_t l0 = W::ctz(cm);
+        next_lane = l0 + 1;
+        const uint32_t s = base0 + l0;
+        M.vst[s] = GIS_PROCESSED;
+        M.queue[0] = s;
+        ccoff[ncc++] = nterm;
         W::fence();
+        uint32_t bh = 0, bn = 1;
+        while (bh < bn) {
+          const uint32_t cnt = bn - bh < W::WIDTH ? bn - bh : W::WIDTH;
+          uint32_t my_v = 0, my_eb = 0, my_ee = 0;
+          if (lane < cnt) {
+            my_v = M.queue[bh + lane];
+            my_eb = M.coff[my_v] - M.e0; my_ee = M.coff[my_v + 1] - M.e0;
+          }
+          for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t cur = W::bcast(my_v, i), eb = W::bcast(my_eb, i), ee = W::bcast(my_ee, i);
+            bool has_s = false, has_a = false;
+            for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+              const uint32_t ce = base + lane;
+              bool live = false, sense = false, unv = false;
+              uint32_t nb = 0;
+              if (ce < ee) {
+                live = !gts_edge_is_marked(M.cstate[ce]);
+                sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+                nb = M.cend[ce];
+                unv = live && M.vst[nb] == GIS_UNVISITED;
+              }
+              has_s |= W::ballot(live && sense) != 0;
+              has_a |= W::ballot(live && !sense) != 0;
+              const uint64_t mask = W::ballot(unv);
+              if (unv) {
+                M.queue[bn + W::popc_below(mask, lane)] = nb;
+                M.vst[nb] = GIS_PROCESSED;
+              }
+              bn += W::popc(mask);
+              W::fence();
+            }
+            if (!(has_s && has_a)) M.term[nterm++] = cur;
+            M.vst[cur] = GIS_VISITED;
+            W::fence();
+          }
+          bh += cnt;
+        }
       }
     }
     ccoff[ncc] = nterm;
@@ -1154,32 +1177,41 @@ struct GtsComponent {
     M.gorient[0] = 2;
     W::fence();
     while (qh2 < qn2 && !bad) {
-      const uint32_t u = W::uni(Q[qh2]);
-      ++qh2;
-      const bool ou = W::uni((uint32_t)M.gorient[u]) == 2;
-      const uint32_t eb = eoff(u), ee = eoff(u + 1);
-      for (uint32_t base = eb; base < ee; base += W::WIDTH) {
-        const uint32_t ce = base + lane;
-        bool fresh = false, clash = false;
-        uint32_t v = 0, ov = 0;
-        if (ce < ee) {
-          const uint32_t fl = M.cflags[ce];
-          const bool sense = (fl & GTS_F_SENSE) != 0;
-          v = M.cend[ce];
-          ov = (gts_next_dir((uint8_t)fl) != (sense != ou)) ? 2u : 1u;
-          const uint32_t cur = M.gorient[v];
-          clash = (fl & GTS_F_UTURN) || v == u || (cur != 0 && cur != ov);
-          fresh = cur == 0;
-        }
-        if (W::ballot(clash)) { bad = true; break; }
-        const uint64_t fm = W::ballot(fresh);
-        if (fresh) {
-          M.gorient[v] = (uint8_t)ov;
-          Q[qn2 + W::popc_below(fm, lane)] = v;
-        }
-        qn2 += W::popc(fm);
-        W::fence();
+      /* the known part of the queue, a chunk at a time (see calc_cc) */
+      const uint32_t cnt = qn2 - qh2 < W::WIDTH ? qn2 - qh2 : W::WIDTH;
+      uint32_t my_u = 0, my_eb = 0, my_ee = 0, my_o = 0;
+      if (lane < cnt) {
+        my_u = Q[qh2 + lane];
+        my_eb = M.coff[my_u] - M.e0; my_ee = M.coff[my_u + 1] - M.e0;
+        my_o = M.gorient[my_u];
       }
+      for (uint32_t i = 0; i < cnt && !bad; ++i) {
+        const uint32_t u = W::bcast(my_u, i), eb = W::bcast(my_eb, i), ee = W::bcast(my_ee, i);
+        const bool ou = W::bcast(my_o, i) == 2;
+        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+          const uint32_t ce = base + lane;
+          bool fresh = false, clash = false;
+          uint32_t v = 0, ov = 0;
+          if (ce < ee) {
+            const uint32_t fl = M.cflags[ce];
+            const bool sense = (fl & GTS_F_SENSE) != 0;
+            v = M.cend[ce];
+            ov = (gts_next_dir((uint8_t)fl) != (sense != ou)) ? 2u : 1u;
+            const uint32_t cur = M.gorient[v];
+            clash = (fl & GTS_F_UTURN) || v == u || (cur != 0 && cur != ov);
+            fresh = cur == 0;
+          }
+          if (W::ballot(clash)) { bad = true; break; }
+          const uint64_t fm = W::ballot(fresh);
+          if (fresh) {
+            M.gorient[v] = (uint8_t)ov;
+            Q[qn2 + W::popc_below(fm, lane)] = v;
+          }
+          qn2 += W::popc(fm);
+          W::fence();
+        }
+      }
+      qh2 += cnt;
     }
     return !bad && qn2 == nv;
   }
@@ -1227,28 +1259,37 @@ struct GtsComponent {
       }
       W::fence();
       while (th < tn) {
-        const uint32_t u = W::uni(Qp[th]);
-        if (fwd) M.tpos[u] = th;
-        ++th;
-        const uint32_t gu = W::uni((uint32_t)M.gorient[u]);
-        M.gorient[u] = (uint8_t)(gu & ~bit);
-        const bool ou = (gu & 3u) == 2;
-        const uint32_t eb = eoff(u), ee = eoff(u + 1);
-        for (uint32_t base = eb; base < ee; base += W::WIDTH) {
-          const uint32_t ce = base + lane;
-          bool ready = false;
-          uint32_t v = 0;
-          if (ce < ee && d_arc(ce, ou, fwd)) {   /* out-arcs when peeling sources */
-            v = M.cend[ce];
-            const uint32_t d = deg[v] - 1;
-            deg[v] = d;
-            ready = d == 0;
-          }
-          const uint64_t rm = W::ballot(ready);
-          if (ready) Qp[tn + W::popc_below(rm, lane)] = v;
-          tn += W::popc(rm);
-          W::fence();
+        /* the known part of the queue, a chunk at a time (see calc_cc); the
+           lanes retire their own vertices' bookkeeping */
+        const uint32_t cnt = tn - th < W::WIDTH ? tn - th : W::WIDTH;
+        uint32_t my_u = 0, my_eb = 0, my_ee = 0, my_g = 0;
+        if (lane < cnt) {
+          my_u = Qp[th + lane];
+          my_eb = M.coff[my_u] - M.e0; my_ee = M.coff[my_u + 1] - M.e0;
+          my_g = M.gorient[my_u];
+          if (fwd) M.tpos[my_u] = th + lane;
+          M.gorient[my_u] = (uint8_t)(my_g & ~bit);
         }
+        for (uint32_t i = 0; i < cnt; ++i) {
+          const uint32_t eb = W::bcast(my_eb, i), ee = W::bcast(my_ee, i);
+          const bool ou = (W::bcast(my_g, i) & 3u) == 2;
+          for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+            const uint32_t ce = base + lane;
+            bool ready = false;
+            uint32_t v = 0;
+            if (ce < ee && d_arc(ce, ou, fwd)) {   /* out-arcs when peeling sources */
+              v = M.cend[ce];
+              const uint32_t d = deg[v] - 1;
+              deg[v] = d;
+              ready = d == 0;
+            }
+            const uint64_t rm = W::ballot(ready);
+            if (ready) Qp[tn + W::popc_below(rm, lane)] = v;
+            tn += W::popc(rm);
+            W::fence();
+          }
+        }
+        th += cnt;
       }
       if (fwd && tn == nv) return true;   /* acyclic: flags all cleared */
     }

@@ -39,13 +39,14 @@ enum : uint8_t {
 /* ref gt_scaffolder_algorithms.c:38-47 */
 GTS_HD bool gts_vertex_is_marked(uint8_t s)
 {
-  return s == GIS_POLYMORPHIC || s == GIS_REPEAT || s == GIS_CYCLIC;
+  /* POLYMORPHIC, REPEAT, CYCLIC as a bit set: one shift instead of a chain of
+     compares and branches in the per-edge loops */
+  return ((0x8Au >> (s & 7u)) & 1u) != 0;
 }
 /* ref gt_scaffolder_algorithms.c:50-58 */
 GTS_HD bool gts_edge_is_marked(uint8_t s)
 {
-  return s == GIS_INCONSISTENT || s == GIS_POLYMORPHIC || s == GIS_CYCLIC ||
-         s == GIS_REPEAT;
+  return ((0x8Eu >> (s & 7u)) & 1u) != 0;   /* POLYMORPHIC, INCONSISTENT, REPEAT, CYCLIC */
 }
 /* direction in which a walk leaves the end vertex of an edge,
    ref gt_scaffolder_algorithms.c:475-478, 688-691, 968-971 */
