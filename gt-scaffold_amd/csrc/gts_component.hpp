@@ -138,11 +138,18 @@ template <class T> struct GtsPtrSel<T, true> {
    fit 16 bits (a component that fits 160 KB of LDS has far fewer than 65535
    vertices or edges), distances and contig lengths are staged as int32 (a
    component holding a wider value is run from global memory instead). */
+/* nd_t: integer labels of the linear-time walks; len_t: contig bases along a
+   walk.  The packed LDS layout is used only for components whose sums fit
+   (k_comp_lds_keys: fewer than 4096 contigs, |distance| < 2^19, contig
+   lengths adding up to less than 2^32), so 32 bits hold them and the float
+   conversions are single instructions. */
 template <bool LDS> struct GtsCompTypes {
   typedef uint32_t idx_t; typedef int64_t dist_t; typedef int64_t seq_t;
+  typedef int64_t nd_t; typedef uint64_t len_t;
 };
 template <> struct GtsCompTypes<true> {
   typedef uint16_t idx_t; typedef int32_t dist_t; typedef int32_t seq_t;
+  typedef int32_t nd_t; typedef uint32_t len_t;
 };
 
 /* base pointers of ONE component, component-local indices */
@@ -151,6 +158,8 @@ struct GtsCompMemT {
   typedef typename GtsCompTypes<LDS>::idx_t idx_t;
   typedef typename GtsCompTypes<LDS>::dist_t dist_t;
   typedef typename GtsCompTypes<LDS>::seq_t seq_t;
+  typedef typename GtsCompTypes<LDS>::nd_t nd_t;
+  typedef typename GtsCompTypes<LDS>::len_t len_t;
   uint32_t nv, ne;           /* slots, compact edges of the component */
   uint32_t e0;               /* value to subtract from coff[] entries */
   GTS_P(const idx_t) coff;   /* nv+1 */
@@ -176,8 +185,8 @@ struct GtsCompMemT {
   GTS_P(uint8_t) st_dir;
   GTS_P(uint8_t) tight;
   GTS_P(float) distmap;
-  GTS_P(int64_t) nd;
-  GTS_P(uint64_t) plen;
+  GTS_P(nd_t) nd;
+  GTS_P(len_t) plen;
   /* whole-component analysis (orient + peel): strand of every vertex + 1, a
      topological order of the forward sheet and its inverse */
   GTS_P(uint8_t) gorient;
@@ -194,8 +203,7 @@ GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
   uint32_t b = 0;
   b += (((nv + 1) * 2 + a - 1) / a) * a * 2;          /* coff, ccoff */
   b += ((nv * 2 + a - 1) / a) * a * 12;               /* queue .. cc_best, topo, tpos */
-  b += ((nv * 4 + a - 1) / a) * a * 3;                /* lastpop, distmap, cseq */
-  b += ((nv * 8 + a - 1) / a) * a * 2;                /* nd, plen */
+  b += ((nv * 4 + a - 1) / a) * a * 5;                /* lastpop, distmap, cseq, nd, plen */
   b += ((nv + a - 1) / a) * a * 4;                    /* vst, st_dir, tight, gorient */
   b += ((ne * 2 + a - 1) / a) * a * 2;                /* cstart, cend */
   b += ((ne * 4 + a - 1) / a) * a;                    /* cdist */
@@ -253,6 +261,12 @@ struct GtsComponent {
     return m;
   }
 
+  typedef typename GtsCompTypes<LDS>::nd_t nd_t;
+  typedef typename GtsCompTypes<LDS>::len_t len_t;
+  static GTS_HD int32_t uni_t(int32_t v) { return (int32_t)W::uni((uint32_t)v); }
+  static GTS_HD uint32_t uni_t(uint32_t v) { return W::uni(v); }
+  static GTS_HD int64_t uni_t(int64_t v) { return W::uni64(v); }
+  static GTS_HD uint64_t uni_t(uint64_t v) { return (uint64_t)W::uni64((int64_t)v); }
   GTS_HD uint32_t eoff(uint32_t ls) const { return W::uni(M.coff[ls]) - M.e0; }
   /* walk_task: the vertices a search labels (see try_defer) */
   GTS_HD void note_labelled(uint32_t v) const
@@ -885,20 +899,20 @@ struct GtsComponent {
           if (++pops > max_pops) { bad = true; break; }
           dirty[u] = 0;
           const bool du = (W::uni((uint32_t)orient[u]) & 3u) == 2;
-          const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
+          const nd_t ndu = u == start ? (nd_t)0 : uni_t(M.nd[u]);
           const uint32_t eb = eoff(u), ee = eoff(u + 1);
           for (uint32_t eb2 = eb; eb2 < ee; eb2 += W::WIDTH) {
             const uint32_t ce = eb2 + lane;
             if (ce < ee && !gts_edge_is_marked(M.cstate[ce]) &&
                 ((M.cflags[ce] & GTS_F_SENSE) != 0) == du) {
               const uint32_t v = M.cend[ce];
-              const int64_t w = M.cdist[ce];
+              const nd_t w = (nd_t)M.cdist[ce];
               const float cand = u == start ? (float)w : (float)(ndu + w);
               const float old = M.distmap[v];
               if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
               if (old == GTS_DIST_UNSET || old > cand) {
                 M.distmap[v] = cand;
-                M.nd[v] = u == start ? w : (int64_t)cand;
+                M.nd[v] = u == start ? w : (nd_t)cand;
                 dirty[v] = 1;
               }
             }
@@ -919,14 +933,14 @@ struct GtsComponent {
     uint32_t bh = 0, bt = 1;
     best_len = 0; best_t = GTS_NONE;
     BQ[0] = start;
-    M.plen[start] = (uint64_t)M.cseq[start];
+    M.plen[start] = (len_t)M.cseq[start];
     W::fence();
     while (bh < bt) {
       const uint32_t u = W::uni(BQ[bh]);
       ++bh;
       const bool du = (W::uni((uint32_t)orient[u]) & 3u) == 2;
-      const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
-      const uint64_t plu = (uint64_t)W::uni64((int64_t)M.plen[u]);
+      const nd_t ndu = u == start ? (nd_t)0 : uni_t(M.nd[u]);
+      const len_t plu = uni_t(M.plen[u]);
       const uint32_t eb = eoff(u), ee = eoff(u + 1);
       bool us = false, ua = false;
       for (uint32_t base = eb; base < ee; base += W::WIDTH) {
@@ -938,7 +952,7 @@ struct GtsComponent {
           sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
           if (live && sense == du) {
             v = M.cend[ce];
-            const int64_t w = M.cdist[ce];
+            const nd_t w = (nd_t)M.cdist[ce];
             const float cand = u == start ? (float)w : (float)(ndu + w);
             take = cand == M.distmap[v] && !(orient[v] & 4u);
           }
@@ -949,7 +963,7 @@ struct GtsComponent {
         if (take) {
           orient[v] = (uint8_t)(orient[v] | 4u);
           M.edgemap[v] = ce;
-          M.plen[v] = plu + (uint64_t)M.cseq[v];
+          M.plen[v] = (len_t)(plu + (len_t)M.cseq[v]);
           BQ[bt + W::popc_below(tm, lane)] = v;
         }
         bt += W::popc(tm);
@@ -1041,14 +1055,14 @@ struct GtsComponent {
     bool inexact = false;     /* a label left the range where floats are exact */
     if (!bad) {
       TQ[0] = start;
-      M.plen[start] = (uint64_t)M.cseq[start];
+      M.plen[start] = (len_t)M.cseq[start];
       W::fence();
       while (qh2 < nq && !bad) {
         const uint32_t u = W::uni(TQ[qh2]);
         ++qh2; ++processed;
         const bool du = W::uni((uint32_t)orient[u]) == 2;
-        const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
-        const uint64_t plu = (uint64_t)W::uni64((int64_t)M.plen[u]);
+        const nd_t ndu = u == start ? (nd_t)0 : uni_t(M.nd[u]);
+        const len_t plu = uni_t(M.plen[u]);
         const uint32_t dpu = u == start ? 0 : W::uni(depth[u]);
         const uint32_t eb = eoff(u), ee = eoff(u + 1);
         bool us = false, ua = false;
@@ -1062,15 +1076,15 @@ struct GtsComponent {
             arc = live && sense == du;
             if (arc) {
               v = M.cend[ce];
-              const int64_t w = M.cdist[ce];
+              const nd_t w = (nd_t)M.cdist[ce];
               const float cand = u == start ? (float)w : (float)(ndu + w);
               const float old = M.distmap[v];
               if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
               if (old == GTS_DIST_UNSET || old > cand) {
                 M.distmap[v] = cand;
                 M.edgemap[v] = ce;
-                M.nd[v] = u == start ? w : (int64_t)cand;
-                M.plen[v] = plu + (uint64_t)M.cseq[v];
+                M.nd[v] = u == start ? w : (nd_t)cand;
+                M.plen[v] = (len_t)(plu + (len_t)M.cseq[v]);
                 depth[v] = dpu + 1;
               } else if (old == cand)
                 tie = true;
@@ -1094,7 +1108,7 @@ struct GtsComponent {
             const uint32_t up = W::uni(M.cstart[W::uni(M.edgemap[tv])]);
             if (pushed_after(up, u, start)) {       /* u's value came first */
               M.edgemap[tv] = tce;
-              M.plen[tv] = plu + (uint64_t)W::uni64(M.cseq[tv]);
+              M.plen[tv] = (len_t)(plu + (len_t)uni_t(M.cseq[tv]));
               depth[tv] = dpu + 1;
               W::fence();
             }
@@ -1324,7 +1338,7 @@ struct GtsComponent {
     uint32_t nr = 0, pending = 1, best_t = GTS_NONE;
     uint64_t best_len = 0;
     bool inexact = false, bad = false;
-    M.plen[start] = (uint64_t)M.cseq[start];
+    M.plen[start] = (len_t)M.cseq[start];
     depth[start] = 0;
     M.nd[start] = 0;
     W::fence();
@@ -1350,8 +1364,8 @@ struct GtsComponent {
         const uint32_t u = W::bcast(cv, l);
         --pending;
         const bool du = ((W::uni((uint32_t)M.gorient[u]) & 3u) == 2) == forward;
-        const int64_t ndu = u == start ? 0 : W::uni64(M.nd[u]);
-        const uint64_t plu = (uint64_t)W::uni64((int64_t)M.plen[u]);
+        const nd_t ndu = u == start ? (nd_t)0 : uni_t(M.nd[u]);
+        const len_t plu = uni_t(M.plen[u]);
         const uint32_t dpu = u == start ? 0 : W::uni(depth[u]);
         const uint32_t eb = eoff(u), ee = eoff(u + 1);
         bool us = false, ua = false;
@@ -1365,7 +1379,7 @@ struct GtsComponent {
             arc = live && sense == du;
             if (arc) {
               v = M.cend[ce];
-              const int64_t w = M.cdist[ce];
+              const nd_t w = (nd_t)M.cdist[ce];
               const float cand = u == start ? (float)w : (float)(ndu + w);
               const float old = M.distmap[v];
               if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
@@ -1373,8 +1387,8 @@ struct GtsComponent {
                 fresh = old == GTS_DIST_UNSET;
                 M.distmap[v] = cand;
                 M.edgemap[v] = ce;
-                M.nd[v] = u == start ? w : (int64_t)cand;
-                M.plen[v] = plu + (uint64_t)M.cseq[v];
+                M.nd[v] = u == start ? w : (nd_t)cand;
+                M.plen[v] = (len_t)(plu + (len_t)M.cseq[v]);
                 depth[v] = dpu + 1;
               } else if (old == cand)
                 tie = true;
@@ -1396,7 +1410,7 @@ struct GtsComponent {
             const uint32_t up = W::uni(M.cstart[W::uni(M.edgemap[tv])]);
             if (pushed_after(up, u, start)) {
               M.edgemap[tv] = tce;
-              M.plen[tv] = plu + (uint64_t)W::uni64(M.cseq[tv]);
+              M.plen[tv] = (len_t)(plu + (len_t)uni_t(M.cseq[tv]));
               depth[tv] = dpu + 1;
               W::fence();
             }

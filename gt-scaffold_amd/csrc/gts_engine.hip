@@ -714,7 +714,8 @@ __global__ void k_slot_finish(const uint32_t *labels, const uint32_t *cidx,
 __global__ void k_slot_bases(const uint32_t *head, const uint32_t *cidx,
                              const uint32_t *comp_off, const int64_t *cseq,
                              uint32_t *slot_base, uint32_t *slot_comp,
-                             uint8_t *comp_wide, uint32_t nslots)
+                             uint8_t *comp_wide, unsigned long long *comp_len,
+                             uint32_t nslots)
 {
   uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nslots) return;
@@ -723,6 +724,7 @@ __global__ void k_slot_bases(const uint32_t *head, const uint32_t *cidx,
   slot_comp[s] = c;
   const int64_t l = cseq[s];
   if (l != (int32_t)l) comp_wide[c] = 1;
+  atomicAdd(&comp_len[c], (unsigned long long)l);   /* bases of the component (len_t of the LDS layout) */
 }
 /* an edge enters the compact graph if it or its twin is live: marking a walk
    edge's twin SCAFFOLD (algorithms.c:842-845) revives a marked twin.  One lane
@@ -760,7 +762,8 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart, const uin
   const bool uturn = ((ft & GTS_F_SENSE) != 0) == gts_next_dir(f);
   cstart[k] = s - base; cend[k] = slot_of[G.end[p]] - base;
   const int64_t d = G.dist[p];
-  if (d != (int32_t)d) comp_wide[slot_comp[s]] = 1;
+  /* the LDS layout adds up to 4095 distances in 32 bits (nd_t) */
+  if (d >= (1 << 19) || d <= -(1 << 19)) comp_wide[slot_comp[s]] = 1;
   cdist[k] = d;
   cflags[k] = (uint8_t)((f & 3u) | (uturn ? GTS_F_UTURN : 0u) |
                         ((ft & 0x80u) ? GTS_F_TWINLIVE : 0u));
@@ -774,8 +777,9 @@ struct GtsWave64 {
   static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
   static __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
   static __device__ __forceinline__ uint32_t popc(uint64_t m) { return (uint32_t)__popcll(m); }
-  static __device__ __forceinline__ uint32_t popc_below(uint64_t m, uint32_t l)
-  { return (uint32_t)__popcll(m & ((1ull << l) - 1ull)); }
+  /* set bits of m below the calling lane (l is always lane()): v_mbcnt_lo/hi */
+  static __device__ __forceinline__ uint32_t popc_below(uint64_t m, uint32_t)
+  { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
   static __device__ __forceinline__ uint32_t ctz(uint64_t m) { return (uint32_t)__ffsll((long long)m) - 1u; }
   static __device__ __forceinline__ uint32_t msb(uint64_t m) { return 63u - (uint32_t)__clzll((long long)m); }
   static __device__ __forceinline__ uint32_t shfl(uint32_t v, uint32_t l) { return (uint32_t)__shfl((int)v, (int)l); }
@@ -884,7 +888,7 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   M.topo = lds_carve<idx_t>(p, nv); M.tpos = lds_carve<idx_t>(p, nv);
   M.lastpop = lds_carve<uint32_t>(p, nv); M.distmap = lds_carve<float>(p, nv);
   auto cseq = lds_carve<int32_t>(p, nv);
-  M.nd = lds_carve<int64_t>(p, nv); M.plen = lds_carve<uint64_t>(p, nv);
+  M.nd = lds_carve<int32_t>(p, nv); M.plen = lds_carve<uint32_t>(p, nv);
   M.vst = lds_carve<uint8_t>(p, nv); M.st_dir = lds_carve<uint8_t>(p, nv);
   M.tight = lds_carve<uint8_t>(p, nv); M.gorient = lds_carve<uint8_t>(p, nv);
   auto cstart = lds_carve<idx_t>(p, ne);
@@ -964,8 +968,8 @@ k_select_walks(GtsCompView C, uint32_t ndeferred)
    components fit each size class */
 __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 uint32_t *keys, uint32_t *vals, uint32_t ncomp,
-                                const uint8_t *comp_wide, uint8_t *comp_klass,
-                                const uint32_t *klass, uint32_t nklass,
+                                const uint8_t *comp_wide, const unsigned long long *comp_len,
+                                uint8_t *comp_klass, const uint32_t *klass, uint32_t nklass,
                                 uint32_t *klass_count, unsigned long long *klass_bytes,
                                 uint32_t *klass_slots)
 {
@@ -981,7 +985,8 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
     const uint32_t cnv = s1 - s0, cne = coff[s1] - coff[s0];
     uint32_t need = gts_comp_lds_bytes(cnv, cne);
     /* not representable in the packed LDS layout: run from global memory */
-    if (comp_wide[c] || cnv > GTS_LDS_MAX_INDEX || cne > GTS_LDS_MAX_INDEX) need = 0x7FFFFFFFu;
+    if (comp_wide[c] || cnv >= 4096u || cne > GTS_LDS_MAX_INDEX || comp_len[c] >= (1ull << 32))
+      need = 0x7FFFFFFFu;
     keys[c] = ~need;   /* ascending sort = largest first */
     vals[c] = (uint32_t)c;
     uint32_t k = 0;
@@ -1608,8 +1613,10 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(slot_base, uint32_t, nslots);
     PALLOC(slot_comp, uint32_t, nslots); PALLOC(comp_wide, uint8_t, (size_t)ncomp + 1);
     HIPCHK(hipMemsetAsync(comp_wide, 0, (size_t)ncomp + 1, e->st));
+    PALLOC(comp_len, unsigned long long, (size_t)ncomp + 1);
+    HIPCHK(hipMemsetAsync(comp_len, 0, ((size_t)ncomp + 1) * 8, e->st));
     LAUNCH("comp_slot_bases", k_slot_bases, nblk(nslots), GTS_BLOCK, head, cidx, comp_off, cseq,
-           slot_base, slot_comp, comp_wide, nslots);
+           slot_base, slot_comp, comp_wide, comp_len, nslots);
     PALLOC(coff, uint32_t, (size_t)nslots + 1);
     PALLOC(incl, uint32_t, (size_t)m + 1); PALLOC(ipos, uint32_t, (size_t)m + 2);
     if (m) LAUNCH("comp_compact_flags", k_compact_flags, nblk(m), GTS_BLOCK, live, e->twin, incl, m);
@@ -1672,7 +1679,7 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_KSIZE, 0, (GTS_S_NDEF + 4 - GTS_S_KSIZE) * 4, e->st));
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, sizeof gts_klass_bytes, hipMemcpyHostToDevice, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
-           ncomp, comp_wide, comp_klass, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
+           ncomp, comp_wide, comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
            (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS);
     LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + GTS_S_KSLOTS, e->d_scalars + GTS_S_TQBASE);
     const uint32_t *order;

@@ -128,6 +128,22 @@ def test_misjoin_heavy_graphs_need_no_reference_search(seed):
     assert eng.stat("slow_walks") == 0 and eng.stat("fast_walks") > 0
 
 
+@pytest.mark.parametrize("what", ["distances", "lengths", "length_sums"])
+def test_values_the_packed_lds_layout_cannot_carry(what):
+    """components with a distance of 2^19 or more, a contig of 2^31 bases or
+    contigs adding up to 2^32 bases run from global memory (64-bit labels)"""
+    g = make_inputs(4000, 77, p_chimeric=0.03)
+    if what == "distances":
+        g["dist"] = g["dist"] * 4096
+    elif what == "lengths":
+        g["seq_len"] = g["seq_len"].copy()
+        g["seq_len"][::97] += 1 << 31
+    else:
+        g["seq_len"] = g["seq_len"] + (1 << 29)
+    eng, _ = run_pipeline(g, ocutoff=400 if what == "distances" else 1 << 40)
+    assert eng.stat("components_global_mem") > 0
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_deferred_walk_tasks(seed):
     """large clean components fan their walks out to one workgroup per
