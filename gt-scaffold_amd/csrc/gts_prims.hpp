@@ -22,7 +22,7 @@
 #define GTS_WAVE 64
 #define GTS_SCAN_ITEMS 8
 #define GTS_SCAN_TILE (GTS_BLOCK * GTS_SCAN_ITEMS)
-#define GTS_SORT_ITEMS 8
+#define GTS_SORT_ITEMS 16
 #define GTS_SORT_TILE (GTS_BLOCK * GTS_SORT_ITEMS)
 
 __device__ __forceinline__ uint32_t gts_lane() { return threadIdx.x & 63u; }
@@ -193,8 +193,9 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
     rank[i] = prev + (uint32_t)__popcll(peers & lt);
   }
   __syncthreads();
-  {
-    /* thread d: turn per-wave counts of digit d into global start offsets */
+  if constexpr (sizeof(K) > 4) {
+    /* 64-bit keys: straight from the registers (the staging below would cost
+       a third of the resident waves: measured slower) */
     const uint32_t d = threadIdx.x;
     uint32_t run = offs[(uint64_t)d * ntiles + blockIdx.x];
 #pragma unroll
@@ -203,16 +204,61 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
       cnt[i][d] = run;
       run += c;
     }
-  }
-  __syncthreads();
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
-    const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
-    if (idx < n) {
-      const uint32_t d = (uint32_t)(key[i] >> shift) & 255u;
-      const uint32_t dst = cnt[w][d] + rank[i];
-      okeys[dst] = key[i];
-      ovals[dst] = val[i];
+    for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
+      const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
+      if (idx < n) {
+        const uint32_t dg = (uint32_t)(key[i] >> shift) & 255u;
+        const uint32_t dst = cnt[w][dg] + rank[i];
+        okeys[dst] = key[i];
+        ovals[dst] = val[i];
+      }
+    }
+  } else {
+    /* 32-bit keys: the tile is first put in digit order in LDS, then written
+       out by consecutive threads: elements of one digit go to consecutive
+       addresses, so every run of a digit is written as whole lines instead of
+       one store per lane into 64 different lines. */
+    __shared__ K s_key[GTS_SORT_TILE];
+    __shared__ uint32_t s_val[GTS_SORT_TILE];
+    __shared__ uint32_t s_goff[256];
+    {
+      /* thread d: per-wave counts of digit d -> starts inside the digit's run;
+         digit totals -> start of the run in the tile (block scan) */
+      const uint32_t d = threadIdx.x;
+      uint32_t run = 0;
+#pragma unroll
+      for (int i = 0; i < GTS_BLOCK / GTS_WAVE; ++i) {
+        const uint32_t c = cnt[i][d];
+        cnt[i][d] = run;
+        run += c;
+      }
+      uint32_t total;
+      const uint32_t lbase = gts_block_exscan<uint32_t>(run, total);
+#pragma unroll
+      for (int i = 0; i < GTS_BLOCK / GTS_WAVE; ++i) cnt[i][d] += lbase;
+      s_goff[d] = offs[(uint64_t)d * ntiles + blockIdx.x] - lbase;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
+      const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
+      if (idx < n) {
+        const uint32_t d = (uint32_t)(key[i] >> shift) & 255u;
+        const uint32_t pos = cnt[w][d] + rank[i];
+        s_key[pos] = key[i];
+        s_val[pos] = val[i];
+      }
+    }
+    __syncthreads();
+    const uint64_t tbase = (uint64_t)blockIdx.x * GTS_SORT_TILE;
+    const uint32_t tcount = n - tbase < GTS_SORT_TILE ? (uint32_t)(n - tbase) : (uint32_t)GTS_SORT_TILE;
+    for (uint32_t t = threadIdx.x; t < tcount; t += GTS_BLOCK) {
+      const K k = s_key[t];
+      const uint32_t dst = s_goff[(uint32_t)(k >> shift) & 255u] + t;
+      okeys[dst] = k;
+      ovals[dst] = s_val[t];
     }
   }
 }
