@@ -194,26 +194,56 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
   }
   __syncthreads();
   if constexpr (sizeof(K) > 4) {
-    /* 64-bit keys: straight from the registers (the staging below would cost
-       a third of the resident waves: measured slower) */
-    const uint32_t d = threadIdx.x;
-    uint32_t run = offs[(uint64_t)d * ntiles + blockIdx.x];
+    /* 64-bit keys: as below, but keys and values take turns in the same
+       32 KB of LDS (both at once would cost a third of the resident waves) */
+    __shared__ K s_key[GTS_SORT_TILE];
+    __shared__ uint32_t s_goff[256];
+    uint32_t *s_val = (uint32_t *)s_key;
+    {
+      const uint32_t d = threadIdx.x;
+      uint32_t run = 0;
 #pragma unroll
-    for (int i = 0; i < GTS_BLOCK / GTS_WAVE; ++i) {
-      const uint32_t c = cnt[i][d];
-      cnt[i][d] = run;
-      run += c;
+      for (int i = 0; i < GTS_BLOCK / GTS_WAVE; ++i) {
+        const uint32_t c = cnt[i][d];
+        cnt[i][d] = run;
+        run += c;
+      }
+      uint32_t total;
+      const uint32_t lbase = gts_block_exscan<uint32_t>(run, total);
+#pragma unroll
+      for (int i = 0; i < GTS_BLOCK / GTS_WAVE; ++i) cnt[i][d] += lbase;
+      s_goff[d] = offs[(uint64_t)d * ntiles + blockIdx.x] - lbase;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
       const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
-      if (idx < n) {
-        const uint32_t dg = (uint32_t)(key[i] >> shift) & 255u;
-        const uint32_t dst = cnt[w][dg] + rank[i];
-        okeys[dst] = key[i];
-        ovals[dst] = val[i];
+      if (idx < n) s_key[cnt[w][(uint32_t)(key[i] >> shift) & 255u] + rank[i]] = key[i];
+    }
+    __syncthreads();
+    const uint64_t tbase = (uint64_t)blockIdx.x * GTS_SORT_TILE;
+    const uint32_t tcount = n - tbase < GTS_SORT_TILE ? (uint32_t)(n - tbase) : (uint32_t)GTS_SORT_TILE;
+    uint32_t dst[GTS_SORT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
+      const uint32_t t = threadIdx.x + (uint32_t)i * GTS_BLOCK;
+      if (t < tcount) {
+        const K k = s_key[t];
+        dst[i] = s_goff[(uint32_t)(k >> shift) & 255u] + t;
+        okeys[dst[i]] = k;
       }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
+      const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
+      if (idx < n) s_val[cnt[w][(uint32_t)(key[i] >> shift) & 255u] + rank[i]] = val[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
+      const uint32_t t = threadIdx.x + (uint32_t)i * GTS_BLOCK;
+      if (t < tcount) ovals[dst[i]] = s_val[t];
     }
   } else {
     /* 32-bit keys: the tile is first put in digit order in LDS, then written
