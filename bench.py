@@ -175,9 +175,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the engine has no CPU path")
+    # rehearsal on a box with fewer GPUs than ranks (not a measurement):
+    # GTS_BENCH_BACKEND=gloo maps the ranks onto the devices there are
+    backend = os.environ.get("GTS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     pkg = load_package()
     dev = "cuda:%d" % local_rank
 
@@ -246,8 +254,9 @@ def main():
         edges += step()
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    etot = torch.tensor([edges], dtype=torch.float64, device=dev)
+    rdev = dev if backend == "nccl" else "cpu"
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    etot = torch.tensor([edges], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(etot, op=dist.ReduceOp.SUM)
