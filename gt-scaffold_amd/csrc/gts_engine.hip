@@ -775,7 +775,7 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart, const uin
 struct GtsWave64 {
   static const uint32_t WIDTH = 64;
   static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
-  static __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+  static __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
   static __device__ __forceinline__ uint32_t popc(uint64_t m) { return (uint32_t)__popcll(m); }
   /* set bits of m below the calling lane (l is always lane()): v_mbcnt_lo/hi */
   static __device__ __forceinline__ uint32_t popc_below(uint64_t m, uint32_t)

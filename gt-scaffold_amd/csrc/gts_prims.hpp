@@ -177,10 +177,10 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
     key[i] = valid ? keys[idx] : (K)0;
     val[i] = valid ? vals[idx] : 0u;
     const uint32_t d = (uint32_t)(key[i] >> shift) & 255u;
-    uint64_t peers = __ballot(valid);
+    uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const uint64_t bm = __ballot(valid && ((d >> b) & 1u));
+      const uint64_t bm = __builtin_amdgcn_ballot_w64(valid && ((d >> b) & 1u));
       peers &= ((d >> b) & 1u) ? bm : ~bm;
     }
     uint32_t prev = 0;
