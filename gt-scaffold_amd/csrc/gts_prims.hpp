@@ -138,6 +138,14 @@ static void gts_exscan(const TI *in, TO *out, uint64_t n, TO *tmp, TO *total,
 /* ------------------------------------------------------------------ */
 /* radix sort */
 
+/* 8-bit digit of a key.  Bit 63 of a 64-bit key is payload that rides along
+   (gts_engine.hip, k_pair_keys) and never takes part in the order. */
+__device__ __forceinline__ uint32_t gts_digit(uint32_t key, int shift) { return (key >> shift) & 255u; }
+__device__ __forceinline__ uint32_t gts_digit(uint64_t key, int shift)
+{
+  return (uint32_t)((key & ~(1ull << 63)) >> shift) & 255u;
+}
+
 template <typename K>
 __global__ void __launch_bounds__(GTS_BLOCK)
 k_radix_hist(const K *keys, uint64_t n, int shift, uint32_t *hist,
@@ -150,7 +158,7 @@ k_radix_hist(const K *keys, uint64_t n, int shift, uint32_t *hist,
 #pragma unroll
   for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
     const uint64_t idx = base + (uint64_t)i * GTS_BLOCK + threadIdx.x;
-    if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
+    if (idx < n) atomicAdd(&h[gts_digit(keys[idx], shift)], 1u);
   }
   __syncthreads();
   hist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
@@ -176,7 +184,7 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
     const bool valid = idx < n;
     key[i] = valid ? keys[idx] : (K)0;
     val[i] = valid ? vals[idx] : 0u;
-    const uint32_t d = (uint32_t)(key[i] >> shift) & 255u;
+    const uint32_t d = gts_digit(key[i], shift);
     uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -218,7 +226,7 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
 #pragma unroll
     for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
       const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
-      if (idx < n) s_key[cnt[w][(uint32_t)(key[i] >> shift) & 255u] + rank[i]] = key[i];
+      if (idx < n) s_key[cnt[w][gts_digit(key[i], shift)] + rank[i]] = key[i];
     }
     __syncthreads();
     const uint64_t tbase = (uint64_t)blockIdx.x * GTS_SORT_TILE;
@@ -229,7 +237,7 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
       const uint32_t t = threadIdx.x + (uint32_t)i * GTS_BLOCK;
       if (t < tcount) {
         const K k = s_key[t];
-        dst[i] = s_goff[(uint32_t)(k >> shift) & 255u] + t;
+        dst[i] = s_goff[gts_digit(k, shift)] + t;
         okeys[dst[i]] = k;
       }
     }
@@ -237,7 +245,7 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
 #pragma unroll
     for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
       const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
-      if (idx < n) s_val[cnt[w][(uint32_t)(key[i] >> shift) & 255u] + rank[i]] = val[i];
+      if (idx < n) s_val[cnt[w][gts_digit(key[i], shift)] + rank[i]] = val[i];
     }
     __syncthreads();
 #pragma unroll
@@ -275,7 +283,7 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
     for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
       const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
       if (idx < n) {
-        const uint32_t d = (uint32_t)(key[i] >> shift) & 255u;
+        const uint32_t d = gts_digit(key[i], shift);
         const uint32_t pos = cnt[w][d] + rank[i];
         s_key[pos] = key[i];
         s_val[pos] = val[i];
@@ -286,7 +294,7 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
     const uint32_t tcount = n - tbase < GTS_SORT_TILE ? (uint32_t)(n - tbase) : (uint32_t)GTS_SORT_TILE;
     for (uint32_t t = threadIdx.x; t < tcount; t += GTS_BLOCK) {
       const K k = s_key[t];
-      const uint32_t dst = s_goff[(uint32_t)(k >> shift) & 255u] + t;
+      const uint32_t dst = s_goff[gts_digit(k, shift)] + t;
       okeys[dst] = k;
       ovals[dst] = s_val[t];
     }

@@ -128,6 +128,28 @@ def test_misjoin_heavy_graphs_need_no_reference_search(seed):
     assert eng.stat("slow_walks") == 0 and eng.stat("fast_walks") > 0
 
 
+def test_contig_ids_above_2_to_24():
+    """more than 2^24 contigs: the pair sort's last digit reaches bit 63 of the
+    key, which carries a flag that must not take part in the order"""
+    g = make_inputs(6000, 41, p_relist=0.05, p_chimeric=0.03)
+    off = (1 << 24) + 1234
+    n = off + g["seq_len"].size
+    big = dict(g)
+    for k, fill in (("seq_len", 1000), ("astat", 50.0), ("copy_num", 1.0)):
+        a = np.full(n, fill, dtype=g[k].dtype)
+        a[off:] = g[k]
+        big[k] = a
+    # every second contig keeps its small id: pairs straddle the 2^24 line
+    keep = np.arange(g["seq_len"].size) % 2 == 0
+    newid = np.where(keep, np.arange(g["seq_len"].size), np.arange(g["seq_len"].size) + off).astype(np.uint32)
+    for k in ("seq_len", "astat", "copy_num"):
+        big[k][newid] = g[k]
+    big["root"] = newid[g["root"]]
+    big["ctg"] = newid[g["ctg"]]
+    eng, og = run_pipeline(big)
+    assert eng.ne == og.ne and eng.ne > 0
+
+
 @pytest.mark.parametrize("what", ["distances", "lengths", "length_sums"])
 def test_values_the_packed_lds_layout_cannot_carry(what):
     """components with a distance of 2^19 or more, a contig of 2^31 bases or
