@@ -1175,8 +1175,9 @@ struct GtsComponent {
          is a topological order of D = forward arcs + reversed mirror arcs
          (from x's list: edges with sense == o(x) that are live or whose twin
          is), swept upwards on the forward sheet and downwards on the mirror.
-     The analysis costs two passes over the component; the result is dropped
-     as soon as a SCAFFOLD mark revives a marked twin (new arcs). */
+     The analysis costs two passes over the component.  It survives the
+     SCAFFOLD marks of makescaffold: a marked twin that turns SCAFFOLD is a new
+     live arc of one sheet, but D already holds it (its twin was live). */
   /* strands by a search over all compact edges, whatever their state.  False
      on a contradiction, a u-turn arc or a self loop. */
   GTS_HD bool orient()
@@ -1494,7 +1495,6 @@ struct GtsComponent {
         /* mark the best walk, algorithms.c:835-848 (a walk without edges is
            undefined behaviour there and is left unmarked here) */
         if (cc_n > 0) {
-          bool revived = false;
           for (uint32_t k = lane; k < cc_n; k += W::WIDTH) {
             const uint32_t ce = M.cc_best[k];
             const uint32_t p = C.cgpos[e0g + ce], t = C.G.twin[p];
@@ -1503,13 +1503,14 @@ struct GtsComponent {
             C.G.state[t] = GIS_SCAFFOLD;
             const uint32_t ct = C.cmap[t];
             if (ct != GTS_NONE) {
-              if (gts_edge_is_marked(M.cstate[ct - e0g])) revived = true;   /* new arc */
               M.cstate[ct - e0g] = GIS_SCAFFOLD;
             }
             M.vst[M.cend[ce]] = GIS_SCAFFOLD;
             M.vst[M.cstart[ce]] = GIS_SCAFFOLD;
           }
-          if (W::ballot(revived)) clean = false;
+          /* a marked twin that turns SCAFFOLD is a new live arc, but not a new
+             arc of D (d_arc counts an edge whose twin is live): the component
+             stays clean, its sweep order holds */
           W::fence();
         }
       }
@@ -1603,10 +1604,7 @@ struct GtsComponent {
   GTS_HD void walk_task(uint64_t t)
   {
     const uint32_t lane = W::lane();
-    /* 2: clean; 3: strands assigned but new arcs since the last peeling --
-       the order is recomputed here (one pass, then every walk is one sweep) */
-    const uint32_t df = W::uni((uint32_t)C.defer_flag[c]);
-    clean = df == 2 || (df == 3 && peel());
+    clean = W::uni((uint32_t)C.defer_flag[c]) == 2;   /* revived twins do not change D */
     const uint32_t nw = (nv + 31) / 32;
     reach_bits = C.paths + C.task_roff[t];
     no_reference = true;
@@ -1760,9 +1758,7 @@ struct GtsComponent {
     }
     if (lane == 0) {
       C.comp_next_cc[c] = i;
-      /* new arcs: the sweep order of a clean component is void (the strands hold) */
-      const uint8_t df = C.defer_flag[c];
-      C.defer_flag[c] = i == ncc ? 0 : (revived_any && df == 2 ? 3 : df);
+      if (i == ncc) C.defer_flag[c] = 0;
     }
     W::fence();
     return i < ncc;
