@@ -85,7 +85,7 @@ struct GtsgEngine {
   int64_t walk_pool_entries = 1ll << 26;
   int64_t class_streams = GTS_NSTREAMS;
   int64_t mixed_task_limit = 256;
-  int64_t defer_min_contigs = 320, walk_path_entries = 1ll << 24;
+  int64_t defer_min_contigs = 256, walk_path_entries = 1ll << 24;
   int64_t fast_walks = 1, lds_components = 1;
   int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
   /* profiling */

@@ -130,7 +130,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      2 = also the three slowest components as "top<r>_*" statistics),
      "fast_walks" (default 1; 0 forces the reference's label-correcting search
      for every walk), "lds_components" (default 1; 0 runs every component
-     from global memory), "defer_min_contigs" (default 320; components with at
+     from global memory), "defer_min_contigs" (default 256; components with at
      least that many contigs hand their walks to one workgroup per terminal,
      0 = never), "class_streams" (default 6: side streams the LDS size classes
      are launched on), "mixed_task_limit" (default 256: a round with at most
