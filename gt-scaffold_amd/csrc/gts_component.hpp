@@ -202,8 +202,11 @@ GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
   const uint32_t a = 16;
   uint32_t b = 0;
   b += (((nv + 1) * 2 + a - 1) / a) * a * 2;          /* coff, ccoff */
-  b += ((nv * 2 + a - 1) / a) * a * 12;               /* queue .. cc_best, topo, tpos */
-  b += ((nv * 4 + a - 1) / a) * a * 5;                /* lastpop, distmap, cseq, nd, plen */
+  /* scratch that is never live at the same time shares storage: st_cur (cycle
+     search) with cc_best (walks), touched (reference search) with visited,
+     lastpop (reference search, zeroed on entry) with nd (linear walks) */
+  b += ((nv * 2 + a - 1) / a) * a * 10;               /* queue .. cc_best, topo, tpos */
+  b += ((nv * 4 + a - 1) / a) * a * 4;                /* distmap, cseq, nd, plen */
   b += ((nv + a - 1) / a) * a * 4;                    /* vst, st_dir, tight, gorient */
   b += ((ne * 2 + a - 1) / a) * a * 2;                /* cstart, cend */
   b += ((ne * 4 + a - 1) / a) * a;                    /* cdist */
@@ -569,6 +572,9 @@ struct GtsComponent {
     qh = 0; qn = 0; ntouch = 0;
     uint32_t nwt = 0;
     bool ok = true;
+    /* lastpop may share its storage with the labels of the linear walks */
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) M.lastpop[s] = 0;
+    W::fence();
     /* seed with the start's live edges, algorithms.c:661-679 */
     {
       const uint32_t eb = eoff(start), ee = eoff(start + 1);

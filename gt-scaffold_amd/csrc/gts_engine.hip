@@ -882,13 +882,16 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   M.ccoff = lds_carve<idx_t>(p, nv + 1);
   M.queue = lds_carve<idx_t>(p, nv); M.term = lds_carve<idx_t>(p, nv);
   M.visited = lds_carve<idx_t>(p, nv); M.st_v = lds_carve<idx_t>(p, nv);
-  M.st_par = lds_carve<idx_t>(p, nv); M.st_cur = lds_carve<idx_t>(p, nv);
+  M.st_par = lds_carve<idx_t>(p, nv);
   M.edgemap = lds_carve<idx_t>(p, nv); M.wterm = lds_carve<idx_t>(p, nv);
-  M.touched = lds_carve<idx_t>(p, nv); M.cc_best = lds_carve<idx_t>(p, nv);
+  M.cc_best = lds_carve<idx_t>(p, nv);
   M.topo = lds_carve<idx_t>(p, nv); M.tpos = lds_carve<idx_t>(p, nv);
-  M.lastpop = lds_carve<uint32_t>(p, nv); M.distmap = lds_carve<float>(p, nv);
+  M.distmap = lds_carve<float>(p, nv);
   auto cseq = lds_carve<int32_t>(p, nv);
   M.nd = lds_carve<int32_t>(p, nv); M.plen = lds_carve<uint32_t>(p, nv);
+  /* never live at the same time (gts_comp_lds_bytes) */
+  M.st_cur = M.cc_best; M.touched = M.visited;
+  M.lastpop = (uint32_t __attribute__((address_space(3))) *)M.nd;
   M.vst = lds_carve<uint8_t>(p, nv); M.st_dir = lds_carve<uint8_t>(p, nv);
   M.tight = lds_carve<uint8_t>(p, nv); M.gorient = lds_carve<uint8_t>(p, nv);
   auto cstart = lds_carve<idx_t>(p, ne);
@@ -899,7 +902,7 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   for (uint32_t i = lane; i <= nv; i += GTS_WAVE) coff[i] = (idx_t)(G0.coff[i] - G0.e0);
   for (uint32_t i = lane; i < nv; i += GTS_WAVE) {
     cseq[i] = (int32_t)G0.cseq[i]; M.vst[i] = G0.vst[i];
-    M.lastpop[i] = 0; M.distmap[i] = GTS_DIST_UNSET; M.st_dir[i] = 0; M.tight[i] = 0;
+    M.distmap[i] = GTS_DIST_UNSET; M.st_dir[i] = 0; M.tight[i] = 0;
     if (with_analysis) {
       M.gorient[i] = G0.gorient[i]; M.topo[i] = (idx_t)G0.topo[i]; M.tpos[i] = (idx_t)G0.tpos[i];
     }
