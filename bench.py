@@ -329,6 +329,9 @@ def main():
                        walk_tasks=eng.stat("walk_tasks"), walk_task_rounds=eng.stat("walk_task_rounds"),
                        walk_task_runs=eng.stat("walk_task_runs"),
                        deferred_components=eng.stat("deferred_components"),
+                       by_size={"<=%s" % b: dict(components=eng.stat("size_band%d_components" % i),
+                                                 wave_us=eng.stat("size_band%d_us" % i))
+                                for i, b in enumerate(("2", "3", "4", "8", "16", "32", "64", "inf"))},
                        slowest_components=[
                            {k: eng.stat("top%d_%s" % (r, k)) for k in
                             ("size", "edges", "terminals", "clean", "deferred", "why_not_deferred", "walks",

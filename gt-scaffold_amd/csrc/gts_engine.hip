@@ -1869,6 +1869,22 @@ static int run_components(GtsgEngine *e, int mode)
       HIPCHK(hipMemcpy(hc.data(), stat_clean, (size_t)ncomp * 4, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(ho.data(), comp_off, ((size_t)ncomp + 1) * 4, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(hco.data(), coff, ((size_t)nslots + 1) * 4, hipMemcpyDeviceToHost));
+      {   /* component sizes and the time spent per size band */
+        static const uint32_t band[8] = {2, 3, 4, 8, 16, 32, 64, 0xFFFFFFFFu};
+        uint64_t bc[8] = {0}, bt[8] = {0};
+        for (uint32_t c2 = 0; c2 < ncomp; ++c2) {
+          const uint32_t sz = ho[c2 + 1] - ho[c2];
+          int b = 0;
+          while (sz > band[b]) ++b;
+          ++bc[b];
+          const uint64_t *t = &ht[5 * (size_t)c2];
+          bt[b] += t[0] + t[1] + t[2] + t[3];
+        }
+        for (int b = 0; b < 8; ++b) {
+          e->stats["size_band" + std::to_string(b) + "_components"] = (int64_t)bc[b];
+          e->stats["size_band" + std::to_string(b) + "_us"] = (int64_t)(bt[b] / 100);
+        }
+      }
       auto total = [&](uint32_t c2) { const uint64_t *t = &ht[5 * (size_t)c2]; return t[0] + t[1] + t[2] + t[3]; };
       for (int r = 0; r < 12 && r < (int)ncomp; ++r) {
         uint32_t best = 0;
