@@ -1454,8 +1454,8 @@ struct GtsComponent {
 
   GTS_HD bool create_walk(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
-    const uint32_t gv = C.slot_v[s0 + start];
-    if (W::uni(C.G.row[gv + 1]) == W::uni(C.G.row[gv])) return true; /* :655 */
+    /* (the reference's test for a start without any edge, algorithms.c:655,
+       cannot fire: a vertex is in a component because it has a live edge) */
     const uint64_t t0 = W::clock();
     if (C.fast_walks && (clean ? create_walk_clean(start, cc_len, cc_n)
                                : create_walk_fast(start, cc_len, cc_n))) {
