@@ -82,6 +82,7 @@ struct GtsCompView {
   int64_t *nd;               /* slot -> integer label pushed with the node */
   uint64_t *plen;            /* slot -> contig length of the tree path */
   uint8_t *tight;            /* slot -> number of tight in-arcs (saturating) */
+  uint32_t *par;             /* nslots: parent vertex of the linear walks */
   uint8_t *gorient;          /* slot -> strand + 1 of the whole-component analysis */
   uint32_t *topo, *tpos;     /* topological order of the forward sheet, inverse */
   uint32_t *stat_clean;      /* per component: bit0 the analysis succeeded, bit1 walks deferred,
@@ -133,6 +134,54 @@ template <class T> struct GtsPtrSel<T, true> {
 #endif
 #define GTS_P(T) typename GtsPtrSel<T, LDS>::type
 
+/* Per-edge arrays of the working set.  In the global arrays the start vertex,
+   the flags and the state of a compact edge are arrays of their own.  The LDS
+   copy spends 7 instead of 10 bytes per edge: flags (low nibble) and state
+   (high nibble) share a byte, and the start vertex is not stored -- the few
+   places that need it outside the walks' parent array search the offsets. */
+template <bool LDS> struct GtsEdgeArrays {
+  typedef uint8_t *flags_t; typedef uint8_t *state_t; typedef const uint32_t *start_t;
+};
+#if defined(__HIPCC__)
+typedef uint8_t __attribute__((address_space(3))) *gts_lds_u8p;
+struct GtsLdsStateRef {
+  gts_lds_u8p p;
+  __device__ __forceinline__ operator uint8_t() const { return (uint8_t)(*p >> 4); }
+  __device__ __forceinline__ void operator=(uint8_t st) const { *p = (uint8_t)((*p & 15u) | (st << 4)); }
+  __device__ __forceinline__ void operator=(const GtsLdsStateRef &o) const { *this = (uint8_t)o; }
+};
+struct GtsLdsFlagsRef {
+  gts_lds_u8p p;
+  __device__ __forceinline__ operator uint8_t() const { return (uint8_t)(*p & 15u); }
+  __device__ __forceinline__ void operator=(uint8_t f) const { *p = (uint8_t)((*p & 0xF0u) | (f & 15u)); }
+  __device__ __forceinline__ void operator=(const GtsLdsFlagsRef &o) const { *this = (uint8_t)o; }
+};
+struct GtsLdsStateArr {
+  gts_lds_u8p b;
+  __device__ __forceinline__ GtsLdsStateRef operator[](uint32_t i) const { return GtsLdsStateRef{b + i}; }
+};
+struct GtsLdsFlagsArr {
+  gts_lds_u8p b;
+  __device__ __forceinline__ GtsLdsFlagsRef operator[](uint32_t i) const { return GtsLdsFlagsRef{b + i}; }
+};
+struct GtsLdsStartArr {
+  const uint16_t __attribute__((address_space(3))) *coff;   /* local offsets, nv + 1 */
+  uint32_t nv;
+  __device__ __forceinline__ uint32_t operator[](uint32_t ce) const
+  {
+    uint32_t lo = 0, hi = nv;          /* last vertex whose list starts at or before ce */
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (coff[mid] <= ce) lo = mid; else hi = mid;
+    }
+    return lo;
+  }
+};
+template <> struct GtsEdgeArrays<true> {
+  typedef GtsLdsFlagsArr flags_t; typedef GtsLdsStateArr state_t; typedef GtsLdsStartArr start_t;
+};
+#endif
+
 /* Element types of the working set.  In the global arrays everything is
    32 / 64 bit.  The LDS copy is packed: component-local slot and edge numbers
    fit 16 bits (a component that fits 160 KB of LDS has far fewer than 65535
@@ -163,12 +212,12 @@ struct GtsCompMemT {
   uint32_t nv, ne;           /* slots, compact edges of the component */
   uint32_t e0;               /* value to subtract from coff[] entries */
   GTS_P(const idx_t) coff;   /* nv+1 */
-  GTS_P(const idx_t) cstart;
+  typename GtsEdgeArrays<LDS>::start_t cstart;
   GTS_P(const idx_t) cend;
   GTS_P(const dist_t) cdist;
-  GTS_P(uint8_t) cflags;       /* GTS_F_TWINLIVE is cleared when a twin dies */
+  typename GtsEdgeArrays<LDS>::flags_t cflags;   /* GTS_F_TWINLIVE is cleared when a twin dies */
   GTS_P(const seq_t) cseq;
-  GTS_P(uint8_t) cstate;
+  typename GtsEdgeArrays<LDS>::state_t cstate;
   GTS_P(uint8_t) vst;
   GTS_P(idx_t) queue;
   GTS_P(idx_t) term;
@@ -177,6 +226,7 @@ struct GtsCompMemT {
   GTS_P(idx_t) st_par;
   GTS_P(idx_t) st_cur;
   GTS_P(idx_t) edgemap;
+  GTS_P(idx_t) par;          /* linear walks: start vertex of edgemap[v] */
   GTS_P(uint32_t) lastpop;
   GTS_P(idx_t) wterm;
   GTS_P(idx_t) touched;
@@ -205,12 +255,12 @@ GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
   /* scratch that is never live at the same time shares storage: st_cur (cycle
      search) with cc_best (walks), touched (reference search) with visited,
      lastpop (reference search, zeroed on entry) with nd (linear walks) */
-  b += ((nv * 2 + a - 1) / a) * a * 10;               /* queue .. cc_best, topo, tpos */
+  b += ((nv * 2 + a - 1) / a) * a * 11;               /* queue .. cc_best, par, topo, tpos */
   b += ((nv * 4 + a - 1) / a) * a * 4;                /* distmap, cseq, nd, plen */
   b += ((nv + a - 1) / a) * a * 4;                    /* vst, st_dir, tight, gorient */
-  b += ((ne * 2 + a - 1) / a) * a * 2;                /* cstart, cend */
+  b += ((ne * 2 + a - 1) / a) * a;                    /* cend */
   b += ((ne * 4 + a - 1) / a) * a;                    /* cdist */
-  b += ((ne + a - 1) / a) * a * 2;                    /* cflags, cstate */
+  b += ((ne + a - 1) / a) * a;                        /* flags + state */
   return b;
 }
 /* the packed layout addresses at most this many slots / edges */
@@ -256,7 +306,7 @@ struct GtsComponent {
     m.cstate = C.cstate + e0; m.vst = C.vst + s0;
     m.queue = C.queue + s0; m.term = C.term + s0; m.visited = C.visited + s0;
     m.st_v = C.st_v + s0; m.st_par = C.st_par + s0; m.st_cur = C.st_cur + s0;
-    m.edgemap = C.edgemap + s0; m.lastpop = C.lastpop + s0; m.wterm = C.wterm + s0;
+    m.edgemap = C.edgemap + s0; m.par = C.par + s0; m.lastpop = C.lastpop + s0; m.wterm = C.wterm + s0;
     m.touched = C.touched + s0; m.cc_best = C.cc_best + s0;
     m.ccoff = C.ccoff + s0 + comp; m.st_dir = C.st_dir + s0; m.tight = C.tight + s0;
     m.distmap = C.distmap + s0; m.nd = C.nd + s0; m.plen = C.plen + s0;
@@ -834,10 +884,10 @@ struct GtsComponent {
     const uint32_t db = b == start ? 0 : W::uni(M.st_par[b]);
     if (da != db) return da > db;
     uint32_t ea = W::uni(M.edgemap[a]), eb = W::uni(M.edgemap[b]);
-    uint32_t pa = W::uni(M.cstart[ea]), pb = W::uni(M.cstart[eb]);
+    uint32_t pa = W::uni(M.par[a]), pb = W::uni(M.par[b]);
     while (pa != pb) {
       ea = W::uni(M.edgemap[pa]); eb = W::uni(M.edgemap[pb]);
-      pa = W::uni(M.cstart[ea]); pb = W::uni(M.cstart[eb]);
+      pa = W::uni(M.par[pa]); pb = W::uni(M.par[pb]);
     }
     return ea > eb;
   }
@@ -969,6 +1019,7 @@ struct GtsComponent {
         if (take) {
           orient[v] = (uint8_t)(orient[v] | 4u);
           M.edgemap[v] = ce;
+          M.par[v] = u;
           M.plen[v] = (len_t)(plu + (len_t)M.cseq[v]);
           BQ[bt + W::popc_below(tm, lane)] = v;
         }
@@ -1089,6 +1140,7 @@ struct GtsComponent {
               if (old == GTS_DIST_UNSET || old > cand) {
                 M.distmap[v] = cand;
                 M.edgemap[v] = ce;
+                M.par[v] = u;
                 M.nd[v] = u == start ? w : (nd_t)cand;
                 M.plen[v] = (len_t)(plu + (len_t)M.cseq[v]);
                 depth[v] = dpu + 1;
@@ -1111,9 +1163,10 @@ struct GtsComponent {
             const uint32_t l = W::ctz(tm);
             tm &= tm - 1;
             const uint32_t tv = W::bcast(v, l), tce = W::bcast(ce, l);
-            const uint32_t up = W::uni(M.cstart[W::uni(M.edgemap[tv])]);
+            const uint32_t up = W::uni(M.par[tv]);
             if (pushed_after(up, u, start)) {       /* u's value came first */
               M.edgemap[tv] = tce;
+              M.par[tv] = u;
               M.plen[tv] = (len_t)(plu + (len_t)uni_t(M.cseq[tv]));
               depth[tv] = dpu + 1;
               W::fence();
@@ -1146,7 +1199,7 @@ struct GtsComponent {
       while (cv != start) {
         const uint32_t re = W::uni(M.edgemap[cv]);
         M.cc_best[n++] = re;
-        cv = W::uni(M.cstart[re]);
+        cv = W::uni(M.par[cv]);
       }
       cc_len = best_len;
       cc_n = n;
@@ -1394,6 +1447,7 @@ struct GtsComponent {
                 fresh = old == GTS_DIST_UNSET;
                 M.distmap[v] = cand;
                 M.edgemap[v] = ce;
+                M.par[v] = u;
                 M.nd[v] = u == start ? w : (nd_t)cand;
                 M.plen[v] = (len_t)(plu + (len_t)M.cseq[v]);
                 depth[v] = dpu + 1;
@@ -1414,9 +1468,10 @@ struct GtsComponent {
             const uint32_t tl = W::ctz(tm);
             tm &= tm - 1;
             const uint32_t tv = W::bcast(v, tl), tce = W::bcast(ce, tl);
-            const uint32_t up = W::uni(M.cstart[W::uni(M.edgemap[tv])]);
+            const uint32_t up = W::uni(M.par[tv]);
             if (pushed_after(up, u, start)) {
               M.edgemap[tv] = tce;
+              M.par[tv] = u;
               M.plen[tv] = (len_t)(plu + (len_t)uni_t(M.cseq[tv]));
               depth[tv] = dpu + 1;
               W::fence();
@@ -1439,7 +1494,7 @@ struct GtsComponent {
       while (cv != start) {
         const uint32_t re = W::uni(M.edgemap[cv]);
         M.cc_best[n++] = re;
-        cv = W::uni(M.cstart[re]);
+        cv = W::uni(M.par[cv]);
       }
       cc_len = best_len;
       cc_n = n;

@@ -884,6 +884,7 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   M.visited = lds_carve<idx_t>(p, nv); M.st_v = lds_carve<idx_t>(p, nv);
   M.st_par = lds_carve<idx_t>(p, nv);
   M.edgemap = lds_carve<idx_t>(p, nv); M.wterm = lds_carve<idx_t>(p, nv);
+  M.par = lds_carve<idx_t>(p, nv);
   M.cc_best = lds_carve<idx_t>(p, nv);
   M.topo = lds_carve<idx_t>(p, nv); M.tpos = lds_carve<idx_t>(p, nv);
   M.distmap = lds_carve<float>(p, nv);
@@ -894,11 +895,10 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   M.lastpop = (uint32_t __attribute__((address_space(3))) *)M.nd;
   M.vst = lds_carve<uint8_t>(p, nv); M.st_dir = lds_carve<uint8_t>(p, nv);
   M.tight = lds_carve<uint8_t>(p, nv); M.gorient = lds_carve<uint8_t>(p, nv);
-  auto cstart = lds_carve<idx_t>(p, ne);
   auto cend = lds_carve<idx_t>(p, ne);
   auto cdist = lds_carve<int32_t>(p, ne);
-  M.cflags = lds_carve<uint8_t>(p, ne);
-  M.cstate = lds_carve<uint8_t>(p, ne);
+  auto cfs = lds_carve<uint8_t>(p, ne);   /* flags | state << 4 */
+  M.cflags.b = cfs; M.cstate.b = cfs;
   for (uint32_t i = lane; i <= nv; i += GTS_WAVE) coff[i] = (idx_t)(G0.coff[i] - G0.e0);
   for (uint32_t i = lane; i < nv; i += GTS_WAVE) {
     cseq[i] = (int32_t)G0.cseq[i]; M.vst[i] = G0.vst[i];
@@ -908,10 +908,11 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
     }
   }
   for (uint32_t i = lane; i < ne; i += GTS_WAVE) {
-    cstart[i] = (idx_t)G0.cstart[i]; cend[i] = (idx_t)G0.cend[i]; cdist[i] = (int32_t)G0.cdist[i];
-    M.cflags[i] = G0.cflags[i]; M.cstate[i] = G0.cstate[i];
+    cend[i] = (idx_t)G0.cend[i]; cdist[i] = (int32_t)G0.cdist[i];
+    cfs[i] = (uint8_t)((G0.cflags[i] & 15u) | (G0.cstate[i] << 4));
   }
-  M.coff = coff; M.cseq = cseq; M.cstart = cstart; M.cend = cend; M.cdist = cdist;
+  M.coff = coff; M.cseq = cseq; M.cend = cend; M.cdist = cdist;
+  M.cstart.coff = coff; M.cstart.nv = nv;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
@@ -1647,7 +1648,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(s_queue, uint32_t, nslots); PALLOC(s_term, uint32_t, nslots);
     PALLOC(s_visited, uint32_t, nslots); PALLOC(s_stv, uint32_t, nslots);
     PALLOC(s_stpar, uint32_t, nslots); PALLOC(s_stcur, uint32_t, nslots);
-    PALLOC(s_edgemap, uint32_t, nslots); PALLOC(s_lastpop, uint32_t, nslots);
+    PALLOC(s_edgemap, uint32_t, nslots); PALLOC(s_lastpop, uint32_t, nslots); PALLOC(s_par, uint32_t, nslots);
     PALLOC(s_wterm, uint32_t, nslots); PALLOC(s_touched, uint32_t, nslots);
     PALLOC(s_ccbest, uint32_t, nslots); PALLOC(s_stdir, uint8_t, nslots);
     PALLOC(s_distmap, float, nslots); PALLOC(s_ccoff, uint32_t, (size_t)nslots + ncomp + 1);
@@ -1704,7 +1705,7 @@ static int run_components(GtsgEngine *e, int mode)
     C.cseq = cseq; C.coff = coff; C.cstart = cstart; C.cend = cend; C.cdist = cdist;
     C.cflags = cflags; C.cgpos = cgpos; C.cstate = cstate; C.vst = vst;
     C.queue = s_queue; C.term = s_term; C.visited = s_visited; C.st_v = s_stv;
-    C.st_par = s_stpar; C.st_cur = s_stcur; C.edgemap = s_edgemap; C.lastpop = s_lastpop;
+    C.st_par = s_stpar; C.st_cur = s_stcur; C.edgemap = s_edgemap; C.par = s_par; C.lastpop = s_lastpop;
     C.wterm = s_wterm; C.touched = s_touched; C.cc_best = s_ccbest; C.st_dir = s_stdir;
     C.distmap = s_distmap; C.ccoff = s_ccoff; C.wq_edge = wq_edge; C.wq_used = wq_used;
     C.wq_pool = wq_pool; C.wq_factor = (uint64_t)factor;

@@ -219,7 +219,7 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   C.cflags = cflags.data(); C.cgpos = cgpos.data(); C.cstate = cstate.data();
   C.vst = vst.data(); C.queue = queue.data(); C.term = term.data();
   C.visited = visited.data(); C.st_v = st_v.data(); C.st_par = st_par.data();
-  C.st_cur = st_cur.data(); C.edgemap = edgemap.data(); C.lastpop = lastpop.data();
+  C.st_cur = st_cur.data(); C.edgemap = edgemap.data(); std::vector<uint32_t> par_v(S); C.par = par_v.data(); C.lastpop = lastpop.data();
   C.wterm = wterm.data(); C.touched = touchedl.data(); C.cc_best = cc_best.data();
   C.st_dir = st_dir.data(); C.distmap = distmap.data(); C.ccoff = ccoff.data();
   C.wq_edge = wq_edge.data(); C.wq_dist = wq_dist.data(); C.wq_used = &wq_used;
