@@ -1743,7 +1743,8 @@ struct GtsComponent {
       if (te - tb < 2) continue;
       bool stale = false;
       if (revived_any)
-        for (uint32_t j = tb; j < te && !stale; ++j) stale = task_touches(C, t0 + j, nv, wb);
+        for (uint32_t j = tb; j < te && !stale; ++j)   /* (a walk left to the reference search is made below) */
+          stale = W::uni(C.task_n[t0 + j]) != GTS_NONE && task_touches(C, t0 + j, nv, wb);
       if (stale) break;
       /* walks the tasks left to the reference search: here, in terminal
          order, on the global arrays, with one ring per component */
