@@ -430,13 +430,20 @@ struct GtsEdgeAccLds {
 
 /* what the pair passes gather per edge from the end vertex, in one 16-byte
    record (two separate arrays cost two sectors per edge) */
-struct __attribute__((aligned(16))) GtsVAttr { int64_t len; float cn; uint32_t pad; };
+struct __attribute__((aligned(16))) GtsVAttr { int64_t len; float cn; uint32_t tpoly; };
 __global__ void k_pack_vattr(const int64_t *seq_len, const float *copy_num, GtsVAttr *va, uint32_t n)
 {
   uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
-  GtsVAttr a; a.len = seq_len[v]; a.cn = copy_num[v]; a.pad = 0;
+  GtsVAttr a; a.len = seq_len[v]; a.cn = copy_num[v]; a.tpoly = GTS_NONE;
   va[v] = a;
+}
+/* the time stamps of the polymorphic pass join the record: k_filter_ovf_init
+   needs both per edge */
+__global__ void k_vattr_tpoly(const uint32_t *tpoly, GtsVAttr *va, uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) va[v].tpoly = tpoly[v];
 }
 
 __global__ void __launch_bounds__(GTS_BLOCK)
@@ -551,8 +558,9 @@ k_filter_ovf_init(GtsGraphView G, GtsFilterParams P, const GtsVAttr *va, const u
     uint32_t ns = e1 - e0 < GTS_FP_CAP ? e1 - e0 : GTS_FP_CAP;
     for (uint32_t i = threadIdx.x; i < ns; i += GTS_BLOCK) {
       const uint32_t p = e0 + i, x = G.end[p];
-      const bool mk = gts_edge_is_marked(G.state[p]) || tpoly[x] <= estart[p];
-      const int64_t d = G.dist[p], l = va[x].len;
+      const GtsVAttr a = va[x];
+      const bool mk = gts_edge_is_marked(G.state[p]) || a.tpoly <= estart[p];
+      const int64_t d = G.dist[p], l = a.len;
       if (d != (int32_t)d || l != (int32_t)l) s_wide = 1;
       s_d[i] = (int32_t)d; s_l[i] = (int32_t)l;
       s_f[i] = (uint8_t)((G.flags[p] & 3u) | (mk ? 0x80u : 0u));
@@ -1425,6 +1433,7 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   }
   HIPCHK(hipMemsetAsync(tpoly, 0xFF, (size_t)n * 4, e->st));
   if (m) LAUNCH("filter_tpoly", k_filter_tpoly, nblk(m), GTS_BLOCK, G, e->estart, prop, vinfo, tpoly);
+  LAUNCH("filter_pack_vattr", k_vattr_tpoly, nblk(n), GTS_BLOCK, tpoly, vattr, n);
   LAUNCH("filter_ovf_init", k_filter_ovf_init, nblk(n), GTS_BLOCK, G, P, vattr, e->estart, vinfo, tpoly,
          ovf, zero_ovf, (uint32_t)e->hub_degree);
   if (e->nhub && !zero_ovf)
