@@ -510,16 +510,18 @@ __global__ void k_filter_active_round(GtsGraphView G, const uint8_t *prop,
   if (r) vinfo[v] = (uint8_t)(cur | r);
   else *pending = 1;
 }
-/* first active proposer of every vertex, one lane per edge: edge p = (v -> u)
-   counts if its twin (u -> v) carries a proposal and u is active; few do */
+/* first active proposer of every vertex, one lane per edge: an edge
+   q = (u -> v) that carries a proposal counts for v if u is active.  Few edges
+   do, and the test reads the lane's own byte: nothing is gathered for the
+   rest. */
 __global__ void k_filter_tpoly(GtsGraphView G, const uint32_t *estart,
                                const uint8_t *prop, const uint8_t *vinfo,
                                uint32_t *tpoly)
 {
-  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= G.m) return;
-  if (!prop[G.twin[p]]) return;
-  const uint32_t u = G.end[p], v = estart[p];
+  uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= G.m) return;
+  if (!prop[q]) return;
+  const uint32_t u = estart[q], v = G.end[q];
   if (!(vinfo[u] & GTS_VI_ACTIVE0) || gts_vertex_is_marked(G.vstate[v])) return;
   atomicMin(&tpoly[v], u);
 }
@@ -610,19 +612,21 @@ __global__ void k_filter_hit_round(GtsGraphView G, uint8_t *ovf, int zero_ovf,
   if (r) ovf[v] = (uint8_t)r;
   else *pending = 1;
 }
-/* latest neighbour whose overflow marks direction d of the start vertex, one
-   lane per edge q = (a -> y); lasthit[] is pre-set to GTS_NONE = -1 as int32 */
+/* latest neighbour whose overflow marks direction d of a vertex a, one lane
+   per edge t = (y -> a) seen from the overflowing side: the test reads the
+   lane's own start vertex and flags, only a hit touches a (lasthit[] is
+   pre-set to GTS_NONE = -1 as int32) */
 __global__ void k_filter_lasthit(GtsGraphView G, const uint32_t *estart,
                                  const uint8_t *ovf, uint32_t *lasthit)
 {
-  uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= G.m) return;
-  const uint32_t y = G.end[q];
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= G.m) return;
+  const uint32_t y = estart[t];
   const uint32_t oy = ovf[y];
   if (!(oy & GTS_OV_ACTIVE1) || !(oy & (GTS_OV_A | GTS_OV_S))) return;
-  const uint8_t ff = G.flags[G.twin[q]];      /* the edge y -> a */
+  const uint8_t ff = G.flags[t];
   if (!(oy & ((ff & GTS_F_SENSE) ? GTS_OV_S : GTS_OV_A))) return;
-  atomicMax((int *)&lasthit[2 * (uint64_t)estart[q] + (gts_twin_dir(ff) ? 1 : 0)], (int)y);
+  atomicMax((int *)&lasthit[2 * (uint64_t)G.end[t] + (gts_twin_dir(ff) ? 1 : 0)], (int)y);
 }
 __global__ void k_filter_final(GtsGraphView G, const uint32_t *estart,
                                const uint32_t *tpoly, const uint8_t *ovf,
