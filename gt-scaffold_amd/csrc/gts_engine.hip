@@ -398,12 +398,15 @@ __global__ void k_repeat_vertices(const float *astat, const float *cn,
 }
 /* an edge turns REPEAT iff one of its ends is marked by THIS call
    (mark_vertex marks the vertex' edges and their twins, algorithms.c:61-87) */
-__global__ void k_repeat_edges(const uint32_t *estart, const uint32_t *eend,
+__global__ void k_repeat_edges(const uint32_t *estart, const uint32_t *twin,
                                const uint8_t *isrep, uint8_t *state, uint32_t m)
 {
+  /* from the repeat's side: its own edges and their twins; an edge of another
+     contig reads its start vertex' flag and nothing else */
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= m) return;
-  if (isrep[estart[p]] || isrep[eend[p]]) state[p] = GIS_REPEAT;
+  if (p >= m || !isrep[estart[p]]) return;
+  state[p] = GIS_REPEAT;
+  state[twin[p]] = GIS_REPEAT;
 }
 
 /* ---- filter ---- */
@@ -628,13 +631,26 @@ __global__ void k_filter_lasthit(GtsGraphView G, const uint32_t *estart,
   if (!(oy & ((ff & GTS_F_SENSE) ? GTS_OV_S : GTS_OV_A))) return;
   atomicMax((int *)&lasthit[2 * (uint64_t)G.end[t] + (gts_twin_dir(ff) ? 1 : 0)], (int)y);
 }
+/* final edge states in two passes: every edge from what its own start vertex
+   holds (coalesced), then the edges that END in a polymorphic vertex once more
+   with that vertex' time stamp -- found from the polymorphic side, through
+   the twin, so that the common edge gathers nothing */
 __global__ void k_filter_final(GtsGraphView G, const uint32_t *estart,
                                const uint32_t *tpoly, const uint8_t *ovf,
                                const uint32_t *lasthit, uint8_t *newstate)
 {
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.m) return;
-  newstate[p] = gts_filter_final_edge(G, estart[p], (uint32_t)p, tpoly, ovf, lasthit);
+  newstate[p] = gts_filter_final_edge(G, estart[p], (uint32_t)p, tpoly, ovf, lasthit, false);
+}
+__global__ void k_filter_final_poly_ends(GtsGraphView G, const uint32_t *estart,
+                                         const uint32_t *tpoly, const uint8_t *ovf,
+                                         const uint32_t *lasthit, uint8_t *newstate)
+{
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= G.m || tpoly[estart[t]] == GTS_NONE) return;
+  const uint32_t p = G.twin[t];   /* ends in the polymorphic vertex estart[t] */
+  newstate[p] = gts_filter_final_edge(G, G.end[t], p, tpoly, ovf, lasthit, true);
 }
 __global__ void k_filter_final_vertices(uint8_t *vstate, const uint32_t *tpoly,
                                         uint32_t n)
@@ -662,9 +678,10 @@ __global__ void k_live_union(GtsGraphView G, const uint32_t *estart,
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.m) return;
   const uint32_t a = estart[p], b = G.end[p];
-  const bool lv = !gts_edge_is_marked(G.state[p]) &&
-                  !gts_vertex_is_marked(G.vstate[a]) &&
-                  !gts_vertex_is_marked(G.vstate[b]);
+  /* an unmarked edge has unmarked ends: whatever marks a vertex marks its
+     edges and their twins (mark_vertex, algorithms.c:76-87), and no edge ever
+     goes back from a marked state */
+  const bool lv = !gts_edge_is_marked(G.state[p]);
   /* bit 7: live; low bits: the edge's flags, so that k_compact_fill gets both
      about the twin from one gather */
   live[p] = (uint8_t)((G.flags[p] & 3u) | (lv ? 0x80u : 0u));
@@ -1393,7 +1410,7 @@ int gtsg_mark_repeats(GtsgEngine *e, int have_file, float copy_num_cutoff,
     LAUNCH("repeat_vertices", k_repeat_vertices, nblk(e->n), GTS_BLOCK, e->astat,
            e->copy_num, e->vstate, isrep, e->n, have_file, copy_num_cutoff, astat_cutoff);
   if (e->m)
-    LAUNCH("repeat_edges", k_repeat_edges, nblk(e->m), GTS_BLOCK, e->estart, e->eend, isrep,
+    LAUNCH("repeat_edges", k_repeat_edges, nblk(e->m), GTS_BLOCK, e->estart, e->twin, isrep,
            e->state, e->m);
   return sync_stream(e);
 }
@@ -1491,6 +1508,8 @@ int gtsg_filter_end(GtsgEngine *e)
   e->filter_open = false;
   if (m) {
     LAUNCH("filter_final", k_filter_final, nblk(m), GTS_BLOCK, G, e->estart, e->f_tpoly,
+           e->f_ovf, e->f_lasthit, e->f_newstate);
+    LAUNCH("filter_final", k_filter_final_poly_ends, nblk(m), GTS_BLOCK, G, e->estart, e->f_tpoly,
            e->f_ovf, e->f_lasthit, e->f_newstate);
     HIPCHK(hipMemcpyAsync(e->state, e->f_newstate, m, hipMemcpyDeviceToDevice, e->st));
   }

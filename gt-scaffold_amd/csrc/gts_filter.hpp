@@ -283,14 +283,17 @@ GTS_HD void gts_filter_lasthit(const GtsGraphView &G, uint32_t a,
 }
 
 /* (F) final state of edge position p of vertex a */
+/* with_end = false leaves out what the END vertex contributes (its time stamp
+   of the polymorphic pass): the engine adds it in a second pass over the few
+   edges that end in a polymorphic vertex */
 GTS_HD uint8_t gts_filter_final_edge(const GtsGraphView &G, uint32_t a,
                                      uint32_t p, const uint32_t *tpoly,
-                                     const uint8_t *ovf, const uint32_t *lasthit)
+                                     const uint8_t *ovf, const uint32_t *lasthit,
+                                     bool with_end = true)
 {
-  const uint32_t bnd = G.end[p];
   const bool s = G.flags[p] & GTS_F_SENSE;
   int64_t tp = -1, ti = -1;
-  const uint32_t ta = tpoly[a], tb = tpoly[bnd];
+  const uint32_t ta = tpoly[a], tb = with_end ? tpoly[G.end[p]] : GTS_NONE;
   if (ta != GTS_NONE) tp = 2 * (int64_t)ta;
   if (tb != GTS_NONE && 2 * (int64_t)tb > tp) tp = 2 * (int64_t)tb;
   const uint32_t oa = ovf[a];

@@ -109,3 +109,24 @@ def test_lazy_and_faithful_distance_maps_agree():
             og.mark_repeats(); og.filter(); og.makescaffold(lazy)
             res.append((og.vertex_states(), og.edge_states()))
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_an_unmarked_edge_has_unmarked_ends():
+    """mark_vertex marks a vertex' edges and their twins (algorithms.c:76-87) and
+    no edge goes back from a marked state: the engine's live-edge test relies on
+    it (k_live_union reads the edge state only)"""
+    import numpy as np
+    from helpers import make_inputs, oracle_from_inputs
+    marked_v = np.zeros(8, bool); marked_v[[1, 3, 7]] = True
+    marked_e = np.zeros(8, bool); marked_e[[1, 2, 3, 7]] = True
+    for seed in range(4):
+        g = make_inputs(3000, 300 + seed, p_chimeric=0.05, p_bubble=0.05, p_relist=0.03,
+                        p_inversion=0.5 * (seed % 2))
+        og = oracle_from_inputs(g)
+        stages = [og.mark_repeats, og.filter, og.removecycles, lambda: og.makescaffold(True)]
+        for stage in stages:
+            stage()
+            e = og.edges()
+            vs, es = og.vertex_states(), og.edge_states()
+            bad = ~marked_e[es] & (marked_v[vs[e["start"]]] | marked_v[vs[e["end"]]])
+            assert not bad.any()
