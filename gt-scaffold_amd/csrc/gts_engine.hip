@@ -502,14 +502,25 @@ k_filter_pairs_hub(GtsGraphView G, GtsFilterParams P, uint8_t *prop,
   if (gts_lane() == 0)
     vinfo[v] = (uint8_t)((s ? GTS_VI_OVALL_S : 0u) | (a ? GTS_VI_OVALL_A : 0u));
 }
-__global__ void k_filter_active_round(GtsGraphView G, const uint8_t *prop,
+/* vertices that a smaller vertex proposes, found from the proposing edges
+   (few): the others are active at once, without looking at their lists */
+__global__ void k_filter_proposed(GtsGraphView G, const uint32_t *estart, const uint8_t *prop,
+                                  uint8_t *proposed)
+{
+  uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= G.m || !prop[q]) return;
+  const uint32_t u = estart[q], v = G.end[q];
+  if (u < v) proposed[v] = 1;
+}
+__global__ void k_filter_active_round(GtsGraphView G, const uint8_t *prop, const uint8_t *proposed,
                                       uint8_t *vinfo, uint32_t *pending)
 {
   uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= G.n) return;
   const uint8_t cur = vinfo[v];
   if (cur & (GTS_VI_ACTIVE0 | GTS_VI_INACTIVE)) return;
-  const uint32_t r = gts_filter_active_round(G, (uint32_t)v, prop, vinfo);
+  const uint32_t r = proposed[v] ? gts_filter_active_round(G, (uint32_t)v, prop, vinfo)
+                                 : (uint32_t)GTS_VI_ACTIVE0;
   if (r) vinfo[v] = (uint8_t)(cur | r);
   else *pending = 1;
 }
@@ -1423,7 +1434,7 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   e->filter_open = false;
   if (!n) return 0;
   int rc;
-  if ((rc = pool_reserve(e, (size_t)m * 2 + (size_t)n * 40 + (8u << 20)))) return rc;
+  if ((rc = pool_reserve(e, (size_t)m * 2 + (size_t)n * 42 + (8u << 20)))) return rc;
   GtsGraphView G = view_of(e);
   GtsFilterParams P;
   P.amb = gts_amb_thresholds(pcutoff);
@@ -1443,10 +1454,13 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
     LAUNCH("filter_pairs_hub", k_filter_pairs_hub, nblk((uint64_t)e->nhub * GTS_WAVE),
            GTS_BLOCK, G, P, prop, vinfo, e->hubs, e->nhub);
   int64_t rounds_p = 0, rounds_i = 0;
+  PALLOC(proposed, uint8_t, (size_t)n + 1);
+  HIPCHK(hipMemsetAsync(proposed, 0, (size_t)n + 1, e->st));
+  if (m) LAUNCH("filter_active_round", k_filter_proposed, nblk(m), GTS_BLOCK, G, e->estart, prop, proposed);
   for (;;) {
     uint32_t h = 0;
     HIPCHK(hipMemsetAsync(pending, 0, 4, e->st));
-    LAUNCH("filter_active_round", k_filter_active_round, nblk(n), GTS_BLOCK, G, prop, vinfo,
+    LAUNCH("filter_active_round", k_filter_active_round, nblk(n), GTS_BLOCK, G, prop, proposed, vinfo,
            pending);
     ++rounds_p;
     if ((rc = read_u32(e, pending, &h))) return rc;
