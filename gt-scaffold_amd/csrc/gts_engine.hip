@@ -774,7 +774,9 @@ __global__ void k_compact_flags(const uint8_t *live, const uint32_t *twin,
                                 uint32_t *incl, uint32_t m)
 {
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < m) incl[p] = ((live[p] | live[twin[p]]) & 0x80u) ? 1u : 0u;
+  if (p >= m) return;
+  /* the twin is looked up only for an edge that is not live itself */
+  incl[p] = (live[p] & 0x80u) ? 1u : (live[twin[p]] & 0x80u) ? 1u : 0u;
 }
 __global__ void k_compact_count(const uint32_t *row, const uint32_t *ipos,
                                 const uint32_t *slot_v, uint32_t *cnt,
