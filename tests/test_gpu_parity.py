@@ -367,3 +367,54 @@ def test_ragged_inputs():
         g[name] = rec[name]
     g["astat"][hub] = 100.0; g["copy_num"][hub] = 1.0           # the hub is not a repeat
     run_pipeline(g, hub_degree=16)
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] (10 M contigs / 100 M edges, the workload bench.py
+    times) through properties that need no oracle: structural invariants of the
+    built graph, the same digest whatever the parallel decomposition (deferred
+    walks or not, one or six streams), and the oracle's digest on a sample drawn by the same generator."""
+    import torch
+    import bench
+    n = 10_000_000
+    g = bench.make_inputs(pkg, n, 1234, "cuda:0", bench.WORKLOAD["gen"])
+    g["num_pairs"] = g["num_pairs"].to(torch.int64)
+    digests = []
+    for opts in (dict(), dict(defer_min_contigs=0, class_streams=1), dict(defer_min_contigs=96, mixed_task_limit=0)):
+        eng = pkg.engine.Engine(0, torch.cuda.current_stream().cuda_stream)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        bench.run_step(eng, g)
+        digests.append(eng.digest())
+        if not opts:
+            assert eng.ne > 90_000_000 and eng.stat("components") > 100_000
+            e = eng.edges()
+            m = eng.ne
+            # edge 2j and 2j+1 are created together as twins (parser.c:369-377)
+            assert np.array_equal(e["start"][0:m:2], e["end"][1:m:2])
+            assert np.array_equal(e["end"][0:m:2], e["start"][1:m:2])
+            assert np.array_equal(e["flags"][0:m:2] & 2, e["flags"][1:m:2] & 2)   # same
+            assert int(e["start"].max()) < n and int(e["end"].max()) < n
+            # every contig pair owns one edge pair
+            lo = np.minimum(e["start"][0:m:2], e["end"][0:m:2]).astype(np.uint64)
+            hi = np.maximum(e["start"][0:m:2], e["end"][0:m:2]).astype(np.uint64)
+            key = lo * np.uint64(n) + hi
+            assert np.unique(key).size == key.size
+            del e, lo, hi, key
+            # states: an unmarked edge has unmarked ends; SCAFFOLD edges join SCAFFOLD contigs
+            vs, es = eng.vertex_states(), eng.edge_states()
+            ee = eng.edges()
+            marked_v = np.zeros(8, bool); marked_v[[1, 3, 7]] = True
+            marked_e = np.zeros(8, bool); marked_e[[1, 2, 3, 7]] = True
+            assert not (~marked_e[es] & (marked_v[vs[ee["start"]]] | marked_v[vs[ee["end"]]])).any()
+            sc = es == 6
+            assert sc.any() and (vs[ee["start"][sc]] == 6).all() and (vs[ee["end"][sc]] == 6).all()
+            assert np.array_equal(es[0:m:2] == 6, es[1:m:2] == 6)   # twins are marked together
+            del vs, es, ee
+        del eng
+    assert digests[0] == digests[1] == digests[2]
+    # the oracle on a sample of the same generator
+    gs = make_inputs(100000, 99, **bench.WORKLOAD["gen"])
+    eng, og = run_pipeline(gs, pcutoff=bench.CUTS["pcutoff"], cncutoff=bench.CUTS["cncutoff"],
+                           ocutoff=bench.CUTS["ocutoff"])
+    assert eng.digest() == pkg.engine.state_digest_host(og.vertex_states(), og.edge_states())
