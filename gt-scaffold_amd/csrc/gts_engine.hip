@@ -764,7 +764,19 @@ __global__ void k_slot_bases(const uint32_t *head, const uint32_t *cidx,
   slot_comp[s] = c;
   const int64_t l = cseq[s];
   if (l != (int32_t)l) comp_wide[c] = 1;
-  atomicAdd(&comp_len[c], (unsigned long long)l);   /* bases of the component (len_t of the LDS layout) */
+  /* bases of the component (len_t of the LDS layout).  Slots are sorted by
+     component: the lanes of a run add up first (segmented wave scan), the last
+     lane of the run does the atomic */
+  unsigned long long sum = (unsigned long long)l;
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long o = __shfl_up(sum, off);
+    const uint32_t oc = __shfl_up(c, off);
+    if (lane >= (uint32_t)off && oc == c) sum += o;
+  }
+  const uint32_t nc = __shfl_down(c, 1);
+  if (lane == 63u || nc != c || s + 1 == nslots) atomicAdd(&comp_len[c], sum);
 }
 /* an edge enters the compact graph if it or its twin is live: marking a walk
    edge's twin SCAFFOLD (algorithms.c:842-845) revives a marked twin.  One lane
