@@ -319,7 +319,7 @@ __global__ void k_emit_edges(const uint32_t *is_creator, const uint32_t *jidx,
                              const uint32_t *root, const uint32_t *ctg,
                              const int64_t *dist, const float *sd,
                              const int64_t *npairs, const uint8_t *flags,
-                             uint32_t *estart, GtsEdgeRec *rec, uint64_t nrec)
+                             uint32_t *estart, uint32_t *ids, GtsEdgeRec *rec, uint64_t nrec)
 {
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nrec || !is_creator[k]) return;
@@ -340,6 +340,7 @@ __global__ void k_emit_edges(const uint32_t *is_creator, const uint32_t *jidx,
   } else
     b.flags = flags[bw] & 3u;
   estart[e0] = r; estart[e0 + 1] = c;
+  ids[e0] = (uint32_t)e0; ids[e0 + 1] = (uint32_t)e0 + 1u;   /* values of the CSR sort */
   rec[e0] = a; rec[e0 + 1] = b;
 }
 
@@ -1079,25 +1080,44 @@ __global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
   if (cerr[c] == GTS_CERR_WALKQ_OVERFLOW) atomicAdd(&out[0], 1u);
   else if (cerr[c] != 0) atomicAdd(&out[1], 1u);
 }
+/* statistics: the lanes of a wave add up (or take the maximum) first, one
+   atomic per wave */
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max(unsigned long long v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
 /* out[k] = sum, out[4+k] = max of column k of the per-component tick table */
 __global__ void k_tstat_reduce(const uint64_t *t, uint32_t ncomp, unsigned long long *out)
 {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncomp) return;
   for (int k = 0; k < 4; ++k) {
-    const unsigned long long v = t[5 * c + k];
-    if (v) { atomicAdd(&out[k], v); atomicMax(&out[4 + k], v); }
+    const unsigned long long v = c < ncomp ? t[5 * c + k] : 0ull;
+    const unsigned long long sm = wave_sum(v), mx = wave_max(v);
+    if ((threadIdx.x & 63u) == 0 && sm) { atomicAdd(&out[k], sm); atomicMax(&out[4 + k], mx); }
   }
 }
 __global__ void k_sum_u32(const uint32_t *a, uint32_t n, unsigned long long *out)
 {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < n && a[c]) atomicAdd(out, (unsigned long long)a[c]);
+  const unsigned long long sm = wave_sum(c < n ? (unsigned long long)a[c] : 0ull);
+  if ((threadIdx.x & 63u) == 0 && sm) atomicAdd(out, sm);
 }
 __global__ void k_sum_bit(const uint32_t *a, uint32_t n, uint32_t bit, unsigned long long *out)
 {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < n && (a[c] >> bit & 1u)) atomicAdd(out, 1ull);
+  const unsigned long long sm = wave_sum(c < n ? (unsigned long long)(a[c] >> bit & 1u) : 0ull);
+  if ((threadIdx.x & 63u) == 0 && sm) atomicAdd(out, sm);
 }
 __global__ void k_max_u32_diff(const uint32_t *off, uint32_t n, uint32_t *out)
 {
@@ -1386,8 +1406,7 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
     PALLOC(rec, GtsEdgeRec, m);
     PALLOC(stmp2, uint32_t, gts_sort_tmp_elems(m));
     LAUNCH("build_emit_edges", k_emit_edges, nblk(nrec), GTS_BLOCK, is_creator, jidx, fwd,
-           bwd, d_root, d_ctg, d_dist, d_sd, d_np, d_flags, es0, rec, nrec);
-    LAUNCH("iota", k_iota, nblk(m), GTS_BLOCK, id0, (uint64_t)m);
+           bwd, d_root, d_ctg, d_dist, d_sd, d_np, d_flags, es0, id0, rec, nrec);
     const int vb = bits_for(n);
     int shifts[4], np = 0;
     for (int s = 0; s < vb; s += 8) shifts[np++] = s;
@@ -1903,8 +1922,9 @@ static int run_components(GtsgEngine *e, int mode)
     LAUNCH("comp_walk_stats", k_sum_bit, nblk(ncomp), GTS_BLOCK, stat_clean, ncomp, 1u,
            (unsigned long long *)(e->d_scalars + 22));
     HIPCHK(hipMemsetAsync(e->d_scalars + 32, 0, 64, e->st));
-    LAUNCH("comp_walk_stats", k_tstat_reduce, nblk(ncomp), GTS_BLOCK, tstat, ncomp,
-           (unsigned long long *)(e->d_scalars + 32));
+    if (e->profile >= 2)   /* the per-component clocks are reduced for the detailed profile only */
+      LAUNCH("comp_walk_stats", k_tstat_reduce, nblk(ncomp), GTS_BLOCK, tstat, ncomp,
+             (unsigned long long *)(e->d_scalars + 32));
     uint64_t ts[8];
     HIPCHK(hipMemcpyAsync(ts, e->d_scalars + 32, 64, hipMemcpyDeviceToHost, e->st));
     uint64_t why[8];

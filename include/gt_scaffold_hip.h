@@ -127,7 +127,8 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      re-run from a snapshot if a ring or the pool overflows),
      "max_walk_pops" (default 2^32),
      "hub_degree" (default 32), "profile" (0, 1 = hipEvents around every kernel,
-     2 = also the three slowest components as "top<r>_*" statistics),
+     2 = also the per-component clocks: "us_sum_*" / "us_max_*", the slowest
+     components as "top<r>_*" and the size bands as "size_band<b>_*" statistics),
      "fast_walks" (default 1; 0 forces the reference's label-correcting search
      for every walk), "lds_components" (default 1; 0 runs every component
      from global memory), "defer_min_contigs" (default 256; components with at
