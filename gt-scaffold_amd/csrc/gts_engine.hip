@@ -1821,8 +1821,9 @@ static int run_components(GtsgEngine *e, int mode)
       /* the size classes are independent: fork them onto side streams so the
          launches overlap (each has its own tail and, being bound by its LDS
          footprint, leaves room for workgroups of the other classes); join
-         before the statistics.  The runtime serves a process with four
-         hardware queues: about four launches are in flight at a time. */
+         before the statistics.  The runtime multiplexes a process' streams
+         onto GPU_MAX_HW_QUEUES hardware queues (default 4, the main stream
+         included): that many launches are in flight at a time. */
       for (int k = (int)nk - 1; k >= 0; --k) {
         if (!kcount[k]) continue;
         static std::string kn[2][GTS_NKLASS];   /* event names live as long as the library */
