@@ -937,6 +937,7 @@ struct GtsComponent {
     uint64_t pops = 0;
     const uint64_t max_pops = 64ull * nr + 64;
     dirty[start] = 1;
+    M.nd[start] = 0;
     W::fence();
     while (changed && !bad) {
       changed = false;
@@ -955,7 +956,7 @@ struct GtsComponent {
           if (++pops > max_pops) { bad = true; break; }
           dirty[u] = 0;
           const bool du = (W::uni((uint32_t)orient[u]) & 3u) == 2;
-          const nd_t ndu = u == start ? (nd_t)0 : uni_t(M.nd[u]);
+          const nd_t ndu = uni_t(M.nd[u]);   /* nd[start] = 0 */
           const uint32_t eb = eoff(u), ee = eoff(u + 1);
           for (uint32_t eb2 = eb; eb2 < ee; eb2 += W::WIDTH) {
             const uint32_t ce = eb2 + lane;
@@ -963,7 +964,7 @@ struct GtsComponent {
                 ((M.cflags[ce] & GTS_F_SENSE) != 0) == du) {
               const uint32_t v = M.cend[ce];
               const nd_t w = (nd_t)M.cdist[ce];
-              const float cand = u == start ? (float)w : (float)(ndu + w);
+              const float cand = (float)(ndu + w);
               const float old = M.distmap[v];
               if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
               if (old == GTS_DIST_UNSET || old > cand) {
@@ -995,7 +996,7 @@ struct GtsComponent {
       const uint32_t u = W::uni(BQ[bh]);
       ++bh;
       const bool du = (W::uni((uint32_t)orient[u]) & 3u) == 2;
-      const nd_t ndu = u == start ? (nd_t)0 : uni_t(M.nd[u]);
+      const nd_t ndu = uni_t(M.nd[u]);   /* nd[start] = 0 */
       const len_t plu = uni_t(M.plen[u]);
       const uint32_t eb = eoff(u), ee = eoff(u + 1);
       bool us = false, ua = false;
@@ -1009,7 +1010,7 @@ struct GtsComponent {
           if (live && sense == du) {
             v = M.cend[ce];
             const nd_t w = (nd_t)M.cdist[ce];
-            const float cand = u == start ? (float)w : (float)(ndu + w);
+            const float cand = (float)(ndu + w);
             take = cand == M.distmap[v] && !(orient[v] & 4u);
           }
         }
@@ -1113,14 +1114,16 @@ struct GtsComponent {
     if (!bad) {
       TQ[0] = start;
       M.plen[start] = (len_t)M.cseq[start];
+      M.nd[start] = 0;      /* no conditional loads in the loop: they would be fetched one by one */
+      depth[start] = 0;
       W::fence();
       while (qh2 < nq && !bad) {
         const uint32_t u = W::uni(TQ[qh2]);
         ++qh2; ++processed;
         const bool du = W::uni((uint32_t)orient[u]) == 2;
-        const nd_t ndu = u == start ? (nd_t)0 : uni_t(M.nd[u]);
+        const nd_t ndu = uni_t(M.nd[u]);   /* nd[start] = 0 */
         const len_t plu = uni_t(M.plen[u]);
-        const uint32_t dpu = u == start ? 0 : W::uni(depth[u]);
+        const uint32_t dpu = W::uni(depth[u]);   /* depth[start] = 0 */
         const uint32_t eb = eoff(u), ee = eoff(u + 1);
         bool us = false, ua = false;
         for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
@@ -1134,7 +1137,7 @@ struct GtsComponent {
             if (arc) {
               v = M.cend[ce];
               const nd_t w = (nd_t)M.cdist[ce];
-              const float cand = u == start ? (float)w : (float)(ndu + w);
+              const float cand = (float)(ndu + w);
               const float old = M.distmap[v];
               if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
               if (old == GTS_DIST_UNSET || old > cand) {
@@ -1424,9 +1427,9 @@ struct GtsComponent {
         const uint32_t u = W::bcast(cv, l);
         --pending;
         const bool du = ((W::uni((uint32_t)M.gorient[u]) & 3u) == 2) == forward;
-        const nd_t ndu = u == start ? (nd_t)0 : uni_t(M.nd[u]);
+        const nd_t ndu = uni_t(M.nd[u]);   /* nd[start] = 0 */
         const len_t plu = uni_t(M.plen[u]);
-        const uint32_t dpu = u == start ? 0 : W::uni(depth[u]);
+        const uint32_t dpu = W::uni(depth[u]);   /* depth[start] = 0 */
         const uint32_t eb = eoff(u), ee = eoff(u + 1);
         bool us = false, ua = false;
         for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
@@ -1440,7 +1443,7 @@ struct GtsComponent {
             if (arc) {
               v = M.cend[ce];
               const nd_t w = (nd_t)M.cdist[ce];
-              const float cand = u == start ? (float)w : (float)(ndu + w);
+              const float cand = (float)(ndu + w);
               const float old = M.distmap[v];
               if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
               if (old == GTS_DIST_UNSET || old > cand) {
