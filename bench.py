@@ -305,7 +305,9 @@ def main():
                    warmup=args.warmup, ms_per_step=dt_max / args.steps * 1e3,
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int64/u8",
                    data="synthetic",
-                   config=dict(workload=WORKLOAD["name"], contigs_per_gpu=n, edges_per_gpu=m,
+                   config=dict(workload=WORKLOAD["name"] if n == WORKLOAD["n_contigs"] else
+                               "synthetic scaffold graph, %d contigs per GPU (same generator)" % n,
+                               contigs_per_gpu=n, edges_per_gpu=m,
                                records_per_gpu=nrec, components=eng.stat("components"),
                                max_component=eng.stat("max_component"),
                                parallelism="components sharded, %d GPU(s), mode %s" % (world, args.mode),
