@@ -328,11 +328,21 @@ struct GtsComponent {
   }
 
   /* ---- ref algorithms.c:379-436 (with isterminal, :346-373, fused) ---- */
-  GTS_HD void calc_cc()
+  GTS_HD void calc_cc() { bool unused; calc_cc_t<false>(unused); }
+
+  /* ORIENT: also assigns the strands as orient() does.  Only for a component
+     whose compact edges are all live: then the terminal search and orient()
+     are the same traversal (one cc, every edge followed), and one pass does
+     for both.  oriented = false on a contradiction. */
+  template <bool ORIENT>
+  GTS_HD void calc_cc_t(bool &oriented)
   {
     const uint32_t lane = W::lane();
-    for (uint32_t s = lane; s < nv; s += W::WIDTH)
+    oriented = ORIENT;
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) {
       if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
+      if (ORIENT) M.gorient[s] = 0;
+    }
     W::fence();
     auto ccoff = M.ccoff;
     nterm = 0; ncc = 0;
@@ -356,29 +366,44 @@ struct GtsComponent {
         const uint32_t s = base0 + l0;
         M.vst[s] = GIS_PROCESSED;
         M.queue[0] = s;
+        if (ORIENT) {
+          if (ncc > 0) oriented = false;   /* a second cc: not the case this is for */
+          M.gorient[s] = 2;
+        }
         ccoff[ncc++] = nterm;
         W::fence();
         uint32_t bh = 0, bn = 1;
         while (bh < bn) {
           const uint32_t cnt = bn - bh < W::WIDTH ? bn - bh : W::WIDTH;
-          uint32_t my_v = 0, my_eb = 0, my_ee = 0;
+          uint32_t my_v = 0, my_eb = 0, my_ee = 0, my_o = 0;
           if (lane < cnt) {
             my_v = M.queue[bh + lane];
             my_eb = M.coff[my_v] - M.e0; my_ee = M.coff[my_v + 1] - M.e0;
+            if (ORIENT) my_o = M.gorient[my_v];
           }
           for (uint32_t i = 0; i < cnt; ++i) {
             const uint32_t cur = W::bcast(my_v, i), eb = W::bcast(my_eb, i), ee = W::bcast(my_ee, i);
+            const bool ou = ORIENT && W::bcast(my_o, i) == 2;
             bool has_s = false, has_a = false;
             for (uint32_t base = eb; base < ee; base += W::WIDTH) {
               const uint32_t ce = base + lane;
               bool live = false, sense = false, unv = false;
               uint32_t nb = 0;
+              bool clash = false;
               if (ce < ee) {
+                const uint32_t fl = M.cflags[ce];
                 live = !gts_edge_is_marked(M.cstate[ce]);
-                sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+                sense = (fl & GTS_F_SENSE) != 0;
                 nb = M.cend[ce];
                 unv = live && M.vst[nb] == GIS_UNVISITED;
+                if (ORIENT) {   /* as orient(): every compact edge, whatever the end's state */
+                  const uint32_t ov = (gts_next_dir((uint8_t)fl) != (sense != ou)) ? 2u : 1u;
+                  const uint32_t co = M.gorient[nb];
+                  clash = (fl & GTS_F_UTURN) || nb == cur || (co != 0 && co != ov);
+                  if (co == 0) M.gorient[nb] = (uint8_t)ov;
+                }
               }
+              if (ORIENT && W::ballot(clash)) oriented = false;
               has_s |= W::ballot(live && sense) != 0;
               has_a |= W::ballot(live && !sense) != 0;
               const uint64_t mask = W::ballot(unv);
@@ -501,12 +526,22 @@ struct GtsComponent {
   GTS_HD void removecycles(bool keep_cc)
   {
     const uint32_t lane = W::lane();
-    const bool oriented = C.fast_walks && nv > 1 && orient();
+    /* every compact edge live (no marked edge kept for its live twin): the first
+       terminal search assigns the strands on its way */
+    bool all_live = C.fast_walks && nv > 1;
+    for (uint32_t base = 0; base < M.ne && all_live; base += W::WIDTH) {
+      const uint32_t ce = base + lane;
+      all_live = W::ballot(ce < M.ne && gts_edge_is_marked(M.cstate[ce])) == 0;
+    }
+    bool oriented = false, first = true;
+    if (!all_live) oriented = C.fast_walks && nv > 1 && orient();
     bool found = true;
     clean = false;
     while (found) {
       found = false;
-      calc_cc();
+      if (first && all_live) calc_cc_t<true>(oriented);
+      else calc_cc();
+      first = false;
       if (oriented && peel()) { clean = true; break; }
       for (uint32_t s = lane; s < nv; s += W::WIDTH)
         if (!gts_vertex_is_marked(M.vst[s])) M.vst[s] = GIS_UNVISITED;
