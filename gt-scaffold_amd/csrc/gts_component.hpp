@@ -286,13 +286,14 @@ struct GtsComponent {
   bool reuse_cc;        /* makescaffold may use the ccs run() computed */
   uint32_t nodefer;     /* statistics: why try_defer declined */
   uint32_t *reach_bits; /* walk_task: bitmap of the vertices the walk labels */
+  uint64_t ubases;      /* all_bases(), ~0 = not computed yet */
   bool no_reference;    /* walk_task: leave a walk that needs the reference search to select_walks */
   bool needs_reference;
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), no_reference(false), needs_reference(false) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), no_reference(false), needs_reference(false) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -1563,6 +1564,18 @@ struct GtsComponent {
     return ok;
   }
 
+  /* bases of all contigs of the component (computed once) */
+  GTS_HD uint64_t all_bases()
+  {
+    if (ubases == ~0ull) {
+      uint64_t sum = 0;
+      for (uint32_t s = W::lane(); s < nv; s += W::WIDTH) sum += (uint64_t)M.cseq[s];
+      for (uint32_t off = W::WIDTH / 2; off > 0; off >>= 1) sum += W::shfl64(sum, W::lane() ^ off);
+      ubases = (uint64_t)W::uni64((int64_t)sum);
+    }
+    return ubases;
+  }
+
   /* ---- ref algorithms.c:767-868 (after its removecycles call) ---- */
   GTS_HD void makescaffold()
   {
@@ -1588,8 +1601,13 @@ struct GtsComponent {
       if (te - tb > 1) {
         uint64_t cc_len = 0;
         uint32_t cc_n = 0;
-        for (uint32_t j = tb; j < te; ++j)
+        for (uint32_t j = tb; j < te; ++j) {
+          /* a walk is a simple path inside the component: none can be STRICTLY
+             longer (algorithms.c:826) than one that holds every contig of it --
+             the usual outcome on a clean chain, whose other end needs no walk */
+          if (cc_len == all_bases()) break;
           if (!create_walk(W::uni(M.term[j]), cc_len, cc_n)) break;
+        }
         if (err) break;
         /* mark the best walk, algorithms.c:835-848 (a walk without edges is
            undefined behaviour there and is left unmarked here) */
