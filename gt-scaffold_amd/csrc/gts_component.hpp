@@ -1192,12 +1192,12 @@ struct GtsComponent {
           }
           us |= W::ballot(live && sense) != 0;
           ua |= W::ballot(live && !sense) != 0;
-          inexact = W::ballot(inexact) != 0;
           /* two in-arcs attain the label of v: edgemap keeps the one whose
              value arrived first (algorithms.c:711-717), i.e. the arc whose
              source's final node is pushed first */
           uint64_t tm = W::ballot(tie);
-          if (tm && inexact) { W::count(C.why + 5); bad = true; break; }
+          /* (inexact is kept per lane; the wave is asked only where it matters) */
+          if (tm && W::ballot(inexact)) { W::count(C.why + 5); bad = true; break; }
           while (tm) {
             const uint32_t l = W::ctz(tm);
             tm &= tm - 1;
@@ -1222,7 +1222,7 @@ struct GtsComponent {
         if (!bad && u != start && !(us && ua)) {
           if (plu > best_len) { best_len = plu; best_t = u; }
           else if (plu == best_len && best_t != GTS_NONE) {
-            if (inexact) { W::count(C.why + 7); bad = true; }
+            if (W::ballot(inexact)) { W::count(C.why + 7); bad = true; }
             else if (pushed_after(u, best_t, start)) best_t = u;
           }
         }
@@ -1496,13 +1496,13 @@ struct GtsComponent {
           }
           us |= W::ballot(live && sense) != 0;
           ua |= W::ballot(live && !sense) != 0;
-          inexact = W::ballot(inexact) != 0;
           const uint64_t fm = W::ballot(fresh);
           if (fresh) R[nr + W::popc_below(fm, lane)] = v;
           nr += W::popc(fm);
           pending += W::popc(fm);
           uint64_t tm = W::ballot(tie);
-          if (tm && inexact) { W::count(C.why + 5); bad = true; break; }
+          /* (inexact is kept per lane; the wave is asked only where it matters) */
+          if (tm && W::ballot(inexact)) { W::count(C.why + 5); bad = true; break; }
           while (tm) {
             const uint32_t tl = W::ctz(tm);
             tm &= tm - 1;
@@ -1521,7 +1521,7 @@ struct GtsComponent {
         if (!bad && u != start && !(us && ua)) {
           if (plu > best_len) { best_len = plu; best_t = u; }
           else if (plu == best_len && best_t != GTS_NONE) {
-            if (inexact) { W::count(C.why + 7); bad = true; }
+            if (W::ballot(inexact)) { W::count(C.why + 7); bad = true; }
             else if (pushed_after(u, best_t, start)) best_t = u;
           }
         }
