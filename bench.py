@@ -24,7 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 # The engine overlaps the launches of its LDS size classes on side streams; the
 # HIP runtime multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware
-# queues (default 4, shared with the main stream).  Eight let every class
+# queues (default 4; the engine's main stream takes one).  Eight let every class
 # launch that fits run (measured 88.4 -> 85.0 ms per step); has to be set
 # before the runtime starts, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -200,8 +200,10 @@ def main():
     g = make_inputs(pkg, args.contigs, 1234 + rank, dev, WORKLOAD["gen"])
     g["num_pairs"] = g["num_pairs"].to(torch.int64)
     nrec = g["root"].numel()
-    stream = torch.cuda.current_stream().cuda_stream
-    eng = pkg.engine.Engine(local_rank, stream)
+    # the engine runs on a stream of its own (a blocking stream: HIP orders it
+    # with the null stream the inputs above were generated on; every engine call
+    # drains it before returning)
+    eng = pkg.engine.Engine(local_rank)
     eng.set_option("profile", 0 if args.no_profile else 1)
     for kv in args.opt:
         name, value = kv.split("=")

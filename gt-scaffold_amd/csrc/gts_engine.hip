@@ -30,6 +30,18 @@
 /* LDS size classes of the component launches (bytes of dynamic LDS) */
 static const uint32_t gts_klass_bytes[GTS_NKLASS] = {4096, 6144, 8192, 12288, 16384, 24576, 32768,
                                                     49152, 65536, 98304, 163840};
+/* profile-event names of the class launches: string literals, so the pointers
+   kept in the pending-event table are valid in every thread for the life of
+   the library ([0] removecycles, [1] makescaffold) */
+static const char *const gts_klass_event[2][GTS_NKLASS] = {
+  {"components_removecycles_lds4k", "components_removecycles_lds6k", "components_removecycles_lds8k",
+   "components_removecycles_lds12k", "components_removecycles_lds16k", "components_removecycles_lds24k",
+   "components_removecycles_lds32k", "components_removecycles_lds48k", "components_removecycles_lds64k",
+   "components_removecycles_lds96k", "components_removecycles_lds160k"},
+  {"components_makescaffold_lds4k", "components_makescaffold_lds6k", "components_makescaffold_lds8k",
+   "components_makescaffold_lds12k", "components_makescaffold_lds16k", "components_makescaffold_lds24k",
+   "components_makescaffold_lds32k", "components_makescaffold_lds48k", "components_makescaffold_lds64k",
+   "components_makescaffold_lds96k", "components_makescaffold_lds160k"}};
 #define GTS_NSTREAMS 6
 /* device scalars of the class bookkeeping (u32 index into d_scalars, 16 entries each) */
 #define GTS_S_KSIZE 256
@@ -71,6 +83,7 @@ struct GtsgEngine {
   uint8_t *flags = nullptr, *state = nullptr;
   uint32_t nhub = 0;
   uint32_t *hubs = nullptr;
+  uint32_t built_hub_degree = 32;   /* the hub list holds the vertices above THIS degree */
   bool built = false;
   /* scratch of an open gtsg_filter_begin / gtsg_filter_end pair */
   bool filter_open = false;
@@ -260,11 +273,15 @@ __global__ void k_iota(uint32_t *p, uint64_t n)
 
 /* ---- build ---- */
 __global__ void k_pair_keys(const uint32_t *root, const uint32_t *ctg,
-                            uint64_t *keys, uint32_t *vals, uint64_t nrec)
+                            uint64_t *keys, uint32_t *vals, uint64_t nrec,
+                            uint32_t n, uint32_t *bad)
 {
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nrec) return;
   uint32_t a = root[k], b = ctg[k];
+  /* ids come straight from the caller: nothing may be indexed with them before
+     the host has seen this flag */
+  if (a >= n || b >= n) *bad = 1;
   uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
   /* bit 63 (contig ids stay below 2^31, no sorting pass looks at it): the
      record is listed from the smaller contig */
@@ -282,13 +299,15 @@ __global__ void k_pair_keys(const uint32_t *root, const uint32_t *ctg,
    root a record was listed from is read off bit 63 of its key. */
 __global__ void k_pair_segments(const uint64_t *keys, const uint32_t *recs,
                                 const float *sd, uint32_t *is_creator,
-                                uint32_t *fwd_win, uint32_t *bwd_win, uint64_t nrec)
+                                uint32_t *fwd_win, uint32_t *bwd_win, uint64_t nrec,
+                                int never_replace)
 {
   const uint64_t PAIR = ~(1ull << 63);
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrec) return;
   const uint64_t key = keys[i];
   if (i > 0 && ((keys[i - 1] ^ key) & PAIR) == 0) { is_creator[recs[i]] = 0; return; }
+  if (never_replace) return;   /* ismatepair: an existing edge is never altered (parser.c:362) */
   if (i + 1 >= nrec || ((keys[i + 1] ^ key) & PAIR) != 0) return;
   const uint32_t k0 = recs[i];
   const bool selfloop = (uint32_t)(key >> 32 & 0x7FFFFFFFu) == (uint32_t)key;
@@ -1208,31 +1227,28 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
   }
   GtsgEngine *e = new GtsgEngine();
   e->device = device;
+  /* gtsg_destroy releases whatever has been created so far */
   if (hipSetDevice(device) != hipSuccess) { delete e; return GTSG_EHIP; }
   if (stream) e->st = (hipStream_t)stream;
   else {
     if (hipStreamCreate(&e->st) != hipSuccess) { delete e; return GTSG_EHIP; }
     e->own_stream = true;
   }
-  if (hipMalloc((void **)&e->d_scalars, 4096) != hipSuccess) { delete e; return GTSG_ENOMEM; }
-  for (int k = 0; k < GTS_NSTREAMS; ++k)
-    if (hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking) != hipSuccess) { delete e; return GTSG_EHIP; }
-  for (int k = 0; k < GTS_NKLASS; ++k)
-    if (hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming) != hipSuccess) { delete e; return GTSG_EHIP; }
-  if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { delete e; return GTSG_EHIP; }
-  if (hipFuncSetAttribute((const void *)k_walk_tasks_mixed,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
-    delete e; return GTSG_EHIP;
-  }
-  if (hipFuncSetAttribute((const void *)k_walk_tasks,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
-    delete e; return GTSG_EHIP;
-  }
-  if (hipFuncSetAttribute((const void *)k_components_lds,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
-    fprintf(stderr, "gtsg_create: cannot raise the dynamic LDS limit to 160 KiB\n");
-    delete e; return GTSG_EHIP;
-  }
+  int rc = 0;
+  if (hipMalloc((void **)&e->d_scalars, 4096) != hipSuccess) rc = GTSG_ENOMEM;
+  for (int k = 0; k < GTS_NSTREAMS && !rc; ++k)
+    if (hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking) != hipSuccess) rc = GTSG_EHIP;
+  for (int k = 0; k < GTS_NKLASS && !rc; ++k)
+    if (hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
+  if (!rc && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
+  const void *big_lds[] = {(const void *)k_walk_tasks_mixed, (const void *)k_walk_tasks,
+                           (const void *)k_components_lds};
+  for (const void *f : big_lds)
+    if (!rc && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
+      fprintf(stderr, "gtsg_create: cannot raise the dynamic LDS limit to 160 KiB\n");
+      rc = GTSG_EHIP;
+    }
+  if (rc) { gtsg_destroy(e); return rc; }
   *out = e;
   return 0;
 }
@@ -1324,6 +1340,15 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
                             const float *std_dev, const int64_t *num_pairs,
                             const uint8_t *flags, int on_device)
 {
+  return gtsg_build_from_records_ex(e, nrec, root, ctg, dist, std_dev, num_pairs, flags,
+                                    on_device, 0);
+}
+
+int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
+                               const uint32_t *ctg, const int64_t *dist,
+                               const float *std_dev, const int64_t *num_pairs,
+                               const uint8_t *flags, int on_device, int ismatepair)
+{
   if (!e || (nrec && (!root || !ctg || !dist || !std_dev || !flags))) return GTSG_EINVAL;
   if (nrec >= (1ull << 31) - 1) return fail(e, GTSG_ELIMIT, "too many records");
   HIPCHK(hipSetDevice(e->device));
@@ -1344,13 +1369,14 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
     PALLOC(t_root, uint32_t, nrec); PALLOC(t_ctg, uint32_t, nrec);
     PALLOC(t_dist, int64_t, nrec); PALLOC(t_sd, float, nrec);
     PALLOC(t_flags, uint8_t, nrec);
-    upload(e, t_root, root, nrec, 0); upload(e, t_ctg, ctg, nrec, 0);
-    upload(e, t_dist, dist, nrec, 0); upload(e, t_sd, std_dev, nrec, 0);
-    upload(e, t_flags, flags, nrec, 0);
+    if ((rc = upload(e, t_root, root, nrec, 0)) || (rc = upload(e, t_ctg, ctg, nrec, 0)) ||
+        (rc = upload(e, t_dist, dist, nrec, 0)) || (rc = upload(e, t_sd, std_dev, nrec, 0)) ||
+        (rc = upload(e, t_flags, flags, nrec, 0)))
+      return rc;
     d_root = t_root; d_ctg = t_ctg; d_dist = t_dist; d_sd = t_sd; d_flags = t_flags;
     if (num_pairs) {
       PALLOC(t_np, int64_t, nrec);
-      upload(e, t_np, num_pairs, nrec, 0);
+      if ((rc = upload(e, t_np, num_pairs, nrec, 0))) return rc;
       d_np = t_np;
     }
   }
@@ -1360,7 +1386,9 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
     PALLOC(k0, uint64_t, nrec); PALLOC(k1, uint64_t, nrec);
     PALLOC(v0, uint32_t, nrec); PALLOC(v1, uint32_t, nrec);
     PALLOC(stmp, uint32_t, gts_sort_tmp_elems(nrec));
-    LAUNCH("build_pair_keys", k_pair_keys, nblk(nrec), GTS_BLOCK, d_root, d_ctg, k0, v0, nrec);
+    HIPCHK(hipMemsetAsync(e->d_scalars + 6, 0, 4, e->st));
+    LAUNCH("build_pair_keys", k_pair_keys, nblk(nrec), GTS_BLOCK, d_root, d_ctg, k0, v0, nrec, n,
+           e->d_scalars + 6);
     const int vb = bits_for(n);
     int shifts[8], np = 0;
     for (int s = 0; s < vb; s += 8) shifts[np++] = s;
@@ -1379,10 +1407,13 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
     LAUNCH("fill", k_fill<uint32_t>, nblk(nrec), GTS_BLOCK, is_creator, 1u, (uint64_t)nrec);
     HIPCHK(hipMemsetAsync(fwd, 0xFF, nrec * 4, e->st));
     LAUNCH("build_pair_segments", k_pair_segments, nblk(nrec), GTS_BLOCK, ks, vs, d_sd,
-           is_creator, fwd, bwd, nrec);
+           is_creator, fwd, bwd, nrec, ismatepair ? 1 : 0);
     { ProfScope ps(e, "build_scan_creators");
       gts_exscan<uint32_t, uint32_t>(is_creator, jidx, nrec, sctmp, e->d_scalars, e->st); }
+    uint32_t bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, e->d_scalars + 6, 4, hipMemcpyDeviceToHost, e->st));
     if ((rc = read_u32(e, e->d_scalars, &npairs_created))) return rc;
+    if (bad) return fail(e, GTSG_EINVAL, "contig id out of range in the records (%u contigs)", n);
   }
   const uint64_t m64 = 2ull * npairs_created;
   if (m64 >= 0xFFFFFFFEull) return fail(e, GTSG_ELIMIT, "more than 2^32-2 edges");
@@ -1427,8 +1458,9 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t nrec, const uint32_t *root,
   if (n) {
     PALLOC(hflag, uint32_t, n); PALLOC(hidx, uint32_t, n);
     PALLOC(htmp, uint32_t, gts_scan_tmp_elems(n));
+    e->built_hub_degree = (uint32_t)e->hub_degree;
     LAUNCH("build_hub_flags", k_hub_flags, nblk(n), GTS_BLOCK, e->row, hflag, n,
-           (uint32_t)e->hub_degree);
+           e->built_hub_degree);
     gts_exscan<uint32_t, uint32_t>(hflag, hidx, n, htmp, e->d_scalars + 2, e->st);
     uint32_t nh = 0;
     if ((rc = read_u32(e, e->d_scalars + 2, &nh))) return rc;
@@ -1481,8 +1513,10 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   PALLOC(vattr, GtsVAttr, n);
   HIPCHK(hipMemsetAsync(prop, 0, (size_t)m + 1, e->st));
   LAUNCH("filter_pack_vattr", k_pack_vattr, nblk(n), GTS_BLOCK, e->seq_len, e->copy_num, vattr, n);
+  /* the degree the hub list was built with: option "hub_degree" set after the
+     build takes effect at the next build */
   LAUNCH("filter_pairs", k_filter_pairs, nblk(n), GTS_BLOCK, G, P, vattr, prop, vinfo,
-         (uint32_t)e->hub_degree);
+         e->built_hub_degree);
   if (e->nhub)
     LAUNCH("filter_pairs_hub", k_filter_pairs_hub, nblk((uint64_t)e->nhub * GTS_WAVE),
            GTS_BLOCK, G, P, prop, vinfo, e->hubs, e->nhub);
@@ -1503,7 +1537,7 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   if (m) LAUNCH("filter_tpoly", k_filter_tpoly, nblk(m), GTS_BLOCK, G, e->estart, prop, vinfo, tpoly);
   LAUNCH("filter_pack_vattr", k_vattr_tpoly, nblk(n), GTS_BLOCK, tpoly, vattr, n);
   LAUNCH("filter_ovf_init", k_filter_ovf_init, nblk(n), GTS_BLOCK, G, P, vattr, e->estart, vinfo, tpoly,
-         ovf, zero_ovf, (uint32_t)e->hub_degree);
+         ovf, zero_ovf, e->built_hub_degree);
   if (e->nhub && !zero_ovf)
     LAUNCH("filter_ovf_init_hub", k_filter_ovf_init_hub,
            nblk((uint64_t)e->nhub * GTS_WAVE), GTS_BLOCK, G, P, vinfo, tpoly, ovf, e->hubs,
@@ -1579,11 +1613,13 @@ int gtsg_filter(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocutoff)
    root under the smaller); on return labels[v] is the root = smallest contig
    of v's tree. */
 __global__ void k_label_union(const uint32_t *root, const uint32_t *ctg,
-                              const uint8_t *skip, uint32_t *parent, uint64_t nrec)
+                              const uint8_t *skip, uint32_t *parent, uint64_t nrec,
+                              uint32_t n, uint32_t *bad)
 {
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nrec) return;
   uint32_t x = root[k], y = ctg[k];
+  if (x >= n || y >= n) { *bad = 1; return; }
   if (skip && (skip[x] || skip[y])) return;
   for (;;) {
     x = uf_find(parent, x); y = uf_find(parent, y);
@@ -1602,6 +1638,7 @@ int gtsg_label_components(GtsgEngine *e, uint64_t n, uint64_t nrec, const uint32
                           int on_device)
 {
   if (!e || !labels || (nrec && (!root || !ctg))) return GTSG_EINVAL;
+  if (n >= (1ull << 31)) return fail(e, GTSG_ELIMIT, "more than 2^31-1 contigs");
   HIPCHK(hipSetDevice(e->device));
   int rc;
   const uint32_t *d_root = root, *d_ctg = ctg;
@@ -1611,13 +1648,20 @@ int gtsg_label_components(GtsgEngine *e, uint64_t n, uint64_t nrec, const uint32
     if ((rc = pool_reserve(e, nrec * 8 + n * 5 + (1u << 20)))) return rc;
     PALLOC(tr, uint32_t, nrec + 1); PALLOC(tc, uint32_t, nrec + 1);
     PALLOC(tl, uint32_t, n + 1); PALLOC(ts, uint8_t, n + 1);
-    upload(e, tr, root, nrec, 0); upload(e, tc, ctg, nrec, 0); upload(e, tl, labels, n, 0);
-    if (skip) upload(e, ts, skip, n, 0);
+    if ((rc = upload(e, tr, root, nrec, 0)) || (rc = upload(e, tc, ctg, nrec, 0)) ||
+        (rc = upload(e, tl, labels, n, 0)) || (skip && (rc = upload(e, ts, skip, n, 0))))
+      return rc;
     d_root = tr; d_ctg = tc; d_lab = tl; d_skip = skip ? ts : nullptr;
   }
+  HIPCHK(hipMemsetAsync(e->d_scalars + 6, 0, 4, e->st));
   if (nrec)
-    LAUNCH("label_union", k_label_union, nblk(nrec), GTS_BLOCK, d_root, d_ctg, d_skip, d_lab, nrec);
+    LAUNCH("label_union", k_label_union, nblk(nrec), GTS_BLOCK, d_root, d_ctg, d_skip, d_lab, nrec,
+           (uint32_t)n, e->d_scalars + 6);
   if (n) LAUNCH("label_flatten", k_label_flatten, nblk(n), GTS_BLOCK, d_lab, (uint32_t)n);
+  uint32_t bad = 0;
+  if ((rc = read_u32(e, e->d_scalars + 6, &bad))) return rc;
+  if (bad) return fail(e, GTSG_EINVAL, "contig id out of range in the records (%llu contigs)",
+                       (unsigned long long)n);
   if (!on_device)
     HIPCHK(hipMemcpyAsync(labels, d_lab, n * 4, hipMemcpyDeviceToHost, e->st));
   return sync_stream(e);
@@ -1826,18 +1870,13 @@ static int run_components(GtsgEngine *e, int mode)
          included): that many launches are in flight at a time. */
       for (int k = (int)nk - 1; k >= 0; --k) {
         if (!kcount[k]) continue;
-        static std::string kn[2][GTS_NKLASS];   /* event names live as long as the library */
-        if (kn[0][k].empty()) {
-          kn[0][k] = "components_removecycles_lds" + std::to_string(klass_h[k] / 1024) + "k";
-          kn[1][k] = "components_makescaffold_lds" + std::to_string(klass_h[k] / 1024) + "k";
-        }
         hipStream_t ss = e->side[((int)nk - 1 - k) % (int)e->class_streams];
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
         k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode);
         if (e->profile) { hipEventRecord(_b, ss);
-                          e->pending.push_back({kn[mode == GTS_MODE_MAKESCAFFOLD][k].c_str(), _a, _b}); }
+                          e->pending.push_back({gts_klass_event[mode == GTS_MODE_MAKESCAFFOLD][k], _a, _b}); }
         HIPCHK(hipEventRecord(e->ev_join[k], ss));
         e->stats["components_lds_class" + std::to_string(k)] = kcount[k];
         first += kcount[k];
@@ -2001,9 +2040,15 @@ static int run_components(GtsgEngine *e, int mode)
     e->stats["components"] = ncomp;
     e->stats["max_component"] = res[2];
     e->stats["compact_edges"] = nce;
-    if (res[1])
+    if (res[1]) {
+      /* the graph goes back to its state before the call: some components have
+         written their marks, others have not */
+      HIPCHK(hipMemcpyAsync(e->vstate, snap_v, n, hipMemcpyDeviceToDevice, e->st));
+      if (m) HIPCHK(hipMemcpyAsync(e->state, snap_e, m, hipMemcpyDeviceToDevice, e->st));
+      HIPCHK(hipStreamSynchronize(e->st));
       return fail(e, GTSG_EWALK, "%u components exceeded max_walk_pops=%lld or hold a "
-                  "cyclic distance map", res[1], (long long)e->max_walk_pops);
+                  "cyclic distance map; states restored", res[1], (long long)e->max_walk_pops);
+    }
     if (!res[0]) break;
     /* walk queue too small somewhere: restore and retry with more room */
     HIPCHK(hipMemcpyAsync(e->vstate, snap_v, n, hipMemcpyDeviceToDevice, e->st));
@@ -2096,7 +2141,9 @@ int gtsg_selftest_ambiguous(GtsgEngine *e, uint64_t n, const int64_t *d1,
   if ((rc = pool_reserve(e, n * 32 + (1u << 20)))) return rc;
   PALLOC(a, int64_t, n); PALLOC(b, float, n); PALLOC(c, int64_t, n);
   PALLOC(d, float, n); PALLOC(o, uint8_t, n);
-  upload(e, a, d1, n, 0); upload(e, b, s1, n, 0); upload(e, c, d2, n, 0); upload(e, d, s2, n, 0);
+  if ((rc = upload(e, a, d1, n, 0)) || (rc = upload(e, b, s1, n, 0)) || (rc = upload(e, c, d2, n, 0)) ||
+      (rc = upload(e, d, s2, n, 0)))
+    return rc;
   LAUNCH("amb_test", k_amb_test, nblk(n), GTS_BLOCK, a, b, c, d, o, n, gts_amb_thresholds(pcutoff));
   HIPCHK(hipMemcpyAsync(out, o, n, hipMemcpyDeviceToHost, e->st));
   return sync_stream(e);

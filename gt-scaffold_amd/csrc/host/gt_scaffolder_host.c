@@ -46,6 +46,7 @@ struct GtScaffolderGraph {
   bool edges_cached;
   uint8_t *vstate, *estate;  /* host copies, refreshed from the engine */
   GtsgEngine *eng;           /* NULL for hand-built graphs */
+  bool sorted;               /* contigs in header order (ids are final) */
   char err[512];
 };
 
@@ -175,15 +176,17 @@ static bool find_contig(const GtScaffolderGraph *g, const char *name, uint32_t *
 }
 
 /* FASTA: '>' description newline, then sequence characters up to the next
-   '>' (blanks and line ends do not count).  Keeps contigs longer than
-   min_ctg_len (ref parser.c:481), header cut at the first blank (parser.c:
-   452-458), optional "length= depth= k= astat=" annotation (parser.c:438-450). */
-static int read_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len,
-                        bool annotated, char *err, size_t errlen)
+   '>' (blanks and line ends do not count).  With a graph: keeps contigs longer
+   than min_ctg_len (ref parser.c:481), header cut at the first blank
+   (parser.c:452-458), optional "length= depth= k= astat=" annotation
+   (parser.c:438-450).  Without (g == NULL): counts the contigs of at least
+   min_ctg_len into *count (ref parser.c:399-415, which tests >=). */
+static int scan_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len,
+                        bool annotated, uint64_t *count, char *err, size_t errlen)
 {
   size_t len, i = 0;
   char *buf = slurp(path, &len);
-  uint64_t cap = 0;
+  uint64_t cap = g ? g->max_nof_vertices : 0;
   if (!buf) return seterr(err, errlen, "cannot open file %s", path);
   if (len == 0) { free(buf); return seterr(err, errlen, "sequence file %s is empty", path); }
   if (buf[0] != '>') {
@@ -206,7 +209,7 @@ static int read_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len
       char save = buf[de];
       char *desc = buf + ds, *sp;
       buf[de] = '\0';
-      if (annotated) {
+      if (g && annotated) {
         char part[1024];
         long n1, n2;
         if (sscanf(desc, "%1023s length=%ld depth=%ld k=%f astat=%f", part, &n1, &n2,
@@ -215,19 +218,23 @@ static int read_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len
           return seterr(err, errlen, "No A-statistic/copy number was found in header");
         }
       }
-      if (de == ds) { free(buf); return seterr(err, errlen, "Invalid header length"); }
+      if (g && de == ds) { free(buf); return seterr(err, errlen, "Invalid header length"); }
       if (slen == 0) { free(buf); return seterr(err, errlen, "Invalid sequence length"); }
       sp = strchr(desc, ' ');
       if (sp) *sp = '\0';
-      if (slen > min_len) {
+      if (!g) {
+        if (slen >= min_len) ++*count;
+      } else if (slen > min_len) {
         if (g->nof_vertices == cap) {
           cap = cap ? 2 * cap : 1024;
           g->ctg = xrealloc(g->ctg, cap * sizeof *g->ctg);
+          g->vstate = xrealloc(g->vstate, cap);
         }
         g->ctg[g->nof_vertices].name = strdup(desc);
         g->ctg[g->nof_vertices].seq_len = slen;
         g->ctg[g->nof_vertices].astat = astat;
         g->ctg[g->nof_vertices].copy_num = copynum;
+        g->vstate[g->nof_vertices] = 0;
         g->nof_vertices++;
       }
       if (sp) *sp = ' ';
@@ -235,10 +242,40 @@ static int read_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len
     }
   }
   free(buf);
-  g->max_nof_vertices = g->nof_vertices;
-  /* vertex ids = rank of the header, ref parser.c:172 */
-  qsort(g->ctg, g->nof_vertices, sizeof *g->ctg, contig_cmp);
+  if (g) {
+    g->max_nof_vertices = cap;
+    g->sorted = false;
+  }
   return 0;
+}
+
+/* vertex ids = rank of the header, ref parser.c:172 */
+static void sort_contigs(GtScaffolderGraph *g)
+{
+  if (!g->sorted) qsort(g->ctg, g->nof_vertices, sizeof *g->ctg, contig_cmp);
+  g->sorted = true;
+}
+
+/* ref gt_scaffolder_parser.c:495 */
+int gt_scaffolder_parser_count_contigs(const char *filename, uint64_t min_ctg_len,
+                                       uint64_t *nof_contigs, char *err, size_t errlen)
+{
+  uint64_t n = 0;
+  int rc;
+  if (!filename || !nof_contigs) return seterr(err, errlen, "invalid argument");
+  rc = scan_contigs(NULL, filename, min_ctg_len, false, &n, err, errlen);
+  *nof_contigs = n;
+  return rc;
+}
+
+/* ref gt_scaffolder_parser.c:524 */
+int gt_scaffolder_parser_read_contigs(GtScaffolderGraph *graph, const char *filename,
+                                      uint64_t min_ctg_len, bool astat_is_annotated,
+                                      char *err, size_t errlen)
+{
+  if (!graph || !filename) return seterr(err, errlen, "invalid argument");
+  if (graph->eng) return seterr(err, errlen, "the graph has been built already");
+  return scan_contigs(graph, filename, min_ctg_len, astat_is_annotated, NULL, err, errlen);
 }
 
 /* ------------------------------------------------------------------ */
@@ -286,15 +323,15 @@ static bool scan_record(const char *field, char *hdr, long *dist, long *np, floa
    the direction at ';'.  Lines the reference's 1024-byte fgets buffer would
    split are rejected instead of being mis-parsed. */
 static int read_distance_records(const GtScaffolderGraph *g, const char *path,
-                                 Records *out, char *err, size_t errlen)
+                                 int pass, uint64_t *nof_valid, Records *out,
+                                 char *err, size_t errlen)
 {
   size_t len, pos;
   char *buf = slurp(path, &len), *line = NULL, hdr[1024];
   size_t linecap = 0;
   uint64_t valid_records = 0;
-  int pass;
   if (!buf) return seterr(err, errlen, "can not read distance file %s", path);
-  for (pass = 0; pass < 2; pass++) {
+  {
     pos = 0;
     while (pos < len) {
       size_t ls = pos, ll;
@@ -363,6 +400,7 @@ static int read_distance_records(const GtScaffolderGraph *g, const char *path,
     }
   }
   free(buf); free(line);
+  if (nof_valid) *nof_valid = valid_records;
   return 0;
 }
 
@@ -374,23 +412,45 @@ static int engine_err(GtScaffolderGraph *g, int rc, char *err, size_t errlen)
   return -1;
 }
 
-int gt_scaffolder_graph_new_from_file(GtScaffolderGraph **out, const char *ctg_filename,
-                                      uint64_t min_ctg_len, const char *dist_filename,
-                                      bool astat_is_annotated, char *err, size_t errlen)
+/* ref gt_scaffolder_parser.c:150: integrity check of the .de file; sorts the
+   contigs by header (parser.c:172: ids are final from here on) and returns in
+   *nof_distances the number of edges the records can create at most (two per
+   record between known contigs, parser.c:246-250) */
+int gt_scaffolder_parser_count_distances(const GtScaffolderGraph *graph, const char *file_name,
+                                         uint64_t *nof_distances, char *err, size_t errlen)
 {
-  GtScaffolderGraph *g = xcalloc(1, sizeof *g);
+  uint64_t valid = 0;
+  int rc;
+  if (!graph || !file_name || !nof_distances) return seterr(err, errlen, "invalid argument");
+  sort_contigs((GtScaffolderGraph *)graph);   /* the reference sorts through the const, too */
+  rc = read_distance_records(graph, file_name, 0, &valid, NULL, err, errlen);
+  if (!rc) *nof_distances = 2 * valid;
+  return rc;
+}
+
+/* ref gt_scaffolder_parser.c:295: the records of the file, in file order,
+   become the edges of the graph -- on the GPU (gtsg_build_from_records_ex
+   restates the per-record find_edge / alter_edge / add_edge updates of
+   parser.c:357-378).  One call per graph: the reference sizes its edge array
+   for one file (graph.c:391-396). */
+int gt_scaffolder_parser_read_distances(const char *filename, GtScaffolderGraph *g,
+                                        bool ismatepair, char *err, size_t errlen)
+{
   Records r;
   int64_t *seq;
   float *as, *cn;
   uint64_t i;
   int rc;
+  if (!g || !filename) return seterr(err, errlen, "invalid argument");
+  if (g->eng) return seterr(err, errlen, "distances have been read into this graph already");
+  if (g->nof_edges) return seterr(err, errlen, "the graph holds hand-built edges");
   memset(&r, 0, sizeof r);
-  *out = NULL;
-  rc = read_contigs(g, ctg_filename, min_ctg_len, astat_is_annotated, err, errlen);
-  if (!rc) rc = read_distance_records(g, dist_filename, &r, err, errlen);
-  if (rc) { rec_free(&r); gt_scaffolder_graph_delete(g); return -1; }
+  sort_contigs(g);
+  rc = read_distance_records(g, filename, 1, NULL, &r, err, errlen);
+  if (rc) { rec_free(&r); return -1; }
   if (gtsg_create(&g->eng, g_device, NULL) != 0) {
-    rec_free(&r); gt_scaffolder_graph_delete(g);
+    rec_free(&r);
+    g->eng = NULL;
     return seterr(err, errlen, "no MI355X available: the scaffolder engine has no CPU path");
   }
   seq = xcalloc(g->nof_vertices, sizeof *seq);
@@ -401,13 +461,42 @@ int gt_scaffolder_graph_new_from_file(GtScaffolderGraph **out, const char *ctg_f
   }
   rc = gtsg_set_contigs(g->eng, g->nof_vertices, seq, as, cn, 0);
   if (!rc)
-    rc = gtsg_build_from_records(g->eng, r.n, r.root, r.ctg, r.dist, r.sd, r.np, r.flags, 0);
+    rc = gtsg_build_from_records_ex(g->eng, r.n, r.root, r.ctg, r.dist, r.sd, r.np, r.flags, 0,
+                                    ismatepair ? 1 : 0);
   free(seq); free(as); free(cn); rec_free(&r);
-  if (rc) { engine_err(g, rc, err, errlen); gt_scaffolder_graph_delete(g); return -1; }
+  if (rc) {
+    engine_err(g, rc, err, errlen);
+    gtsg_destroy(g->eng);
+    g->eng = NULL;
+    return -1;
+  }
   g->nof_edges = g->max_nof_edges = gtsg_num_edges(g->eng);
+  free(g->vstate); free(g->estate); free(g->edges);
   g->vstate = xcalloc(g->nof_vertices, 1);
   g->estate = xcalloc(g->nof_edges, 1);
   g->edges = xcalloc(g->nof_edges, sizeof *g->edges);
+  g->edges_cached = false;
+  return 0;
+}
+
+/* ref gt_scaffolder_graph.c:346-419: the same five steps */
+int gt_scaffolder_graph_new_from_file(GtScaffolderGraph **out, const char *ctg_filename,
+                                      uint64_t min_ctg_len, const char *dist_filename,
+                                      bool astat_is_annotated, char *err, size_t errlen)
+{
+  GtScaffolderGraph *g = NULL;
+  uint64_t nof_contigs = 0, nof_distances = 0;
+  int rc;
+  *out = NULL;
+  rc = gt_scaffolder_parser_count_contigs(ctg_filename, min_ctg_len, &nof_contigs, err, errlen);
+  if (!rc) {
+    g = gt_scaffolder_graph_new(nof_contigs, 0);
+    rc = gt_scaffolder_parser_read_contigs(g, ctg_filename, min_ctg_len, astat_is_annotated,
+                                           err, errlen);
+  }
+  if (!rc) rc = gt_scaffolder_parser_count_distances(g, dist_filename, &nof_distances, err, errlen);
+  if (!rc) rc = gt_scaffolder_parser_read_distances(dist_filename, g, false, err, errlen);
+  if (rc) { gt_scaffolder_graph_delete(g); return -1; }
   *out = g;
   return 0;
 }

@@ -15,7 +15,7 @@ _LIB = None
 
 SYMBOLS = [
     "gtsg_create", "gtsg_destroy", "gtsg_last_error", "gtsg_set_contigs",
-    "gtsg_build_from_records", "gtsg_set_astat", "gtsg_mark_repeats", "gtsg_filter",
+    "gtsg_build_from_records", "gtsg_build_from_records_ex", "gtsg_set_astat", "gtsg_mark_repeats", "gtsg_filter",
     "gtsg_removecycles", "gtsg_makescaffold", "gtsg_num_vertices", "gtsg_num_edges",
     "gtsg_get_vertex_states", "gtsg_get_edge_states", "gtsg_get_edges", "gtsg_state_digest",
     "gtsg_set_option", "gtsg_selftest_ambiguous", "gtsg_filter_begin", "gtsg_filter_end",
@@ -33,6 +33,8 @@ HOST_SYMBOLS = [
     "gt_scaffolder_graph_records_delete", "gt_scaffolder_graph_write_scaffold",
     "gt_scaffolder_graph_nof_vertices", "gt_scaffolder_graph_nof_edges",
     "gt_scaffolder_graph_last_error", "gt_scaffolder_set_device",
+    "gt_scaffolder_parser_count_contigs", "gt_scaffolder_parser_read_contigs",
+    "gt_scaffolder_parser_count_distances", "gt_scaffolder_parser_read_distances",
 ]
 
 
@@ -57,6 +59,7 @@ def lib():
         L.gtsg_last_error.restype = C.c_char_p
         L.gtsg_set_contigs.argtypes = [vp, u64, vp, vp, vp, ci]
         L.gtsg_build_from_records.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, ci]
+        L.gtsg_build_from_records_ex.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, ci, ci]
         L.gtsg_set_astat.argtypes = [vp, vp, vp, ci]
         L.gtsg_mark_repeats.argtypes = [vp, ci, f32, f32]
         L.gtsg_filter.argtypes = [vp, f32, f32, i64]
@@ -108,12 +111,19 @@ def lib():
         L.gt_scaffolder_graph_last_error.argtypes = [vp]
         L.gt_scaffolder_graph_last_error.restype = cp
         L.gt_scaffolder_set_device.argtypes = [ci]
+        L.gt_scaffolder_parser_count_contigs.argtypes = [cp, u64, C.POINTER(u64), cp, sz]
+        L.gt_scaffolder_parser_read_contigs.argtypes = [vp, cp, u64, b, cp, sz]
+        L.gt_scaffolder_parser_count_distances.argtypes = [vp, cp, C.POINTER(u64), cp, sz]
+        L.gt_scaffolder_parser_read_distances.argtypes = [cp, vp, b, cp, sz]
         _LIB = L
     return _LIB
 
 
 class EngineError(RuntimeError):
     pass
+
+
+HIP_STREAM_LEGACY = 1   # hip_runtime_api.h: #define hipStreamLegacy ((hipStream_t)1)
 
 
 def _ptr(a, dtype):
@@ -136,9 +146,14 @@ class Engine:
     reference's API (gt_scaffolder_graph_* / gt_scaffolder_*)."""
 
     def __init__(self, device=0, stream=None):
+        """stream: None = the engine creates its own (blocking) stream; an int =
+        a hipStream_t handle, 0 being the legacy null stream (torch's default
+        stream), which the C ABI spells hipStreamLegacy."""
         self._L = lib()
         h = C.c_void_p()
-        rc = self._L.gtsg_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None)
+        self._stream = stream
+        arg = None if stream is None else C.c_void_p(HIP_STREAM_LEGACY if stream == 0 else stream)
+        rc = self._L.gtsg_create(C.byref(h), int(device), arg)
         if rc != 0:
             raise EngineError("gtsg_create failed (%d): no usable HIP device; the engine has no "
                               "CPU fallback" % rc)
@@ -159,6 +174,18 @@ class Engine:
         if rc != 0:
             raise EngineError("%s (code %d)" % (self._L.gtsg_last_error(self._h).decode(), rc))
 
+    def _sync_producer(self, ptrs):
+        """Stream contract of gt_scaffold_hip.h: device inputs must be complete
+        before the call.  Tensors made on torch's null stream are ordered with
+        the engine's own blocking stream by HIP; if torch's current stream is
+        any other stream than the engine's, it is drained here."""
+        if not any(p[1] for p in ptrs if p[1] is not None):
+            return
+        import torch
+        cur = torch.cuda.current_stream().cuda_stream
+        if cur != 0 and cur != self._stream:
+            torch.cuda.current_stream().synchronize()
+
     def _same_side(self, sides):
         sides = [s for s in sides if s is not None]
         if len(set(sides)) > 1:
@@ -170,18 +197,22 @@ class Engine:
         p0, d0, k0 = _ptr(seq_len, np.int64)
         p1, d1, k1 = _ptr(astat, np.float32)
         p2, d2, k2 = _ptr(copy_num, np.float32)
+        self._sync_producer([(p0, d0), (p1, d1), (p2, d2)])
         self._chk(self._L.gtsg_set_contigs(self._h, len(seq_len), p0, p1, p2,
                                            self._same_side([d0, d1, d2])))
 
-    def build_from_records(self, root, ctg, dist, std_dev, num_pairs, flags):
+    def build_from_records(self, root, ctg, dist, std_dev, num_pairs, flags, ismatepair=False):
         a = [_ptr(root, np.uint32), _ptr(ctg, np.uint32), _ptr(dist, np.int64),
              _ptr(std_dev, np.float32), _ptr(num_pairs, np.int64), _ptr(flags, np.uint8)]
-        self._chk(self._L.gtsg_build_from_records(self._h, len(root), *[x[0] for x in a],
-                                                  self._same_side([x[1] for x in a])))
+        self._sync_producer(a)
+        self._chk(self._L.gtsg_build_from_records_ex(self._h, len(root), *[x[0] for x in a],
+                                                     self._same_side([x[1] for x in a]),
+                                                     int(bool(ismatepair))))
 
     def set_astat(self, astat, copy_num):
         p1, d1, k1 = _ptr(astat, np.float32)
         p2, d2, k2 = _ptr(copy_num, np.float32)
+        self._sync_producer([(p1, d1), (p2, d2)])
         self._chk(self._L.gtsg_set_astat(self._h, p1, p2, self._same_side([d1, d2])))
 
     # ---- algorithms ----
@@ -210,10 +241,12 @@ class Engine:
 
     def filter_set_lasthit(self, src):
         p, d, k = _ptr(src, np.int32)
+        self._sync_producer([(p, d)])
         self._chk(self._L.gtsg_filter_set_lasthit(self._h, p, d))
 
     def label_components(self, n, root, ctg, skip, labels):
         a = [_ptr(root, np.uint32), _ptr(ctg, np.uint32), _ptr(skip, np.uint8), _ptr(labels, np.uint32)]
+        self._sync_producer(a)
         self._chk(self._L.gtsg_label_components(self._h, int(n), len(root), a[0][0], a[1][0], a[2][0],
                                                 a[3][0], self._same_side([x[1] for x in a])))
 
@@ -297,6 +330,27 @@ class ScaffolderGraph:
         if rc != 0:
             raise EngineError(err.value.decode())
         return cls(h)
+
+    @classmethod
+    def from_files_stepwise(cls, fasta, dist, min_ctg_len=200, astat_is_annotated=False,
+                            ismatepair=False, device=0):
+        """The reference's parser.h entry points one by one (what
+        gt_scaffolder_graph_new_from_file does, ref graph.c:346-419), with the
+        `ismatepair` switch of read_distances exposed.  Returns the graph and
+        (nof_contigs, nof_distances) as counted."""
+        L = lib()
+        L.gt_scaffolder_set_device(device)
+        err = C.create_string_buffer(512)
+        nc, nd = C.c_uint64(), C.c_uint64()
+        if L.gt_scaffolder_parser_count_contigs(fasta.encode(), min_ctg_len, C.byref(nc), err, 512):
+            raise EngineError(err.value.decode())
+        h = C.c_void_p(L.gt_scaffolder_graph_new(nc.value, 0))
+        g = cls(h)
+        if L.gt_scaffolder_parser_read_contigs(h, fasta.encode(), min_ctg_len, astat_is_annotated, err, 512) or \
+                L.gt_scaffolder_parser_count_distances(h, dist.encode(), C.byref(nd), err, 512) or \
+                L.gt_scaffolder_parser_read_distances(dist.encode(), h, ismatepair, err, 512):
+            raise EngineError(err.value.decode())
+        return g, (nc.value, nd.value)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -28,7 +28,8 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
                scaffold_median=20, scaffold_sigma=1.0, p_repeat=0.02, repeat_degree=24,
                p_bubble=0.02, p_chimeric=0.01, p_missing_astat=0.01, p_relist=0.01,
                p_link=0.97, contig_median=900, dist_range_small=False, scaffold_max=20000,
-               p_relist_flip=0.0, min_dist=-99, p_inversion=1.0, unique_pairs=False):
+               p_relist_flip=0.0, min_dist=-99, p_inversion=1.0, unique_pairs=False,
+               p_repeat_unmarked=0.0):
     """Returns a dict of tensors:
       seq_len[u64 as i64], astat[f32], copy_num[f32]          (per contig)
       root[i32], ctg[i32], dist[i64], std_dev[f32], num_pairs[i64], flags[u8]
@@ -77,6 +78,15 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
     is_rep = rand(n) < p_repeat
     copy_num = torch.where(is_rep, 2.0 + 6.0 * rand(n), copy_num)
     astat = torch.where(is_rep, -50.0 + 60.0 * rand(n), astat)
+    if p_repeat_unmarked > 0:
+        # collapsed repeats that look unique (A-statistic and copy number of a
+        # single-copy contig): mark_repeats leaves them alone, so their many
+        # links reach the filter's hub path and the component programs.  Drawn
+        # only when asked for: the random stream of the other workloads stays
+        # as it was.
+        quiet = is_rep & (rand(n) < p_repeat_unmarked)
+        copy_num = torch.where(quiet, 0.9 + 0.2 * rand(n), copy_num)
+        astat = torch.where(quiet, 30.0 + 100.0 * rand(n), astat)
     missing = rand(n) < p_missing_astat                  # not in the .astat file
     copy_num = torch.where(missing, torch.zeros_like(copy_num), copy_num)
     astat = torch.where(missing, torch.zeros_like(astat), astat)

@@ -18,7 +18,15 @@
     * record/edge flags: bit0 = sense, bit1 = same (ref graph.h:63-69);
     * `on_device` != 0: the array arguments are device pointers valid on the
       engine's GPU (e.g. torch tensors' data_ptr()), consumed on the engine's
-      stream; 0: host pointers, copied with hipMemcpyAsync.
+      stream; 0: host pointers, copied with hipMemcpyAsync;
+    * stream contract: every call enqueues on the engine's stream and returns
+      after that stream has drained, so results are visible to any stream
+      afterwards.  Device INPUTS must be complete before the call: either they
+      were produced on the engine's stream, or on the legacy null stream while
+      the engine runs on a stream it created itself (a blocking stream, ordered
+      with the null stream by HIP), or the producer stream was synchronised by
+      the caller.  To run on the null stream itself pass hipStreamLegacy
+      ((void *)1) to gtsg_create; NULL always means "create a stream".
 */
 #ifndef GT_SCAFFOLD_HIP_H
 #define GT_SCAFFOLD_HIP_H
@@ -63,6 +71,17 @@ int gtsg_build_from_records(GtsgEngine *e, uint64_t n_records,
                             const int64_t *dist, const float *std_dev,
                             const int64_t *num_pairs, const uint8_t *flags,
                             int on_device);
+/* the same with the reference's `ismatepair` argument of
+   gt_scaffolder_parser_read_distances (ref parser.c:297, :362): non-zero = a
+   record of a pair that already has its edges never alters them (the creating
+   record's estimate stays in both directions); 0 = gtsg_build_from_records.
+   Contig ids >= the number of contigs are rejected with GTSG_EINVAL before
+   anything is indexed with them. */
+int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t n_records,
+                               const uint32_t *root, const uint32_t *ctg,
+                               const int64_t *dist, const float *std_dev,
+                               const int64_t *num_pairs, const uint8_t *flags,
+                               int on_device, int ismatepair);
 
 /* A-statistics / copy numbers read from the .astat file, per vertex
    (ref algorithms.c:118-149, the file part of mark_repeats). */

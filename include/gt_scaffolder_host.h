@@ -46,6 +46,31 @@ int gt_scaffolder_graph_new_from_file(GtScaffolderGraph **graph_par,
                                       const char *dist_filename,
                                       bool astat_is_annotated, char *err,
                                       size_t errlen);
+/* The four steps gt_scaffolder_graph_new_from_file is made of, ref
+   src/gt_scaffolder_parser.h (same names and argument order):
+     count_contigs   parser.c:495  contigs of at least min_ctg_len in a FASTA file
+     read_contigs    parser.c:524  contigs longer than min_ctg_len become the
+                                   vertices of `graph` (from gt_scaffolder_graph_new)
+     count_distances parser.c:150  integrity check of the .de file, sorts the
+                                   vertices by header; *nof_distances = upper
+                                   bound of the edges (2 per valid record)
+     read_distances  parser.c:295  the records become edges: this is where the
+                                   graph moves to the GPU (one call per graph).
+                                   ismatepair = true: a record of a contig pair
+                                   that already has its edges never alters
+                                   them (parser.c:362) */
+int gt_scaffolder_parser_count_contigs(const char *filename, uint64_t min_ctg_len,
+                                       uint64_t *nof_contigs, char *err, size_t errlen);
+int gt_scaffolder_parser_read_contigs(GtScaffolderGraph *graph, const char *filename,
+                                      uint64_t min_ctg_len, bool astat_is_annotated,
+                                      char *err, size_t errlen);
+int gt_scaffolder_parser_count_distances(const GtScaffolderGraph *graph,
+                                         const char *file_name,
+                                         uint64_t *nof_distances, char *err,
+                                         size_t errlen);
+int gt_scaffolder_parser_read_distances(const char *filename,
+                                        GtScaffolderGraph *graph, bool ismatepair,
+                                        char *err, size_t errlen);
 /* ref gt_scaffolder_graph.c:247 */
 int gt_scaffolder_graph_print(const GtScaffolderGraph *g, const char *filename,
                               char *err, size_t errlen);

@@ -116,15 +116,17 @@ static bool get_vertex(const OraGraph *g, uint64_t *out, const char *header)
   return false;
 }
 
-/* ref parser.c:357-378 */
-void ora_graph_add_record(OraGraph *g, uint64_t root, uint64_t ctg,
-                          int64_t dist, float std_dev, uint64_t num_pairs,
-                          bool sense, bool same)
+/* ref parser.c:357-378; ismatepair is the argument of
+   gt_scaffolder_parser_read_distances (parser.c:297; new_from_file passes
+   false, graph.c:399) */
+void ora_graph_add_record_mp(OraGraph *g, uint64_t root, uint64_t ctg,
+                             int64_t dist, float std_dev, uint64_t num_pairs,
+                             bool sense, bool same, bool ismatepair)
 {
   uint64_t eid = find_edge(g, root, ctg);
   if (eid != UINT64_MAX) {
-    OraEdge *e = g->e + eid;   /* ismatepair is always false: graph.c:399 */
-    if (e->std_dev < std_dev) {    /* ref graph.c:219-235 alter_edge */
+    OraEdge *e = g->e + eid;
+    if (!ismatepair && e->std_dev < std_dev) {    /* parser.c:362, graph.c:219-235 alter_edge */
       e->dist = dist; e->std_dev = std_dev; e->num_pairs = num_pairs;
       e->sense = sense; e->same = same;
     }
@@ -135,16 +137,31 @@ void ora_graph_add_record(OraGraph *g, uint64_t root, uint64_t ctg,
   }
 }
 
+void ora_graph_add_record(OraGraph *g, uint64_t root, uint64_t ctg,
+                          int64_t dist, float std_dev, uint64_t num_pairs,
+                          bool sense, bool same)
+{
+  ora_graph_add_record_mp(g, root, ctg, dist, std_dev, num_pairs, sense, same, false);
+}
+
+void ora_graph_add_records_mp(OraGraph *g, uint64_t n, const uint32_t *root,
+                              const uint32_t *ctg, const int64_t *dist,
+                              const float *std_dev, const uint64_t *num_pairs,
+                              const uint8_t *flags, bool ismatepair)
+{
+  uint64_t k;
+  for (k = 0; k < n; k++)
+    ora_graph_add_record_mp(g, root[k], ctg[k], dist[k], std_dev[k],
+                            num_pairs ? num_pairs[k] : 0,
+                            (flags[k] & 1) != 0, (flags[k] & 2) != 0, ismatepair);
+}
+
 void ora_graph_add_records(OraGraph *g, uint64_t n, const uint32_t *root,
                            const uint32_t *ctg, const int64_t *dist,
                            const float *std_dev, const uint64_t *num_pairs,
                            const uint8_t *flags)
 {
-  uint64_t k;
-  for (k = 0; k < n; k++)
-    ora_graph_add_record(g, root[k], ctg[k], dist[k], std_dev[k],
-                         num_pairs ? num_pairs[k] : 0,
-                         (flags[k] & 1) != 0, (flags[k] & 2) != 0);
+  ora_graph_add_records_mp(g, n, root, ctg, dist, std_dev, num_pairs, flags, false);
 }
 
 /* ------------------------------------------------------------------ */
@@ -353,8 +370,8 @@ static int count_distances(const OraGraph *g, const char *file_name,
 }
 
 /* ref parser.c:295-394 */
-static int read_distances(const char *filename, OraGraph *g, char *err,
-                          size_t errlen)
+static int read_distances(const char *filename, OraGraph *g, bool ismatepair,
+                          char *err, size_t errlen)
 {
   FILE *file = fopen(filename, "rb");
   char line[ORA_BUFSIZE + 1], ctg_header[ORA_BUFSIZE + 1], *field;
@@ -377,8 +394,8 @@ static int read_distances(const char *filename, OraGraph *g, char *err,
         bool same = ctg_header[len - 1] == '+';
         ctg_header[len - 1] = '\0';
         if (get_vertex(g, &ctg, ctg_header))
-          ora_graph_add_record(g, root, ctg, dist, std_dev,
-                               (uint64_t)num_pairs, sense, same);
+          ora_graph_add_record_mp(g, root, ctg, dist, std_dev,
+                                  (uint64_t)num_pairs, sense, same, ismatepair);
       } else if (*field == ';')
         sense = !sense;
       field = strtok(NULL, " ");
@@ -391,6 +408,17 @@ static int read_distances(const char *filename, OraGraph *g, char *err,
 int ora_graph_new_from_file(OraGraph **out, const char *ctg_filename,
                             uint64_t min_ctg_len, const char *dist_filename,
                             bool astat_is_annotated, char *err, size_t errlen)
+{
+  return ora_graph_new_from_file_mp(out, ctg_filename, min_ctg_len, dist_filename,
+                                    astat_is_annotated, false, err, errlen);
+}
+
+/* the same five steps (graph.c:346-419) with read_distances' ismatepair
+   argument chosen by the caller (graph.c:399 passes false) */
+int ora_graph_new_from_file_mp(OraGraph **out, const char *ctg_filename,
+                               uint64_t min_ctg_len, const char *dist_filename,
+                               bool astat_is_annotated, bool ismatepair,
+                               char *err, size_t errlen)
 {
   FastaData d;
   OraGraph *g = NULL;
@@ -410,7 +438,7 @@ int ora_graph_new_from_file(OraGraph **out, const char *ctg_filename,
     qsort(g->v, g->nv, sizeof *g->v, vertex_cmp);
     had_err = count_distances(g, dist_filename, &nof_distances, err, errlen);
   }
-  if (!had_err) had_err = read_distances(dist_filename, g, err, errlen);
+  if (!had_err) had_err = read_distances(dist_filename, g, ismatepair, err, errlen);
   if (had_err) { ora_graph_delete(g); g = NULL; }
   *out = g;
   return had_err;

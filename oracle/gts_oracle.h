@@ -91,6 +91,15 @@ void ora_graph_add_edge(OraGraph *g, uint64_t vstart, uint64_t vend,
 void ora_graph_add_record(OraGraph *g, uint64_t root, uint64_t ctg,
                           int64_t dist, float std_dev, uint64_t num_pairs,
                           bool sense, bool same);
+/* the same with read_distances' ismatepair argument (parser.c:297, :362:
+   true = an existing edge is never altered) */
+void ora_graph_add_record_mp(OraGraph *g, uint64_t root, uint64_t ctg,
+                             int64_t dist, float std_dev, uint64_t num_pairs,
+                             bool sense, bool same, bool ismatepair);
+void ora_graph_add_records_mp(OraGraph *g, uint64_t n, const uint32_t *root,
+                              const uint32_t *ctg, const int64_t *dist,
+                              const float *std_dev, const uint64_t *num_pairs,
+                              const uint8_t *flags, bool ismatepair);
 /* bulk form of the above for synthetic inputs; flags bit0 = sense, bit1 = same */
 void ora_graph_add_records(OraGraph *g, uint64_t n, const uint32_t *root,
                            const uint32_t *ctg, const int64_t *dist,
@@ -100,6 +109,10 @@ void ora_graph_add_records(OraGraph *g, uint64_t n, const uint32_t *root,
 int ora_graph_new_from_file(OraGraph **out, const char *ctg_filename,
                             uint64_t min_ctg_len, const char *dist_filename,
                             bool astat_is_annotated, char *err, size_t errlen);
+int ora_graph_new_from_file_mp(OraGraph **out, const char *ctg_filename,
+                               uint64_t min_ctg_len, const char *dist_filename,
+                               bool astat_is_annotated, bool ismatepair,
+                               char *err, size_t errlen);
 /* gt_scaffolder_graph.c:421 */
 int ora_graph_test(uint64_t max_v, uint64_t max_e, bool init_v, uint64_t nv,
                    bool init_e, uint64_t ne, const char *dot_out);

@@ -36,9 +36,13 @@ def lib():
         L.ora_graph_add_edge.argtypes = [vp, u64, u64, i64, f32, u64, C.c_bool, C.c_bool]
         L.ora_graph_add_record.argtypes = [vp, u64, u64, i64, f32, u64, C.c_bool, C.c_bool]
         L.ora_graph_add_records.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
+        L.ora_graph_add_records_mp.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, C.c_bool]
         L.ora_graph_new_from_file.argtypes = [C.POINTER(vp), C.c_char_p, u64, C.c_char_p,
                                               C.c_bool, C.c_char_p, C.c_size_t]
         L.ora_graph_new_from_file.restype = ci
+        L.ora_graph_new_from_file_mp.argtypes = [C.POINTER(vp), C.c_char_p, u64, C.c_char_p,
+                                                 C.c_bool, C.c_bool, C.c_char_p, C.c_size_t]
+        L.ora_graph_new_from_file_mp.restype = ci
         L.ora_graph_test.argtypes = [u64, u64, C.c_bool, u64, C.c_bool, u64, C.c_char_p]
         L.ora_graph_test.restype = ci
         L.ora_parser_read_distances_test.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
@@ -92,19 +96,19 @@ class OracleGraph:
 
     # ---- constructors -------------------------------------------------
     @classmethod
-    def from_files(cls, fasta, dist, min_ctg_len=200, astat_is_annotated=False):
+    def from_files(cls, fasta, dist, min_ctg_len=200, astat_is_annotated=False, ismatepair=False):
         L = lib()
         h = C.c_void_p()
         err = C.create_string_buffer(512)
-        rc = L.ora_graph_new_from_file(C.byref(h), fasta.encode(), min_ctg_len, dist.encode(),
-                                       astat_is_annotated, err, 512)
+        rc = L.ora_graph_new_from_file_mp(C.byref(h), fasta.encode(), min_ctg_len, dist.encode(),
+                                          astat_is_annotated, ismatepair, err, 512)
         if rc != 0:
             raise RuntimeError(err.value.decode())
         return cls(h)
 
     @classmethod
     def from_records(cls, seq_len, astat, copy_num, root, ctg, dist, std_dev, num_pairs, flags,
-                     headers=None):
+                     headers=None, ismatepair=False):
         L = lib()
         n = len(seq_len)
         h = C.c_void_p(L.ora_graph_new(max(n, 1), max(2 * len(root), 1)))
@@ -119,8 +123,8 @@ class OracleGraph:
         std_dev = np.ascontiguousarray(std_dev, dtype=np.float32)
         num_pairs = np.ascontiguousarray(num_pairs, dtype=np.uint64)
         flags = np.ascontiguousarray(flags, dtype=np.uint8)
-        L.ora_graph_add_records(h, len(root), _p(root), _p(ctg), _p(dist), _p(std_dev),
-                                _p(num_pairs), _p(flags))
+        L.ora_graph_add_records_mp(h, len(root), _p(root), _p(ctg), _p(dist), _p(std_dev),
+                                   _p(num_pairs), _p(flags), bool(ismatepair))
         return g
 
     def __del__(self):

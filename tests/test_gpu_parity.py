@@ -381,7 +381,7 @@ def test_full_size_properties():
     g["num_pairs"] = g["num_pairs"].to(torch.int64)
     digests = []
     for opts in (dict(), dict(defer_min_contigs=0, class_streams=1), dict(defer_min_contigs=96, mixed_task_limit=0)):
-        eng = pkg.engine.Engine(0, torch.cuda.current_stream().cuda_stream)
+        eng = pkg.engine.Engine(0)
         for k, v in opts.items():
             eng.set_option(k, v)
         bench.run_step(eng, g)

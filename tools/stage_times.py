@@ -6,7 +6,7 @@ import bench
 pkg = load_package()
 g = bench.make_inputs(pkg, 10_000_000, 1234, "cuda:0", bench.WORKLOAD["gen"])
 g["num_pairs"] = g["num_pairs"].to(torch.int64)
-eng = pkg.engine.Engine(0, torch.cuda.current_stream().cuda_stream)
+eng = pkg.engine.Engine(0)
 eng.set_option("profile", 1)
 C = bench.CUTS
 for it in range(3):
