@@ -18,9 +18,25 @@ import math
 import torch
 
 
-def _lognormal_int(gen, n, median, sigma, lo, hi, device):
-    x = torch.empty(n, device=device, dtype=torch.float32).normal_(0.0, 1.0, generator=gen)
-    v = (math.log(median) + sigma * x).exp().round().clamp_(lo, hi)
+def _normal(gen, n, device, portable):
+    """Standard normal draws.  portable: the sum of twelve uniforms minus six
+    (Irwin-Hall), float32 additions only -- IEEE-exact operations, so every host
+    draws the same values; the library's normal_() goes through log / cos
+    implementations (MKL, libm) whose last bit depends on the CPU."""
+    if not portable:
+        return torch.empty(n, device=device, dtype=torch.float32).normal_(0.0, 1.0, generator=gen)
+    acc = torch.rand(n, device=device, generator=gen)
+    for _ in range(11):
+        acc = acc + torch.rand(n, device=device, generator=gen)
+    return acc - 6.0
+
+
+def _lognormal_int(gen, n, median, sigma, lo, hi, device, portable=False):
+    x = _normal(gen, n, device, portable)
+    if portable:   # exp in double, rounded to an integer: one ulp of the library cannot show
+        v = (math.log(median) + sigma * x.double()).exp().round().clamp_(lo, hi)
+    else:
+        v = (math.log(median) + sigma * x).exp().round().clamp_(lo, hi)
     return v.to(torch.int64)
 
 
@@ -29,11 +45,16 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
                p_bubble=0.02, p_chimeric=0.01, p_missing_astat=0.01, p_relist=0.01,
                p_link=0.97, contig_median=900, dist_range_small=False, scaffold_max=20000,
                p_relist_flip=0.0, min_dist=-99, p_inversion=1.0, unique_pairs=False,
-               p_repeat_unmarked=0.0):
+               p_repeat_unmarked=0.0, portable=False):
     """Returns a dict of tensors:
       seq_len[u64 as i64], astat[f32], copy_num[f32]          (per contig)
       root[i32], ctg[i32], dist[i64], std_dev[f32], num_pairs[i64], flags[u8]
-    flags bit0 = sense, bit1 = same (ref gt_scaffolder_graph.h:63-69)."""
+    flags bit0 = sense, bit1 = same (ref gt_scaffolder_graph.h:63-69).
+
+    portable=True draws the same graph on every host (CPU device): no
+    transcendental function reaches an output bit and the file-order sort is
+    stable.  It is a different random stream than portable=False; the
+    full-size oracle fixture (tools/make_full_size_digest.py) uses it."""
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
@@ -47,16 +68,16 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
 
     # --- layout: positions 0..n-1 on concatenated true scaffolds -------
     n_sc = max(4, int(n / scaffold_median * 2.5) + 8)
-    sc_len = _lognormal_int(gen, n_sc, scaffold_median, scaffold_sigma, 1, scaffold_max, dev)
+    sc_len = _lognormal_int(gen, n_sc, scaffold_median, scaffold_sigma, 1, scaffold_max, dev, portable)
     sc_end = torch.cumsum(sc_len, 0)
     while int(sc_end[-1]) < n:  # pathological draw: extend
-        more = _lognormal_int(gen, n_sc, scaffold_median, scaffold_sigma, 1, scaffold_max, dev)
+        more = _lognormal_int(gen, n_sc, scaffold_median, scaffold_sigma, 1, scaffold_max, dev, portable)
         sc_end = torch.cat([sc_end, sc_end[-1] + torch.cumsum(more, 0)])
     pos = torch.arange(n, device=dev)
     sc_id = torch.searchsorted(sc_end, pos, right=True)
     vid = torch.randperm(n, device=dev, generator=gen)  # position -> vertex id
 
-    clen = _lognormal_int(gen, n, contig_median, 0.8, 201, 60000, dev)
+    clen = _lognormal_int(gen, n, contig_median, 0.8, 201, 60000, dev, portable)
     orient = randint(0, 2, n).to(torch.bool)            # True = reverse strand
     gap = randint(-50, 300, n)
     # bubbles: position b and b+1 are two alleles of one locus
@@ -70,7 +91,7 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
     cs = torch.cumsum(step, 0) - step                    # global start coordinate
     # (coordinates are only compared inside one scaffold)
 
-    copy_num = (1.0 + 0.08 * torch.empty(n, device=dev).normal_(0, 1, generator=gen)).clamp_(0.6, 1.4)
+    copy_num = (1.0 + 0.08 * _normal(gen, n, dev, portable)).clamp_(0.6, 1.4)
     allele = bub.clone()
     allele[1:] |= bub[:-1]
     copy_num = torch.where(allele, 0.5 + 0.05 * (rand(n) - 0.5), copy_num)
@@ -134,8 +155,11 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
     cd = randint(-90, reach, ca.numel())
     # repeat links
     rep_pos = pos[is_rep]
-    rdeg = (torch.empty(rep_pos.numel(), device=dev).exponential_(1.0, generator=gen)
-            * repeat_degree).long().clamp_(1, max(1, n - 1))
+    if portable:
+        expo = -torch.log1p(-rand(rep_pos.numel()).double())
+    else:
+        expo = torch.empty(rep_pos.numel(), device=dev).exponential_(1.0, generator=gen)
+    rdeg = (expo * repeat_degree).long().clamp_(1, max(1, n - 1))
     ra = torch.repeat_interleave(rep_pos, rdeg)
     rb = randint(0, n, ra.numel())
     keep = ra != rb
@@ -164,9 +188,13 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
 
     npairs = randint(5, 600, m)
     sigma_lib = 60.0
-    sd = (sigma_lib / npairs.float().sqrt() * (0.8 + 0.4 * rand(m)))
-    sd = (sd * 10).round() / 10                           # .de files carry %.1f
-    noise = (torch.empty(m, device=dev).normal_(0, 1, generator=gen) * sd).round().long()
+    if portable:   # the square root in double; only its value rounded to 0.1 is kept
+        sd = (sigma_lib / npairs.double().sqrt() * (0.8 + 0.4 * rand(m)).double())
+        sd = ((sd * 10).round() / 10).float()
+    else:
+        sd = (sigma_lib / npairs.float().sqrt() * (0.8 + 0.4 * rand(m)))
+        sd = (sd * 10).round() / 10                       # .de files carry %.1f
+    noise = (_normal(gen, m, dev, portable) * sd).round().long()
     dist = (D + noise).clamp_(min=min_dist)
     if dist_range_small:                                  # provoke ties in walks
         dist = dist.clamp_(-99, 99)
@@ -194,7 +222,7 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
     line_of = torch.randperm(n, device=dev, generator=gen)
     key = line_of[root].to(torch.int64) * 2 + (~rsense).to(torch.int64)
     key = key * (1 << 22) + randint(0, 1 << 22, key.numel())
-    order = torch.argsort(key)
+    order = torch.argsort(key, stable=True) if portable else torch.argsort(key)
     flags = (rsense.to(torch.uint8) | (rsame.to(torch.uint8) << 1))
 
     out = dict(
