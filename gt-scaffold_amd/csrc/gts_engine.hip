@@ -1857,6 +1857,10 @@ static int run_components(GtsgEngine *e, int mode)
                                                         : "components_removecycles";
       uint32_t first = 0;
       const uint32_t nk = e->lds_components ? GTS_NKLASS : 0;
+      /* profile: the span of the overlapped class launches, fork -> last join,
+         as one entry next to the per-launch entries */
+      hipEvent_t span_a = nullptr, span_b = nullptr;
+      if (e->profile) { span_a = get_event(e); span_b = get_event(e); hipEventRecord(span_a, e->st); }
       HIPCHK(hipEventRecord(e->ev_fork, e->st));
       if (kcount[nk]) {
         LAUNCH(kname, k_components, kcount[nk], GTS_WAVE, C, order, first, kcount[nk], mode);
@@ -1885,6 +1889,13 @@ static int run_components(GtsgEngine *e, int mode)
          side stream that shares its hardware queue with this stream */
       for (uint32_t k = 0; k < nk; ++k)
         if (kcount[k]) HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
+      if (e->profile) {
+        hipEventRecord(span_b, e->st);
+        e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "span_components_makescaffold"
+                                                            : "span_components_removecycles", span_a, span_b});
+      }
+      hipEvent_t rounds_a = nullptr, rounds_b = nullptr;
+      if (e->profile) { rounds_a = get_event(e); rounds_b = get_event(e); hipEventRecord(rounds_a, e->st); }
       /* deferred walks (gts_component.hpp, try_defer): rounds of one workgroup
          per pending walk, grouped by LDS class, and an in-order select pass */
       uint64_t ntasks = 0, walks_run = 0, task_launches = 0;
@@ -1934,6 +1945,10 @@ static int run_components(GtsgEngine *e, int mode)
           HIPCHK(hipMemcpyAsync(pend, e->d_scalars + GTS_S_TQCNT, sizeof pend, hipMemcpyDeviceToHost, e->st));
           if ((rc = sync_stream(e))) return rc;
         }
+      }
+      if (e->profile) {
+        hipEventRecord(rounds_b, e->st);
+        e->pending.push_back({"span_walk_rounds", rounds_a, rounds_b});
       }
       e->stats["walk_task_rounds"] = rounds;
       e->stats["walk_task_launches"] = (int64_t)task_launches;
@@ -2170,6 +2185,14 @@ void gtsg_reset_kernel_times(GtsgEngine *e) { if (e) { collect_times(e); e->ktim
 int64_t gtsg_get_stat(const GtsgEngine *e, const char *name)
 {
   if (!e || !name) return -1;
+  /* HBM held by the engine: the graph and contig arrays, and the workspace
+     (grown to the largest stage so far) */
+  if (!strcmp(name, "bytes_workspace")) return (int64_t)e->pool_cap;
+  if (!strcmp(name, "bytes_graph")) {
+    size_t b = 0;
+    for (auto &kv : e->alloc_bytes) b += kv.second;
+    return (int64_t)b;
+  }
   auto it = e->stats.find(name);
   return it == e->stats.end() ? -1 : it->second;
 }

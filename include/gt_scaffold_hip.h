@@ -170,7 +170,9 @@ void gtsg_reset_kernel_times(GtsgEngine *e);
 /* counters of the last calls: "filter_rounds_p", "filter_rounds_i",
    "components", "max_component", "slots", "compact_edges", "hubs",
    "walk_retries", "fast_walks", "slow_walks", "clean_components",
-   "deferred_components", "walk_tasks", "walk_task_rounds", "walk_task_runs" */
+   "deferred_components", "walk_tasks", "walk_task_rounds", "walk_task_runs";
+   "bytes_graph" (HBM held by the contig and CSR arrays) and "bytes_workspace"
+   (the scratch region, grown to the largest stage run so far) */
 int64_t gtsg_get_stat(const GtsgEngine *e, const char *name);
 
 #ifdef __cplusplus

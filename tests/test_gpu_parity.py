@@ -418,3 +418,98 @@ def test_full_size_properties():
     eng, og = run_pipeline(gs, pcutoff=bench.CUTS["pcutoff"], cncutoff=bench.CUTS["cncutoff"],
                            ocutoff=bench.CUTS["ocutoff"])
     assert eng.digest() == pkg.engine.state_digest_host(og.vertex_states(), og.edge_states())
+
+
+def test_full_size_against_oracle_digest():
+    """BASELINE configs[2] against the oracle at FULL size: the 10 M-contig /
+    100 M-edge workload is regenerated on this host with the generator's
+    portable mode, checked against the input checksum recorded in
+    tests/golden/full_size_digest.json (written in the build container by
+    tools/make_full_size_digest.py, where the CPU oracle ran on the whole graph
+    for ~45 min) and the engine's state digests are compared with the oracle's
+    after the filter and after makescaffold."""
+    import json
+    import os
+    import sys
+    import torch
+    import bench
+    from helpers import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_full_size_digest as tool
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "full_size_digest.json")))
+    assert want["gen"] == bench.WORKLOADS["10M"]["gen"] and want["cuts"] == bench.CUTS
+    g = tool.generate(pkg, want["n_contigs"], want["seed"], want["gen"])
+    assert len(g["root"]) == want["n_records"]
+    assert tool.input_checksum(g) == want["input_sha256"], "this host draws other inputs than the build container"
+    eng = pkg.engine.Engine(0)
+    eng.set_contigs(g["seq_len"].astype(np.int64), g["astat"], g["copy_num"])
+    eng.build_from_records(g["root"], g["ctg"], g["dist"], g["std_dev"], g["num_pairs"].astype(np.int64),
+                           g["flags"])
+    del g
+    assert eng.ne == want["n_edges"]
+    C = want["cuts"]
+    eng.mark_repeats(True, C["copy_num_cutoff"], C["astat_cutoff"])
+    eng.filter(C["pcutoff"], C["cncutoff"], C["ocutoff"])
+    assert eng.digest() == (want["after_filter"]["vertex_digest"], want["after_filter"]["edge_digest"])
+    assert np.bincount(eng.vertex_states(), minlength=8).tolist() == want["after_filter"]["vertex_state_counts"]
+    eng.makescaffold()
+    vs, es = eng.vertex_states(), eng.edge_states()
+    assert np.bincount(vs, minlength=8).tolist() == want["after_makescaffold"]["vertex_state_counts"]
+    assert np.bincount(es, minlength=8).tolist() == want["after_makescaffold"]["edge_state_counts"]
+    assert eng.digest() == (want["after_makescaffold"]["vertex_digest"],
+                            want["after_makescaffold"]["edge_digest"])
+
+
+def test_50M_contig_repeat_rich_graph():
+    """BASELINE configs[4] on one GPU: 50 M contigs / ~500 M edges, repeat-rich
+    (1.5 % repeats with 100 links on average, a few of which look unique and
+    reach the filter's hub path and the global-memory component programs).  No
+    oracle at this size (the reference's per-walk O(|V|) map alone,
+    algorithms.c:648-650, is 200 MB per walk): structural invariants of the
+    built graph, state invariants, the same digest from two parallel
+    decompositions, and the HBM the engine holds."""
+    import torch
+    import bench
+    W = bench.WORKLOADS["50M"]
+    n = W["n_contigs"]
+    g = bench.make_inputs(pkg, n, 4321, "cuda:0", W["gen"])
+    g["num_pairs"] = g["num_pairs"].to(torch.int64)
+    torch.cuda.empty_cache()
+    eng = pkg.engine.Engine(0)
+    bench.run_step(eng, g)
+    m = eng.ne
+    assert 450_000_000 < m < 600_000_000, m
+    assert eng.stat("hubs") > 100_000                      # vertices above hub_degree
+    assert eng.stat("components_global_mem") > 0           # components too large for LDS
+    assert eng.stat("max_component") >= 4096
+    d0 = eng.digest()
+    held = eng.stat("bytes_graph") + eng.stat("bytes_workspace")
+    assert eng.stat("bytes_graph") >= 34 * m and held < 250 * (1 << 30), held
+    print("50M graph: %d edges, %.1f GB graph + %.1f GB workspace in HBM, %d components, largest %d"
+          % (m, eng.stat("bytes_graph") / 1e9, eng.stat("bytes_workspace") / 1e9,
+             eng.stat("components"), eng.stat("max_component")))
+    # built graph: twins, ids in range, one edge pair per contig pair
+    e = eng.edges()
+    assert np.array_equal(e["start"][0:m:2], e["end"][1:m:2])
+    assert np.array_equal(e["end"][0:m:2], e["start"][1:m:2])
+    assert np.array_equal(e["flags"][0:m:2] & 2, e["flags"][1:m:2] & 2)
+    assert int(e["start"].max()) < n and int(e["end"].max()) < n
+    key = torch.from_numpy(np.minimum(e["start"][0:m:2], e["end"][0:m:2]).astype(np.int64)).cuda() * n + \
+        torch.from_numpy(np.maximum(e["start"][0:m:2], e["end"][0:m:2]).astype(np.int64)).cuda()
+    assert torch.unique(key).numel() == key.numel()
+    del key
+    # states: an unmarked edge has unmarked ends; SCAFFOLD edges join SCAFFOLD contigs, in twins
+    vs, es = eng.vertex_states(), eng.edge_states()
+    marked_v = np.zeros(8, bool); marked_v[[1, 3, 7]] = True
+    marked_e = np.zeros(8, bool); marked_e[[1, 2, 3, 7]] = True
+    assert not (~marked_e[es] & (marked_v[vs[e["start"]]] | marked_v[vs[e["end"]]])).any()
+    sc = es == 6
+    assert sc.any() and (vs[e["start"][sc]] == 6).all() and (vs[e["end"][sc]] == 6).all()
+    assert np.array_equal(es[0:m:2] == 6, es[1:m:2] == 6)
+    assert (es == 1).any() and (es == 2).any() and (es == 3).any()
+    del e, vs, es, sc
+    # another decomposition of the same work: walks in place, one stream
+    eng.set_option("defer_min_contigs", 0)
+    eng.set_option("class_streams", 1)
+    bench.run_step(eng, g)
+    assert eng.digest() == d0
