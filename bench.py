@@ -41,13 +41,18 @@ WORKLOAD = dict(name="synthetic 10M-contig / 100M-edge scaffold graph",
 # BASELINE configs[4]: the human-scale, repeat-rich graph (--workload 50M; one
 # GPU holds it: the CSR, the sort buffers and all scratch stay in HBM).  1.5 % of
 # the contigs are repeats with 100 links on average (exponential, up to ~1500),
-# and one repeat in ~6700 looks unique to mark_repeats: its links reach the
-# filter's hub path and tie hundreds of scaffolds into one component, which
-# runs from global memory.
+# and one repeat in ~33000 (about 22 contigs) looks unique to mark_repeats: its
+# links reach the filter's hub path and tie hundreds of scaffolds into one
+# component, which runs from global memory on one wavefront.  The reference's
+# semantics make such a component quadratic (every best walk that ends in the
+# hub revives an arc out of it, algorithms.c:842-845, so later walks fan out
+# into the scaffolds marked before): at 1.5e-4 (112 hubs, components of up to
+# 55 000 contigs) two components alone take 3.2 s of a 3.4 s step
+# (profiles/r02d_bench_50M_112hubs.json).
 WORKLOAD_50M = dict(name="synthetic 50M-contig / 500M-edge repeat-rich scaffold graph",
                     n_contigs=50_000_000,
                     gen=dict(links_per_side=4, p_repeat=0.015, repeat_degree=100, p_inversion=0.0,
-                             unique_pairs=True, p_repeat_unmarked=1.5e-4))
+                             unique_pairs=True, p_repeat_unmarked=3e-5))
 WORKLOADS = {"10M": WORKLOAD, "50M": WORKLOAD_50M}
 CUTS = dict(copy_num_cutoff=0.3, astat_cutoff=20.0, pcutoff=0.01, cncutoff=1.5, ocutoff=400)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)

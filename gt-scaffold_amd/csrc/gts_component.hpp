@@ -1410,7 +1410,19 @@ struct GtsComponent {
   }
 
   /* create_walk on a clean component: one sweep over the precomputed order
-     (see orient / peel and create_walk_fast for why the result is the reference's) */
+     (see orient / peel and create_walk_fast for why the result is the reference's).
+     The reached vertices are taken in the order of their topological position
+     (upwards on the forward sheet, downwards on the mirror); every arc points
+     onwards in that order, so a vertex is final when its turn comes.
+     Two ways to find the next reached vertex:
+       * LDS-resident components (below 4096 contigs): the order is read a
+         chunk of 64 positions at a time and the lanes look up the labels;
+       * components in global memory (any size): a bitmap over the positions
+         (bit tpos[v] set when v gets its first label), scanned 64 words = 2048
+         positions per load.  A walk then costs its reachable set, not the
+         component: the 3000 walks of a 34 000-contig component (a scaffold each,
+         tied together by one unmarked hub) swept 34 000 / 64 chunks of dependent
+         gathers each before. */
   GTS_HD bool create_walk_clean(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t lane = W::lane();
@@ -1434,99 +1446,132 @@ struct GtsComponent {
     if (has_s && has_a) { W::count(C.why + 0); return false; }
     if (!has_s && !has_a) return true;
     const bool forward = has_s == ((W::uni((uint32_t)M.gorient[start]) & 3u) == 2);
-    uint32_t nr = 0, pending = 1, best_t = GTS_NONE;
+    uint32_t nr = 0, pending = 0, best_t = GTS_NONE;
     uint64_t best_len = 0;
     bool inexact = false, bad = false;
     M.plen[start] = (len_t)M.cseq[start];
     depth[start] = 0;
     M.nd[start] = 0;
     W::fence();
-    int64_t pos = (int64_t)W::uni(M.tpos[start]);
-    while (pending > 0 && !bad && pos >= 0 && pos < (int64_t)nv) {
-      /* next reached vertices in sweep order */
-      const int64_t mypos = forward ? pos + (int64_t)lane : pos - (int64_t)lane;
-      uint32_t cv = 0;
-      const bool inrange = mypos >= 0 && mypos < (int64_t)nv;
-      if (inrange) cv = M.topo[(uint32_t)mypos];
-      /* a vertex handled in this chunk may label a later vertex of the same
-         chunk: look again after every vertex */
-      uint32_t next_lane = 0;
-      while (!bad) {
-        bool reached = false;
-        if (inrange && lane >= next_lane)
-          reached = cv == start ? next_lane == 0 && mypos == (int64_t)W::uni(M.tpos[start])
-                                : M.distmap[cv] != GTS_DIST_UNSET;
-        const uint64_t rm = W::ballot(reached);
-        if (!rm) break;
-        const uint32_t l = W::ctz(rm);
-        next_lane = l + 1;
-        const uint32_t u = W::bcast(cv, l);
-        --pending;
-        const bool du = ((W::uni((uint32_t)M.gorient[u]) & 3u) == 2) == forward;
-        const nd_t ndu = uni_t(M.nd[u]);   /* nd[start] = 0 */
-        const len_t plu = uni_t(M.plen[u]);
-        const uint32_t dpu = W::uni(depth[u]);   /* depth[start] = 0 */
-        const uint32_t eb = eoff(u), ee = eoff(u + 1);
-        bool us = false, ua = false;
-        for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
-          const uint32_t ce = base + lane;
-          bool live = false, sense = false, arc = false, tie = false, fresh = false;
-          uint32_t v = 0;
-          if (ce < ee) {
-            live = !gts_edge_is_marked(M.cstate[ce]);
-            sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
-            arc = live && sense == du;
-            if (arc) {
-              v = M.cend[ce];
-              const nd_t w = (nd_t)M.cdist[ce];
-              const float cand = (float)(ndu + w);
-              const float old = M.distmap[v];
-              if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
-              if (old == GTS_DIST_UNSET || old > cand) {
-                fresh = old == GTS_DIST_UNSET;
-                M.distmap[v] = cand;
-                M.edgemap[v] = ce;
-                M.par[v] = u;
-                M.nd[v] = u == start ? w : (nd_t)cand;
-                M.plen[v] = (len_t)(plu + (len_t)M.cseq[v]);
-                depth[v] = dpu + 1;
-              } else if (old == cand)
-                tie = true;
-            }
+    const uint32_t spos = W::uni(M.tpos[start]);
+    /* sparse sweep: position bitmap in st_cur (zeroed by makescaffold, left
+       zero by every walk; nothing else writes it while the component is clean) */
+    uint32_t *pbits = nullptr;
+    uint32_t nwords = 0;
+    if constexpr (!LDS) { pbits = (uint32_t *)&M.st_cur[0]; nwords = (nv + 31) / 32; }
+
+    /* relaxes the out-arcs of u (its label is final) */
+    auto process = [&](uint32_t u) {
+      const bool du = ((W::uni((uint32_t)M.gorient[u]) & 3u) == 2) == forward;
+      const nd_t ndu = uni_t(M.nd[u]);   /* nd[start] = 0 */
+      const len_t plu = uni_t(M.plen[u]);
+      const uint32_t dpu = W::uni(depth[u]);   /* depth[start] = 0 */
+      const uint32_t eb = eoff(u), ee = eoff(u + 1);
+      bool us = false, ua = false;
+      for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
+        const uint32_t ce = base + lane;
+        bool live = false, sense = false, arc = false, tie = false, fresh = false;
+        uint32_t v = 0;
+        if (ce < ee) {
+          live = !gts_edge_is_marked(M.cstate[ce]);
+          sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+          arc = live && sense == du;
+          if (arc) {
+            v = M.cend[ce];
+            const nd_t w = (nd_t)M.cdist[ce];
+            const float cand = (float)(ndu + w);
+            const float old = M.distmap[v];
+            if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
+            if (old == GTS_DIST_UNSET || old > cand) {
+              fresh = old == GTS_DIST_UNSET;
+              M.distmap[v] = cand;
+              M.edgemap[v] = ce;
+              M.par[v] = u;
+              M.nd[v] = u == start ? w : (nd_t)cand;
+              M.plen[v] = (len_t)(plu + (len_t)M.cseq[v]);
+              depth[v] = dpu + 1;
+            } else if (old == cand)
+              tie = true;
           }
-          us |= W::ballot(live && sense) != 0;
-          ua |= W::ballot(live && !sense) != 0;
-          const uint64_t fm = W::ballot(fresh);
-          if (fresh) R[nr + W::popc_below(fm, lane)] = v;
-          nr += W::popc(fm);
-          pending += W::popc(fm);
-          uint64_t tm = W::ballot(tie);
-          /* (inexact is kept per lane; the wave is asked only where it matters) */
-          if (tm && W::ballot(inexact)) { W::count(C.why + 5); bad = true; break; }
-          while (tm) {
-            const uint32_t tl = W::ctz(tm);
-            tm &= tm - 1;
-            const uint32_t tv = W::bcast(v, tl), tce = W::bcast(ce, tl);
-            const uint32_t up = W::uni(M.par[tv]);
-            if (pushed_after(up, u, start)) {
-              M.edgemap[tv] = tce;
-              M.par[tv] = u;
-              M.plen[tv] = (len_t)(plu + (len_t)uni_t(M.cseq[tv]));
-              depth[tv] = dpu + 1;
-              W::fence();
-            }
-          }
-          W::fence();
         }
-        if (!bad && u != start && !(us && ua)) {
-          if (plu > best_len) { best_len = plu; best_t = u; }
-          else if (plu == best_len && best_t != GTS_NONE) {
-            if (W::ballot(inexact)) { W::count(C.why + 7); bad = true; }
-            else if (pushed_after(u, best_t, start)) best_t = u;
+        us |= W::ballot(live && sense) != 0;
+        ua |= W::ballot(live && !sense) != 0;
+        const uint64_t fm = W::ballot(fresh);
+        if (fresh) {
+          R[nr + W::popc_below(fm, lane)] = v;
+          if constexpr (!LDS) { const uint32_t tp = M.tpos[v]; W::or_bits(pbits + (tp >> 5), 1u << (tp & 31)); }
+        }
+        nr += W::popc(fm);
+        pending += W::popc(fm);
+        uint64_t tm = W::ballot(tie);
+        /* (inexact is kept per lane; the wave is asked only where it matters) */
+        if (tm && W::ballot(inexact)) { W::count(C.why + 5); bad = true; break; }
+        while (tm) {
+          const uint32_t tl = W::ctz(tm);
+          tm &= tm - 1;
+          const uint32_t tv = W::bcast(v, tl), tce = W::bcast(ce, tl);
+          const uint32_t up = W::uni(M.par[tv]);
+          if (pushed_after(up, u, start)) {
+            M.edgemap[tv] = tce;
+            M.par[tv] = u;
+            M.plen[tv] = (len_t)(plu + (len_t)uni_t(M.cseq[tv]));
+            depth[tv] = dpu + 1;
+            W::fence();
           }
+        }
+        W::fence();
+      }
+      if (!bad && u != start && !(us && ua)) {
+        if (plu > best_len) { best_len = plu; best_t = u; }
+        else if (plu == best_len && best_t != GTS_NONE) {
+          if (W::ballot(inexact)) { W::count(C.why + 7); bad = true; }
+          else if (pushed_after(u, best_t, start)) best_t = u;
         }
       }
-      pos = forward ? pos + (int64_t)W::WIDTH : pos - (int64_t)W::WIDTH;
+    };
+
+    process(start);
+    if (LDS) {
+      int64_t pos = forward ? (int64_t)spos + 1 : (int64_t)spos - 1;
+      while (pending > 0 && !bad && pos >= 0 && pos < (int64_t)nv) {
+        /* next reached vertices in sweep order */
+        const int64_t mypos = forward ? pos + (int64_t)lane : pos - (int64_t)lane;
+        uint32_t cv = 0;
+        const bool inrange = mypos >= 0 && mypos < (int64_t)nv;
+        if (inrange) cv = M.topo[(uint32_t)mypos];
+        /* a vertex handled in this chunk may label a later vertex of the same
+           chunk: look again after every vertex */
+        uint32_t next_lane = 0;
+        while (!bad) {
+          const bool reached = inrange && lane >= next_lane && M.distmap[cv] != GTS_DIST_UNSET;
+          const uint64_t rm = W::ballot(reached);
+          if (!rm) break;
+          const uint32_t l = W::ctz(rm);
+          next_lane = l + 1;
+          --pending;
+          process(W::bcast(cv, l));
+        }
+        pos = forward ? pos + (int64_t)W::WIDTH : pos - (int64_t)W::WIDTH;
+      }
+    } else {
+      /* cw: word of the position handled last; bits at or before it (in sweep
+         direction) are never set again */
+      int64_t cw = (int64_t)(spos >> 5);
+      while (pending > 0 && !bad && cw >= 0 && cw < (int64_t)nwords) {
+        const int64_t myw = forward ? cw + (int64_t)lane : cw - (int64_t)lane;
+        uint32_t word = 0;
+        if (myw >= 0 && myw < (int64_t)nwords) word = pbits[myw];
+        const uint64_t wm = W::ballot(word != 0);
+        if (!wm) { cw = forward ? cw + (int64_t)W::WIDTH : cw - (int64_t)W::WIDTH; continue; }
+        const uint32_t l = W::ctz(wm);
+        const uint32_t wv = W::bcast(word, l);
+        const uint32_t bit = forward ? (uint32_t)__builtin_ctz(wv) : 31u - (uint32_t)__builtin_clz(wv);
+        cw = forward ? cw + (int64_t)l : cw - (int64_t)l;
+        if (lane == 0) pbits[cw] = wv & ~(1u << bit);
+        W::fence();
+        --pending;
+        process(W::uni(M.topo[(uint32_t)cw * 32u + bit]));
+      }
     }
     if (!bad && best_t != GTS_NONE && best_len > cc_len) {
       uint32_t cv = best_t, n = 0;
@@ -1539,8 +1584,10 @@ struct GtsComponent {
       cc_n = n;
     }
     for (uint32_t k = lane; k < nr; k += W::WIDTH) {
-      M.distmap[R[k]] = GTS_DIST_UNSET;
-      note_labelled(R[k]);
+      const uint32_t v = R[k];
+      M.distmap[v] = GTS_DIST_UNSET;
+      if (!LDS && bad) pbits[M.tpos[v] >> 5] = 0;   /* a sweep that gave up leaves bits behind (pbits is null with LDS) */
+      note_labelled(v);
     }
     W::fence();
     return !bad;
@@ -1582,6 +1629,8 @@ struct GtsComponent {
     const uint32_t lane = W::lane();
     if (!reuse_cc) calc_cc();   /* else run() just computed the same ccs */
     for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }
+    if constexpr (!LDS)   /* position bitmap of create_walk_clean's sparse sweep */
+      for (uint32_t k = lane; k < (nv + 31) / 32; k += W::WIDTH) ((uint32_t *)&M.st_cur[0])[k] = 0;
     W::fence();
     auto ccoff = M.ccoff;
     for (uint32_t i = 0; i < ncc && !err; ++i) {
@@ -1656,17 +1705,21 @@ struct GtsComponent {
     const uint32_t lane = W::lane();
     if (!C.defer_min_nv || nv < C.defer_min_nv) return false;
     if (nterm < 2) { nodefer = 2; return false; }
-    const uint32_t nw = (nv + 31) / 32;   /* labelled-vertex bitmap of a task */
-    const uint64_t t0 = W::alloc(C.ntasks, nterm);
-    if (t0 + nterm > C.task_cap) return false;
-    const uint64_t p0 = W::alloc(C.path_used, (uint64_t)nterm * nw);
-    if (p0 + (uint64_t)nterm * nw > C.path_cap) { nodefer = 3; return false; }   /* walk in place */
     auto ccoff = M.ccoff;
     uint32_t npend = 0;
     for (uint32_t i = 0; i < ncc; ++i) {
       const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
       if (te - tb >= 2) npend += te - tb;
     }
+    /* no cc with two terminals: no walk to fan out, and nothing would make the
+       host run the select pass that does the lonesome test of a deferred
+       component (found by tests/golden/handmade/cycle) */
+    if (npend == 0) { nodefer = 2; return false; }
+    const uint32_t nw = (nv + 31) / 32;   /* labelled-vertex bitmap of a task */
+    const uint64_t t0 = W::alloc(C.ntasks, nterm);
+    if (t0 + nterm > C.task_cap) return false;
+    const uint64_t p0 = W::alloc(C.path_used, (uint64_t)nterm * nw);
+    if (p0 + (uint64_t)nterm * nw > C.path_cap) { nodefer = 3; return false; }   /* walk in place */
     const uint32_t kl = W::uni((uint32_t)C.comp_klass[c]);
     const uint64_t q0 = C.tq_base[kl] + W::alloc(C.tq_cnt + kl, npend);
     npend = 0;
@@ -1727,6 +1780,8 @@ struct GtsComponent {
     no_reference = true;
     for (uint32_t k = lane; k < nw; k += W::WIDTH) reach_bits[k] = 0;
     for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }   /* as makescaffold */
+    if constexpr (!LDS)   /* (host harness: tasks run on the global arrays) */
+      for (uint32_t k = lane; k < (nv + 31) / 32; k += W::WIDTH) ((uint32_t *)&M.st_cur[0])[k] = 0;
     W::fence();
     uint64_t len = 0;
     uint32_t n = 0;

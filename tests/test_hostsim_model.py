@@ -148,3 +148,30 @@ def test_deferred_walks_give_the_same_scaffolds(seed):
         assert hs.slow_walks > 0   # tasks that fall back to the reference search
     assert np.array_equal(og.vertex_states(), hs.vertex_states())
     assert np.array_equal(og.edge_states(), hs.edge_states())
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(fast_walks=0), dict(defer_min_nv=2)])
+def test_handmade_fixtures_through_the_component_programs(golden_dir, kw):
+    """the hand-derived fixtures (tests/golden/handmade) through the engine's
+    algorithm bodies on the host: plain, reference-search walks, deferred walks
+    (a deferred component whose ccs all have one terminal once lost its
+    lonesome marks: 'cycle' with defer_min_nv = 2)"""
+    from oracle.oracle_py import OracleGraph
+    hm = golden_dir + "/handmade"
+    col = {c: i for i, c in enumerate(["black", "gray80", "gainsboro", "ivory3", "red", "green",
+                                       "magenta", "blue"])}
+    for name in ("polymorphic", "inconsistent", "cycle", "equal_walks", "diamond_tie",
+                 "diamond_improve", "overwrite_polymorphic"):
+        og = OracleGraph.from_files("%s/%s.fa" % (hm, name), "%s/%s.de" % (hm, name))
+        og.mark_repeats_file("%s/%s.astat" % (hm, name))
+        hs = HostSimGraph(csr_from_oracle(og))
+        hs.mark_repeats(); hs.filter()
+        assert hs.makescaffold(**kw) == 0
+        vs, es = [], []
+        for line in open("%s/%s_makescaffold_expected.dot" % (hm, name)):
+            if "->" in line:
+                es.append(col[line.split('color="')[1].split('"')[0]])
+            elif "label" in line:
+                vs.append(col[line.split('color="')[1].split('"')[0]])
+        assert list(hs.vertex_states()) == vs, (name, kw)
+        assert list(hs.edge_states()) == es, (name, kw)
