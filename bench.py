@@ -206,10 +206,15 @@ def main():
     ap.add_argument("--inversions", type=float, default=None,
                     help="fraction of the chimeric links that are inversions (default 0: the "
                          "reference's walk search is exponential on components holding one)")
-    ap.add_argument("--mode", choices=["shards", "partition"], default="shards",
-                    help="shards: every rank scaffolds its own set of components (default); "
-                         "partition: ONE graph over all ranks, records split by file chunk, "
-                         "component-partition step over RCCL included in the timed region")
+    ap.add_argument("--duplicate-pairs", action="store_true",
+                    help="keep false links that repeat a contig pair (two estimates with other "
+                         "geometry for one pair; the headline workload drops them)")
+    ap.add_argument("--mode", choices=["shards", "partition"], default=None,
+                    help="partition (default for N > 1, BASELINE configs[3]): ONE graph of --contigs "
+                         "contigs over all ranks, records split by file chunk, component-partition "
+                         "step over RCCL inside the timed region, strong scaling; shards (default "
+                         "for N = 1): every rank scaffolds its own graph of --contigs contigs, no "
+                         "data-path collective, weak scaling")
     ap.add_argument("--verify", action="store_true",
                     help="also run the oracle on the FULL workload and compare digests (slow)")
     args = ap.parse_args()
@@ -242,12 +247,11 @@ def main():
 
     if args.inversions is not None:
         WORKLOAD["gen"]["p_inversion"] = args.inversions
-    g = make_inputs(pkg, args.contigs, 1234 + rank, dev, WORKLOAD["gen"])
-    g["num_pairs"] = g["num_pairs"].to(torch.int64)
-    torch.cuda.empty_cache()   # the generator's scratch goes back to HIP: the engine allocates for itself
-    nrec = g["root"].numel()
+    if args.duplicate_pairs:
+        WORKLOAD["gen"]["unique_pairs"] = False
+    mode = args.mode or ("partition" if world > 1 else "shards")
     # the engine runs on a stream of its own (a blocking stream: HIP orders it
-    # with the null stream the inputs above were generated on; every engine call
+    # with the null stream the inputs are generated on; every engine call
     # drains it before returning)
     eng = pkg.engine.Engine(local_rank)
     eng.set_option("profile", 0 if args.no_profile else 1)
@@ -255,40 +259,35 @@ def main():
         name, value = kv.split("=")
         eng.set_option(name, int(value))
 
+    def generate(seed):
+        gg = make_inputs(pkg, args.contigs, seed, dev, WORKLOAD["gen"])
+        gg["num_pairs"] = gg["num_pairs"].to(torch.int64)
+        torch.cuda.empty_cache()   # the generator's scratch goes back to HIP: the engine allocates for itself
+        return gg
+
     comm = contigs = rec = None
-    if args.mode == "partition":
-        # one graph of world x contigs: rank r generated the components with contig
-        # ids [r*n, (r+1)*n); its records are dealt out like chunks of one .de
-        # file (record i of every rank goes to rank i mod world), the contig
-        # table is replicated
+    stage_s = {}
+    if mode == "partition":
+        # ONE graph: every rank draws the same graph (same seed) and keeps the
+        # contig table and ITS chunk of the record file, as if the ranks had
+        # read consecutive chunks of one .de file
+        g = generate(1234)
+        nrec_all = g["root"].numel()
+        lo, hi = nrec_all * rank // world, nrec_all * (rank + 1) // world
         comm = pkg.dist.TorchComm() if world > 1 else pkg.dist.ThreadComm(pkg.dist.ThreadComm.Shared(1), 0)
-        nloc = args.contigs
-        def gather(t):
-            if world == 1:
-                return t
-            out = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(out, t)
-            return torch.cat(out)
-        contigs = dict(seq_len=gather(g["seq_len"]), astat=gather(g["astat"]), copy_num=gather(g["copy_num"]))
-        base = torch.tensor([nrec], dtype=torch.int64, device=dev)
-        allc = [torch.zeros_like(base) for _ in range(world)]
-        if world > 1:
-            dist.all_gather(allc, base)
-        else:
-            allc = [base]
-        k0 = int(sum(int(c.item()) for c in allc[:rank]))
-        full = dict(root=g["root"].to(torch.int64) + rank * nloc, ctg=g["ctg"].to(torch.int64) + rank * nloc,
-                    dist=g["dist"], std_dev=g["std_dev"], num_pairs=g["num_pairs"], flags=g["flags"],
-                    k=torch.arange(k0, k0 + nrec, dtype=torch.int64, device=dev))
-        idx = torch.arange(nrec, device=dev)
-        rec = {name: torch.cat(comm.exchange([t[idx % world == r] for r in range(world)]))
-               for name, t in full.items()}
-        o = torch.argsort(rec["k"])
-        rec = {name: t[o] for name, t in rec.items()}
+        contigs = dict(seq_len=g["seq_len"], astat=g["astat"], copy_num=g["copy_num"])
+        rec = {name: g[name][lo:hi].clone() for name in ("root", "ctg", "dist", "std_dev", "num_pairs", "flags")}
+        rec["k"] = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+        g = {**contigs, **rec}
+        torch.cuda.empty_cache()
+    else:
+        g = generate(1234 + rank)
+    nrec = g["root"].numel()
 
     def step():
-        if args.mode == "partition":
-            pkg.dist.scaffold_sharded(comm, eng, contigs, rec, CUTS)
+        if mode == "partition":
+            pkg.dist.scaffold_sharded(comm, eng, contigs, rec, CUTS,
+                                      timers=None if args.no_profile else stage_s)
             return eng.ne
         return run_step(eng, g)
 
@@ -301,6 +300,7 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.reset_kernel_times()
+    stage_s.clear()
     barrier()
     t0 = time.perf_counter()
     edges = 0
@@ -319,7 +319,7 @@ def main():
     if rank == 0:
         n, m = eng.nv, eng.ne
         kt = eng.kernel_times()
-        if not args.no_profile and args.mode == "shards":
+        if not args.no_profile and mode == "shards":
             # one more, untimed, step that also copies the per-component clocks back
             eng.set_option("profile", 2)
             step()
@@ -366,16 +366,23 @@ def main():
         out = dict(metric="scaffold-graph edges processed/sec (build+filter+makescaffold)",
                    value=edges_all / dt_max, unit="edges/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=dt_max / args.steps * 1e3,
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int64/u8",
+                   higher_is_better=True, scaling="strong" if mode == "partition" else "weak",
+                   vs_baseline=None, dtype="int64/u8",
                    data="synthetic",
                    config=dict(workload=(WORKLOAD["name"] + (", %.0f %% of the false links are inversions"
                                                              % (100 * args.inversions) if args.inversions else ""))
-                               if n == WORKLOAD["n_contigs"] else
-                               "synthetic scaffold graph, %d contigs per GPU (same generator)" % n,
-                               contigs_per_gpu=n, edges_per_gpu=m,
-                               records_per_gpu=nrec, components=eng.stat("components"),
-                               max_component=eng.stat("max_component"),
-                               parallelism="components sharded, %d GPU(s), mode %s" % (world, args.mode),
+                               if args.contigs == WORKLOAD["n_contigs"] else
+                               "synthetic scaffold graph, %d contigs (same generator)" % args.contigs,
+                               contigs_total=args.contigs * (1 if mode == "partition" else world),
+                               edges_total=int(edges_all / max(args.steps, 1)),
+                               contigs_rank0=n, edges_rank0=m, records_rank0=nrec,
+                               components_rank0=eng.stat("components"),
+                               max_component_rank0=eng.stat("max_component"),
+                               parallelism=("one graph, its connected components sharded over %d GPU(s): "
+                                            "label / plan / route over RCCL + one all-reduce inside the "
+                                            "filter" % world) if mode == "partition" else
+                                           ("%d independent graph(s), one per GPU, no data-path collective" % world),
+                               mode=mode,
                                hip_hw_queues=int(os.environ["GPU_MAX_HW_QUEUES"])),
                    roofline=roof, roofline_largest_streaming_kernel=roof_stream,
                    component_kernel=dict(
@@ -412,6 +419,9 @@ def main():
                    spans_ms_per_step={k: round(v[1] / args.steps, 3) for k, v in spans.items()},
                    events_ms_per_step={k: round(v[1] / args.steps, 3) for k, v in
                                        sorted(kt.items(), key=lambda kv: -kv[1][1])})
+        if mode == "partition" and stage_s:
+            out["partition_stages_ms_per_step_rank0"] = {k: round(v / args.steps * 1e3, 3)
+                                                         for k, v in stage_s.items()}
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
             cb, og, gs = cpu_baseline(pkg, args.cpu_sample, WORKLOAD["gen"], 99)
             out["cpu_baseline"] = cb

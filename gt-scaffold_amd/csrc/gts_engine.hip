@@ -74,6 +74,8 @@ struct GtsgEngine {
   int64_t *seq_len = nullptr;
   float *astat = nullptr, *copy_num = nullptr;
   uint8_t *vstate = nullptr;
+  uint32_t *vtime = nullptr;   /* time stamps of a shard's vertices (gtsg_set_vertex_times), or null */
+  bool have_vtime = false;
   /* edges, CSR / adjacency order */
   uint32_t m = 0;
   uint32_t *row = nullptr, *estart = nullptr, *eend = nullptr, *twin = nullptr,
@@ -651,7 +653,7 @@ __global__ void k_filter_hit_round(GtsGraphView G, uint8_t *ovf, int zero_ovf,
    lane's own start vertex and flags, only a hit touches a (lasthit[] is
    pre-set to GTS_NONE = -1 as int32) */
 __global__ void k_filter_lasthit(GtsGraphView G, const uint32_t *estart,
-                                 const uint8_t *ovf, uint32_t *lasthit)
+                                 const uint8_t *ovf, uint32_t *lasthit, const uint32_t *vtime)
 {
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= G.m) return;
@@ -660,7 +662,8 @@ __global__ void k_filter_lasthit(GtsGraphView G, const uint32_t *estart,
   if (!(oy & GTS_OV_ACTIVE1) || !(oy & (GTS_OV_A | GTS_OV_S))) return;
   const uint8_t ff = G.flags[t];
   if (!(oy & ((ff & GTS_F_SENSE) ? GTS_OV_S : GTS_OV_A))) return;
-  atomicMax((int *)&lasthit[2 * (uint64_t)G.end[t] + (gts_twin_dir(ff) ? 1 : 0)], (int)y);
+  atomicMax((int *)&lasthit[2 * (uint64_t)G.end[t] + (gts_twin_dir(ff) ? 1 : 0)],
+            (int)(vtime ? vtime[y] : y));
 }
 /* final edge states in two passes: every edge from what its own start vertex
    holds (coalesced), then the edges that END in a polymorphic vertex once more
@@ -668,20 +671,21 @@ __global__ void k_filter_lasthit(GtsGraphView G, const uint32_t *estart,
    the twin, so that the common edge gathers nothing */
 __global__ void k_filter_final(GtsGraphView G, const uint32_t *estart,
                                const uint32_t *tpoly, const uint8_t *ovf,
-                               const uint32_t *lasthit, uint8_t *newstate)
+                               const uint32_t *lasthit, uint8_t *newstate, const uint32_t *vtime)
 {
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.m) return;
-  newstate[p] = gts_filter_final_edge(G, estart[p], (uint32_t)p, tpoly, ovf, lasthit, false);
+  newstate[p] = gts_filter_final_edge(G, estart[p], (uint32_t)p, tpoly, ovf, lasthit, false, vtime);
 }
 __global__ void k_filter_final_poly_ends(GtsGraphView G, const uint32_t *estart,
                                          const uint32_t *tpoly, const uint8_t *ovf,
-                                         const uint32_t *lasthit, uint8_t *newstate)
+                                         const uint32_t *lasthit, uint8_t *newstate,
+                                         const uint32_t *vtime)
 {
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= G.m || tpoly[estart[t]] == GTS_NONE) return;
   const uint32_t p = G.twin[t];   /* ends in the polymorphic vertex estart[t] */
-  newstate[p] = gts_filter_final_edge(G, G.end[t], p, tpoly, ovf, lasthit, true);
+  newstate[p] = gts_filter_final_edge(G, G.end[t], p, tpoly, ovf, lasthit, true, vtime);
 }
 __global__ void k_filter_final_vertices(uint8_t *vstate, const uint32_t *tpoly,
                                         uint32_t n)
@@ -1272,7 +1276,7 @@ void gtsg_destroy(GtsgEngine *e)
   hipStreamSynchronize(e->st);
   collect_times(e);
   free_graph(e, true);
-  void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->pool, e->d_scalars};
+  void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->vtime, e->pool, e->d_scalars};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto ev : e->free_events) hipEventDestroy(ev);
   for (int k = 0; k < GTS_NSTREAMS; ++k) if (e->side[k]) hipStreamDestroy(e->side[k]);
@@ -1321,6 +1325,19 @@ int gtsg_set_contigs(GtsgEngine *e, uint64_t n, const int64_t *seq_len,
   if (copy_num) { if ((rc = upload(e, e->copy_num, copy_num, n, on_device))) return rc; }
   else HIPCHK(hipMemsetAsync(e->copy_num, 0, n * 4, e->st));
   HIPCHK(hipMemsetAsync(e->vstate, GIS_UNVISITED, n ? n : 1, e->st));
+  e->have_vtime = false;
+  return sync_stream(e);
+}
+
+int gtsg_set_vertex_times(GtsgEngine *e, const uint32_t *times, int on_device)
+{
+  if (!e) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  if (!times) { e->have_vtime = false; return 0; }
+  int rc;
+  if ((rc = dev_alloc(e, &e->vtime, e->n))) return rc;
+  if ((rc = upload(e, e->vtime, times, e->n, on_device))) return rc;
+  e->have_vtime = true;
   return sync_stream(e);
 }
 
@@ -1552,7 +1569,8 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
     if (!h) break;
   }
   HIPCHK(hipMemsetAsync(lasthit, 0xFF, (size_t)n * 8, e->st));
-  if (m) LAUNCH("filter_lasthit", k_filter_lasthit, nblk(m), GTS_BLOCK, G, e->estart, ovf, lasthit);
+  if (m) LAUNCH("filter_lasthit", k_filter_lasthit, nblk(m), GTS_BLOCK, G, e->estart, ovf, lasthit,
+                e->have_vtime ? e->vtime : (const uint32_t *)nullptr);
   e->stats["filter_rounds_p"] = rounds_p;
   e->stats["filter_rounds_i"] = rounds_i;
   e->f_tpoly = tpoly; e->f_ovf = ovf; e->f_lasthit = lasthit; e->f_newstate = newstate;
@@ -1588,10 +1606,11 @@ int gtsg_filter_end(GtsgEngine *e)
   GtsGraphView G = view_of(e);
   e->filter_open = false;
   if (m) {
+    const uint32_t *vt = e->have_vtime ? e->vtime : (const uint32_t *)nullptr;
     LAUNCH("filter_final", k_filter_final, nblk(m), GTS_BLOCK, G, e->estart, e->f_tpoly,
-           e->f_ovf, e->f_lasthit, e->f_newstate);
+           e->f_ovf, e->f_lasthit, e->f_newstate, vt);
     LAUNCH("filter_final", k_filter_final_poly_ends, nblk(m), GTS_BLOCK, G, e->estart, e->f_tpoly,
-           e->f_ovf, e->f_lasthit, e->f_newstate);
+           e->f_ovf, e->f_lasthit, e->f_newstate, vt);
     HIPCHK(hipMemcpyAsync(e->state, e->f_newstate, m, hipMemcpyDeviceToDevice, e->st));
   }
   LAUNCH("filter_final_vertices", k_filter_final_vertices, nblk(n), GTS_BLOCK, e->vstate,

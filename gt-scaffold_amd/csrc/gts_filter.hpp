@@ -286,19 +286,25 @@ GTS_HD void gts_filter_lasthit(const GtsGraphView &G, uint32_t a,
 /* with_end = false leaves out what the END vertex contributes (its time stamp
    of the polymorphic pass): the engine adds it in a second pass over the few
    edges that end in a polymorphic vertex */
+/* vtime (may be null = identity): the time stamp of a vertex when the engine
+   holds a SHARD of a larger graph with order-preserving local vertex numbers --
+   the vertex' number in the whole graph.  lasthit[] then holds such numbers
+   too (the shards combine the table), and only here are times of this shard
+   compared with times that may come from another one. */
 GTS_HD uint8_t gts_filter_final_edge(const GtsGraphView &G, uint32_t a,
                                      uint32_t p, const uint32_t *tpoly,
                                      const uint8_t *ovf, const uint32_t *lasthit,
-                                     bool with_end = true)
+                                     bool with_end = true, const uint32_t *vtime = nullptr)
 {
   const bool s = G.flags[p] & GTS_F_SENSE;
   int64_t tp = -1, ti = -1;
-  const uint32_t ta = tpoly[a], tb = with_end ? tpoly[G.end[p]] : GTS_NONE;
+  uint32_t ta = tpoly[a], tb = with_end ? tpoly[G.end[p]] : GTS_NONE;
+  if (vtime) { if (ta != GTS_NONE) ta = vtime[ta]; if (tb != GTS_NONE) tb = vtime[tb]; }
   if (ta != GTS_NONE) tp = 2 * (int64_t)ta;
   if (tb != GTS_NONE && 2 * (int64_t)tb > tp) tp = 2 * (int64_t)tb;
   const uint32_t oa = ovf[a];
   if ((oa & GTS_OV_ACTIVE1) && (oa & (s ? GTS_OV_S : GTS_OV_A)))
-    ti = 2 * (int64_t)a + 1;
+    ti = 2 * (int64_t)(vtime ? vtime[a] : a) + 1;
   const uint32_t lh = lasthit[2 * (uint64_t)a + (s ? 1 : 0)];
   if (lh != GTS_NONE && 2 * (int64_t)lh + 1 > ti) ti = 2 * (int64_t)lh + 1;
   if (tp < 0 && ti < 0) return G.state[p];

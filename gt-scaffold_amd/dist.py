@@ -14,19 +14,28 @@ to the GPU that owns its component:
   2. plan   : records per component, summed over the shards (all_reduce SUM),
               give every component to a rank, largest first in serpentine
               order -- computed identically on every rank;
-  3. route  : all_to_all of the records to the owner of their component (a
-              record touching a repeat contig follows its other contig).
+  3. route  : ONE all_to_all of the records, packed into 32 bytes each, to the
+              owner of their component (a record touching a repeat contig
+              follows its other contig).
 
-Repeat contigs are shared by the shards.  The only effect that crosses shards
-is the time of the latest inconsistency hit on their edges
-(ref algorithms.c:249-258): one all_reduce MAX between the two halves of the
-filter.  Collectives run through a `comm` object so that the same code is
-driven by torch.distributed (RCCL on GPUs, gloo in the CPU tests) or by the
-in-process communicator the single-GPU test uses.
+After routing a rank renumbers its contigs -- the ones it owns plus the repeat
+contigs, which every shard shares -- with consecutive local numbers in the order
+of their ids, so every vertex-indexed kernel of the engine runs over
+n / world + repeats vertices.  The engine gets the whole-graph id of every local
+vertex as its time stamp (gtsg_set_vertex_times): the only effect that crosses
+shards is the time of the latest inconsistency hit on the edges of the repeat
+contigs (ref algorithms.c:249-258), one all_reduce MAX over 2 x int32 per
+repeat contig between the two halves of the filter.
+
+Collectives run through a `comm` object so that the same code is driven by
+torch.distributed (RCCL on GPUs, gloo in the CPU tests) or by the in-process
+communicator the single-GPU test uses.
 """
 import threading
 
 import torch
+
+ROW_WORDS = 4   # int64 words of a packed record
 
 
 class TorchComm:
@@ -38,29 +47,33 @@ class TorchComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self._a2a = dist.get_backend(group) == "nccl"
+        self._on_host = dist.get_backend(group) != "nccl"   # gloo moves CPU tensors
 
     def all_reduce(self, t, op):
         d = self.dist
-        d.all_reduce(t, op={"min": d.ReduceOp.MIN, "max": d.ReduceOp.MAX,
-                            "sum": d.ReduceOp.SUM}[op], group=self.group)
+        rop = {"min": d.ReduceOp.MIN, "max": d.ReduceOp.MAX, "sum": d.ReduceOp.SUM}[op]
+        if self._on_host and t.is_cuda:
+            h = t.cpu()
+            d.all_reduce(h, op=rop, group=self.group)
+            t.copy_(h)
+        else:
+            d.all_reduce(t, op=rop, group=self.group)
         return t
 
-    def exchange(self, send):
-        """send[r] = 1-D tensor for rank r; returns the tensors received."""
+    def exchange_rows(self, rows, counts):
+        """rows: [k, W] tensor grouped by destination rank, counts[r] rows for
+        rank r.  Returns the rows received, grouped by source rank."""
         d = self.dist
-        if self._a2a:
-            cnt = torch.tensor([x.numel() for x in send], dtype=torch.int64, device=send[0].device)
-            rcnt = torch.empty_like(cnt)
-            d.all_to_all_single(rcnt, cnt, group=self.group)
-            rc = rcnt.tolist()
-            out = torch.empty(sum(rc), dtype=send[0].dtype, device=send[0].device)
-            d.all_to_all_single(out, torch.cat(send), rc, cnt.tolist(), group=self.group)
-            return list(torch.split(out, rc))
-        # gloo has no all_to_all: gather everything, keep what is addressed to us
-        box = [None] * self.world
-        d.all_gather_object(box, [x.cpu() for x in send], group=self.group)
-        return [box[r][self.rank].to(send[0].device) for r in range(self.world)]
+        dev = rows.device
+        if self._on_host:
+            rows = rows.cpu()
+        cnt = torch.tensor(counts, dtype=torch.int64, device=rows.device)
+        rcnt = torch.empty_like(cnt)
+        d.all_to_all_single(rcnt, cnt, group=self.group)
+        rc = rcnt.tolist()
+        out = torch.empty((sum(rc), rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        d.all_to_all_single(out, rows.contiguous(), rc, list(counts), group=self.group)
+        return out.to(dev)
 
 
 class ThreadComm:
@@ -87,26 +100,55 @@ class ThreadComm:
         t.copy_(r)
         return t
 
-    def exchange(self, send):
+    def exchange_rows(self, rows, counts):
         s = self.s
-        s.slots[self.rank] = send
+        if self.world == 1:
+            return rows
+        s.slots[self.rank] = list(torch.split(rows, list(counts)))
         s.barrier.wait()
-        out = [s.slots[r][self.rank].clone() for r in range(self.world)]
+        out = torch.cat([s.slots[r][self.rank].clone() for r in range(self.world)])
         s.barrier.wait()
         return out
 
 
+# ---- packed records -------------------------------------------------------
+def pack_records(rec):
+    """rec: root, ctg (ids below 2^31), dist (i64), std_dev (f32), num_pairs
+    (i64), flags (u8: bit0 sense, bit1 same), k (global record index = file
+    order, below 2^32) -> int64 [n, 4]:
+      word 0: root | sense << 31 | ctg << 32 | same << 63
+      word 1: dist        word 2: num_pairs
+      word 3: k | bits(std_dev) << 32"""
+    i64 = torch.int64
+    fl = rec["flags"].to(i64)
+    w0 = rec["root"].to(i64) | ((fl & 1) << 31) | (rec["ctg"].to(i64) << 32) | (((fl >> 1) & 1) << 63)
+    sd = rec["std_dev"].contiguous().view(torch.int32).to(i64) & 0xFFFFFFFF
+    w3 = rec["k"].to(i64) | (sd << 32)
+    return torch.stack([w0, rec["dist"].to(i64), rec["num_pairs"].to(i64), w3], dim=1)
+
+
+def unpack_records(rows):
+    w0, w3 = rows[:, 0], rows[:, 3]
+    sd = ((w3 >> 32) & 0xFFFFFFFF).to(torch.int32).view(torch.float32) if rows.numel() else \
+        torch.empty(0, dtype=torch.float32, device=rows.device)
+    return dict(root=w0 & 0x7FFFFFFF, ctg=(w0 >> 32) & 0x7FFFFFFF,
+                flags=(((w0 >> 31) & 1) | (((w0 >> 63) & 1) << 1)).to(torch.uint8),
+                dist=rows[:, 1].contiguous(), num_pairs=rows[:, 2].contiguous(),
+                k=w3 & 0xFFFFFFFF, std_dev=sd.contiguous())
+
+
+# ---- the three steps --------------------------------------------------------
 def component_labels(comm, n, root, ctg, skip, label_fn, device):
-    """Step 1.  root / ctg: this shard's records (int64 tensors), skip: bool[n]
-    (repeat contigs).  Returns labels[n] (int64): smallest contig of the
-    component, identical on every rank."""
-    labels = torch.arange(n, dtype=torch.int64, device=device)
+    """Step 1.  root / ctg: this shard's records, skip: bool[n] (repeat
+    contigs).  Returns labels[n] (int32): smallest contig of the component,
+    identical on every rank."""
+    labels = torch.arange(n, dtype=torch.int32, device=device)
     rounds = 0
     while True:
         prev = labels.clone()
         labels = label_fn(labels, root, ctg, skip)
         comm.all_reduce(labels, "min")
-        changed = (labels != prev).any().to(torch.int64).reshape(1)
+        changed = (labels != prev).any().to(torch.int32).reshape(1)
         comm.all_reduce(changed, "max")
         rounds += 1
         if not int(changed.item()):
@@ -117,6 +159,7 @@ def plan_owners(comm, n, labels, skip, root, ctg):
     """Step 2.  Returns owner[n] (int64 rank of every contig, -1 for the shared
     repeat contigs) and the per-rank record weight of the plan."""
     dev = labels.device
+    labels = labels.to(torch.int64)
     a_ok, b_ok = ~skip[root], ~skip[ctg]
     anchor = torch.where(a_ok, root, ctg)
     keep = a_ok | b_ok
@@ -137,59 +180,99 @@ def plan_owners(comm, n, labels, skip, root, ctg):
 
 
 def route_records(comm, owner, skip, rec):
-    """Step 3.  rec: dict of equally long 1-D tensors with keys root, ctg, k
-    (global record index = file order) and any payload.  Returns this rank's
-    records, sorted by k."""
-    root, ctg, k = rec["root"], rec["ctg"], rec["k"]
+    """Step 3.  rec: dict of equally long 1-D tensors (root, ctg, dist, std_dev,
+    num_pairs, flags, k = global record index).  One packed all_to_all; returns
+    this rank's records sorted by k (= file order)."""
+    root, ctg = rec["root"].to(torch.int64), rec["ctg"].to(torch.int64)
     # both contigs repeats: any rank, but the same one for every record of the pair
     dest = torch.where(~skip[root], owner[root],
                        torch.where(~skip[ctg], owner[ctg], torch.minimum(root, ctg) % comm.world))
-    out = {}
-    sel = [torch.nonzero(dest == r).flatten() for r in range(comm.world)]
-    for name, t in rec.items():
-        out[name] = torch.cat(comm.exchange([t[i] for i in sel]))
-    o = torch.argsort(out["k"], stable=True)
-    return {name: t[o] for name, t in out.items()}
+    counts = torch.bincount(dest, minlength=comm.world).tolist()
+    rows = pack_records(rec)
+    if comm.world > 1:
+        # stable, so the file order survives inside a destination; one-byte keys
+        # (a rank number) sort in a single radix pass
+        order = torch.sort(dest.to(torch.uint8 if comm.world <= 256 else torch.int32), stable=True)[1]
+        rows = rows[order]
+    rows = comm.exchange_rows(rows, counts)
+    out = unpack_records(rows)
+    k = out["k"]
+    if k.numel() > 1 and not bool((k[1:] >= k[:-1]).all()):   # chunks dealt in file order arrive sorted
+        o = torch.argsort(k, stable=True)
+        out = {name: t[o] for name, t in out.items()}
+    return out
 
 
 def engine_label_fn(eng):
     """label_fn backed by the engine's HIP kernels (gtsg_label_components)."""
     def fn(labels, root, ctg, skip):
-        lab = labels.to(torch.int32).contiguous()
+        lab = labels.contiguous()
         eng.label_components(lab.numel(), root.to(torch.int32).contiguous(),
                              ctg.to(torch.int32).contiguous(),
                              skip.to(torch.uint8).contiguous(), lab)
-        return lab.to(torch.int64)
+        return lab
     return fn
 
 
-def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None):
+def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None, timers=None):
     """The whole hot path for one graph whose records are split over the
-    ranks.  contigs: seq_len / astat / copy_num (replicated, tensors on the
+    ranks.  contigs: seq_len / astat / copy_num of ALL contigs (tensors on the
     engine's device); rec: this rank's slice of the records with global index
-    k.  Returns owner[n] and the number of labelling rounds; results stay in
-    `eng` (vertex states are valid for owned and repeat contigs, every edge
-    lives on exactly one rank)."""
+    k.  Returns (owner[n], labelling rounds, plan load, local[n_local]): the
+    engine holds the shard with LOCAL vertex numbers, local[v] is the contig id
+    of local vertex v (owned contigs and all repeat contigs, ascending); vertex
+    states are valid for owned and repeat contigs, every edge lives on exactly
+    one rank.  timers: optional dict that receives the wall time (s) of the
+    stages, each closed by a device synchronisation (measurement only)."""
+    import time
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if timers is not None:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            now = time.perf_counter()
+            timers[name] = timers.get(name, 0.0) + now - t_last[0]
+            t_last[0] = now
     dev = contigs["seq_len"].device
     n = contigs["seq_len"].numel()
     skip = (contigs["astat"] <= cuts["astat_cutoff"]) | (contigs["copy_num"] < cuts["copy_num_cutoff"])
     root, ctg = rec["root"].to(torch.int64), rec["ctg"].to(torch.int64)
     labels, rounds = component_labels(comm, n, root, ctg, skip, label_fn or engine_label_fn(eng), dev)
+    lap("label")
     owner, load = plan_owners(comm, n, labels, skip, root, ctg)
-    rec64 = dict(rec)
-    rec64["root"], rec64["ctg"] = root, ctg
-    mine = route_records(comm, owner, skip, rec64)
-    eng.set_contigs(contigs["seq_len"], contigs["astat"], contigs["copy_num"])
-    eng.build_from_records(mine["root"].to(torch.int32).contiguous(),
-                           mine["ctg"].to(torch.int32).contiguous(),
+    lap("plan")
+    mine = route_records(comm, owner, skip, rec)
+    lap("route")
+    # local numbering: owned + repeat contigs, in id order
+    member = (owner == comm.rank) | skip
+    local = torch.nonzero(member).flatten()
+    loc_of = torch.cumsum(member.to(torch.int64), 0) - 1
+    eng.set_contigs(contigs["seq_len"][local].contiguous(), contigs["astat"][local].contiguous(),
+                    contigs["copy_num"][local].contiguous())
+    eng.set_vertex_times(local.to(torch.int32).contiguous())
+    eng.build_from_records(loc_of[mine["root"]].to(torch.int32).contiguous(),
+                           loc_of[mine["ctg"]].to(torch.int32).contiguous(),
                            mine["dist"].contiguous(), mine["std_dev"].contiguous(),
                            mine["num_pairs"].contiguous(), mine["flags"].contiguous())
     eng.mark_repeats(True, cuts["copy_num_cutoff"], cuts["astat_cutoff"])
-    eng.filter_begin(cuts["pcutoff"], cuts["cncutoff"], cuts["ocutoff"])
-    lasthit = torch.empty(2 * n, dtype=torch.int32, device=dev)
-    eng.filter_get_lasthit(lasthit)
-    comm.all_reduce(lasthit, "max")
-    eng.filter_set_lasthit(lasthit)
-    eng.filter_end()
-    eng.makescaffold()
-    return owner, rounds, load
+    lap("renumber_build_mark")
+    # latest-hit times of the repeat contigs' edges: whole-graph ids, MAX over
+    # the shards (every rank holds all repeat contigs, so a rank without any
+    # vertex means there is no repeat and nothing to combine)
+    rep_loc = loc_of[torch.nonzero(skip).flatten()]
+    if local.numel():
+        eng.filter_begin(cuts["pcutoff"], cuts["cncutoff"], cuts["ocutoff"])
+        lasthit = torch.empty(2 * local.numel(), dtype=torch.int32, device=dev)
+        eng.filter_get_lasthit(lasthit)
+    if rep_loc.numel():
+        tab = lasthit.view(-1, 2)[rep_loc].contiguous()
+        comm.all_reduce(tab, "max")
+        lasthit.view(-1, 2)[rep_loc] = tab
+        eng.filter_set_lasthit(lasthit)
+    if local.numel():
+        eng.filter_end()
+        lap("filter")
+        eng.makescaffold()
+        lap("makescaffold")
+    return owner, rounds, load, local

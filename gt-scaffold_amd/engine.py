@@ -15,7 +15,7 @@ _LIB = None
 
 SYMBOLS = [
     "gtsg_create", "gtsg_destroy", "gtsg_last_error", "gtsg_set_contigs",
-    "gtsg_build_from_records", "gtsg_build_from_records_ex", "gtsg_set_astat", "gtsg_mark_repeats", "gtsg_filter",
+    "gtsg_build_from_records", "gtsg_build_from_records_ex", "gtsg_set_vertex_times", "gtsg_set_astat", "gtsg_mark_repeats", "gtsg_filter",
     "gtsg_removecycles", "gtsg_makescaffold", "gtsg_num_vertices", "gtsg_num_edges",
     "gtsg_get_vertex_states", "gtsg_get_edge_states", "gtsg_get_edges", "gtsg_state_digest",
     "gtsg_set_option", "gtsg_selftest_ambiguous", "gtsg_filter_begin", "gtsg_filter_end",
@@ -61,6 +61,7 @@ def lib():
         L.gtsg_build_from_records.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, ci]
         L.gtsg_build_from_records_ex.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, ci, ci]
         L.gtsg_set_astat.argtypes = [vp, vp, vp, ci]
+        L.gtsg_set_vertex_times.argtypes = [vp, vp, ci]
         L.gtsg_mark_repeats.argtypes = [vp, ci, f32, f32]
         L.gtsg_filter.argtypes = [vp, f32, f32, i64]
         L.gtsg_filter_begin.argtypes = [vp, f32, f32, i64]
@@ -208,6 +209,12 @@ class Engine:
         self._chk(self._L.gtsg_build_from_records_ex(self._h, len(root), *[x[0] for x in a],
                                                      self._same_side([x[1] for x in a]),
                                                      int(bool(ismatepair))))
+
+    def set_vertex_times(self, times):
+        """shard of a larger graph: times[v] = id of local vertex v in the whole graph"""
+        p, d, k = _ptr(times, np.uint32)
+        self._sync_producer([(p, d)])
+        self._chk(self._L.gtsg_set_vertex_times(self._h, p, d if d is not None else 0))
 
     def set_astat(self, astat, copy_num):
         p1, d1, k1 = _ptr(astat, np.float32)

@@ -62,6 +62,15 @@ const char *gtsg_last_error(const GtsgEngine *e);
 int gtsg_set_contigs(GtsgEngine *e, uint64_t n, const int64_t *seq_len,
                      const float *astat, const float *copy_num, int on_device);
 
+/* For a SHARD of a larger graph (multi-GPU): the engine's vertex
+   numbers are then local -- any numbering that keeps the order of the whole
+   graph's vertex ids -- and times[v] is the id of local vertex v in the whole
+   graph (strictly increasing).  The filter is the only stage that compares
+   "times" across shards (the latest-hit table of gtsg_filter_get/set_lasthit
+   then holds whole-graph ids).  NULL goes back to the identity; a call to
+   gtsg_set_contigs does the same. */
+int gtsg_set_vertex_times(GtsgEngine *e, const uint32_t *times, int on_device);
+
 /* DistEst records in file order -> edges + CSR.  replaces
    gt_scaffolder_parser_read_distances' per-record graph updates
    (ref parser.c:357-378: find_edge / alter_edge / two add_edge calls,

@@ -35,7 +35,7 @@ def numpy_label_fn(labels, root, ctg, skip):
                 parent[rb] = ra
             else:
                 parent[ra] = rb
-    return torch.from_numpy(np.array([find(v) for v in range(len(parent))], dtype=np.int64))
+    return torch.from_numpy(np.array([find(v) for v in range(len(parent))], dtype=labels.numpy().dtype))
 
 
 def shard_inputs(g, world, rank):
@@ -55,19 +55,21 @@ def check_partition(comm, g):
     labels, rounds = dist_mod.component_labels(comm, n, rec["root"], rec["ctg"], skip, numpy_label_fn, "cpu")
     # reference: union-find over ALL records
     allroot = torch.from_numpy(g["root"].astype(np.int64)); allctg = torch.from_numpy(g["ctg"].astype(np.int64))
-    want = numpy_label_fn(torch.arange(n, dtype=torch.int64), allroot, allctg, skip)
-    assert torch.equal(labels, want)
+    want = numpy_label_fn(torch.arange(n, dtype=torch.int32), allroot, allctg, skip)
+    assert labels.dtype == torch.int32 and torch.equal(labels, want)
     owner, load = dist_mod.plan_owners(comm, n, labels, skip, rec["root"], rec["ctg"])
     assert int((owner[~skip] < 0).sum()) == 0 and int((owner[skip] >= 0).sum()) == 0
-    assert torch.equal(owner[~skip], owner[labels][~skip])        # one owner per component
+    assert torch.equal(owner[~skip], owner[labels.to(torch.int64)][~skip])        # one owner per component
     mine = dist_mod.route_records(comm, owner, skip, rec)
     k = mine["k"]
     assert torch.all(k[1:] > k[:-1])                                # file order kept
     a, b = mine["root"], mine["ctg"]
     dest = torch.where(~skip[a], owner[a], torch.where(~skip[b], owner[b], torch.minimum(a, b) % comm.world))
     assert torch.all(dest == comm.rank)
-    # payload travels with its record
-    assert torch.equal(mine["dist"], torch.from_numpy(g["dist"])[k])
+    # every field travels with its record through the packed rows
+    for name in ("root", "ctg", "dist", "std_dev", "flags"):
+        assert torch.equal(mine[name].to(torch.float64), torch.from_numpy(g[name].astype(np.float64))[k]), name
+    assert torch.equal(mine["num_pairs"], torch.from_numpy(g["num_pairs"].astype(np.int64))[k])
     total = torch.tensor([k.numel()], dtype=torch.int64)
     comm.all_reduce(total, "sum")
     assert int(total) == len(g["root"])
@@ -122,3 +124,26 @@ def test_partition_in_process(world):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_packed_rows_round_trip():
+    """32-byte rows: ids up to 2^31-1, negative distances, any float bits, both flags"""
+    rng = np.random.default_rng(3)
+    k = 5000
+    rec = dict(root=torch.from_numpy(rng.integers(0, 2**31 - 1, k)), ctg=torch.from_numpy(rng.integers(0, 2**31 - 1, k)),
+               dist=torch.from_numpy(rng.integers(-2**62, 2**62, k)),
+               std_dev=torch.from_numpy(rng.standard_normal(k).astype(np.float32) * 1e3),
+               num_pairs=torch.from_numpy(rng.integers(0, 2**62, k)),
+               flags=torch.from_numpy(rng.integers(0, 4, k).astype(np.uint8)),
+               k=torch.from_numpy(rng.integers(0, 2**32 - 1, k)))
+    rec["root"][0] = rec["ctg"][1] = 2**31 - 1
+    rec["std_dev"][2] = float("inf"); rec["std_dev"][3] = -0.0
+    back = dist_mod.unpack_records(dist_mod.pack_records(rec))
+    for name, t in rec.items():
+        a, b = back[name], t
+        if name == "std_dev":
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        else:
+            assert torch.equal(a.to(torch.int64), b.to(torch.int64)), name
+    empty = dist_mod.unpack_records(dist_mod.pack_records({n_: t[:0] for n_, t in rec.items()}))
+    assert all(t.numel() == 0 for t in empty.values())

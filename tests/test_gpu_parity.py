@@ -304,9 +304,11 @@ def test_sharded_pipeline_matches_unsharded_oracle(world):
                 {"root": np.int64, "ctg": np.int64, "num_pairs": np.int64}.get(k, g[k].dtype))).to(dev)
                 for k in ("root", "ctg", "dist", "std_dev", "num_pairs", "flags")}
             rec["k"] = torch.arange(lo, hi, dtype=torch.int64, device=dev)
-            owner, rounds, load = dist_mod.scaffold_sharded(dist_mod.ThreadComm(shared, r), eng,
-                                                            contigs, rec, cuts)
-            res[r] = (owner.cpu().numpy(), eng.vertex_states(), eng.edges(), eng.edge_states())
+            owner, rounds, load, local = dist_mod.scaffold_sharded(dist_mod.ThreadComm(shared, r), eng,
+                                                                   contigs, rec, cuts)
+            assert eng.nv == local.numel() < n          # owned + repeat contigs only
+            res[r] = (owner.cpu().numpy(), eng.vertex_states(), eng.edges(), eng.edge_states(),
+                      local.cpu().numpy())
             eng.close()
         except BaseException as ex:   # noqa: B902
             errs.append(ex)
@@ -321,10 +323,10 @@ def test_sharded_pipeline_matches_unsharded_oracle(world):
     vs = np.zeros(n, np.uint8)
     seen = {}
     for r in range(world):
-        _, v, e, es = res[r]
-        mine = (owner == r) | (owner < 0)
-        vs[mine] = v[mine]
-        for a, b, s in zip(e["start"], e["end"], es):
+        _, v, e, es, local = res[r]
+        assert np.array_equal(local, np.nonzero((owner == r) | (owner < 0))[0])
+        vs[local] = v                                    # repeat contigs: the same state on every rank
+        for a, b, s in zip(local[e["start"]], local[e["end"]], es):
             assert (int(a), int(b)) not in seen          # every edge lives on one rank
             seen[(int(a), int(b))] = int(s)
     assert np.array_equal(vs, og.vertex_states())
