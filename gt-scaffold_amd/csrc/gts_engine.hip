@@ -463,17 +463,23 @@ __global__ void k_pack_vattr(const int64_t *seq_len, const float *copy_num, GtsV
   GtsVAttr a; a.len = seq_len[v]; a.cn = copy_num[v]; a.tpoly = GTS_NONE;
   va[v] = a;
 }
-/* the time stamps of the polymorphic pass join the record: k_filter_ovf_init
-   needs both per edge */
-__global__ void k_vattr_tpoly(const uint32_t *tpoly, GtsVAttr *va, uint32_t n)
+/* bitmap of the vertices the polymorphic pass stamped: k_filter_ovf_init asks
+   it per edge (n / 8 bytes, L2 resident) and reaches for tpoly[] only for the
+   few ends that are polymorphic */
+__global__ void k_poly_bitmap(const uint32_t *tpoly, uint32_t *bits, uint32_t n)
 {
   uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < n) va[v].tpoly = tpoly[v];
+  const uint64_t b = __builtin_amdgcn_ballot_w64(v < n && tpoly[v] != GTS_NONE);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (lane == 0 && v < n) bits[v >> 5] = (uint32_t)b;
+  if (lane == 32 && v < n) bits[v >> 5] = (uint32_t)(b >> 32);
 }
+/* "wide" mark of an end vertex' length in elen[] (does not fit the 32-bit staging) */
+#define GTS_ELEN_WIDE INT32_MIN
 
 __global__ void __launch_bounds__(GTS_BLOCK)
 k_filter_pairs(GtsGraphView G, GtsFilterParams P, const GtsVAttr *va, uint8_t *prop,
-               uint8_t *vinfo, uint32_t hub_degree)
+               uint8_t *vinfo, uint32_t hub_degree, int32_t *elen)
 {
   __shared__ int32_t s_d[GTS_FP_CAP], s_l[GTS_FP_CAP];
   __shared__ float s_s[GTS_FP_CAP], s_c[GTS_FP_CAP];
@@ -485,13 +491,21 @@ k_filter_pairs(GtsGraphView G, GtsFilterParams P, const GtsVAttr *va, uint8_t *p
   uint32_t ns = e1 - e0 < GTS_FP_CAP ? e1 - e0 : GTS_FP_CAP;
   if (threadIdx.x == 0) s_wide = 0;
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < ns; i += GTS_BLOCK) {
+  /* every edge of the block: the end vertex' length also goes to elen[] in
+     edge order, so that the overlap pass (k_filter_ovf_init) reads it back
+     coalesced instead of gathering the vertex record a second time */
+  for (uint32_t i = threadIdx.x; i < e1 - e0; i += GTS_BLOCK) {
     const uint32_t p = e0 + i, x = G.end[p];
     const GtsVAttr a = va[x];
-    const int64_t d = G.dist[p], l = a.len;
-    if (d != (int32_t)d || l != (int32_t)l) s_wide = 1;
-    s_d[i] = (int32_t)d; s_s[i] = G.sd[p]; s_f[i] = G.flags[p];
-    s_c[i] = a.cn; s_l[i] = (int32_t)l;
+    const int64_t l = a.len;
+    const bool lw = l != (int32_t)l || (int32_t)l == GTS_ELEN_WIDE;
+    elen[p] = lw ? GTS_ELEN_WIDE : (int32_t)l;
+    if (i < ns) {
+      const int64_t d = G.dist[p];
+      if (d != (int32_t)d || lw) s_wide = 1;
+      s_d[i] = (int32_t)d; s_s[i] = G.sd[p]; s_f[i] = G.flags[p];
+      s_c[i] = a.cn; s_l[i] = (int32_t)l;
+    }
   }
   __syncthreads();
   if (s_wide) ns = 0;
@@ -562,8 +576,8 @@ __global__ void k_filter_tpoly(GtsGraphView G, const uint32_t *estart,
   atomicMin(&tpoly[v], u);
 }
 __global__ void __launch_bounds__(GTS_BLOCK)
-k_filter_ovf_init(GtsGraphView G, GtsFilterParams P, const GtsVAttr *va, const uint32_t *estart,
-                  const uint8_t *vinfo, const uint32_t *tpoly, uint8_t *ovf,
+k_filter_ovf_init(GtsGraphView G, GtsFilterParams P, const int32_t *elen, const uint32_t *ispoly,
+                  const uint32_t *estart, const uint8_t *vinfo, const uint32_t *tpoly, uint8_t *ovf,
                   int zero_ovf, uint32_t hub_degree)
 {
   __shared__ int32_t s_d[GTS_FP_CAP], s_l[GTS_FP_CAP];
@@ -596,11 +610,13 @@ k_filter_ovf_init(GtsGraphView G, GtsFilterParams P, const GtsVAttr *va, const u
     uint32_t ns = e1 - e0 < GTS_FP_CAP ? e1 - e0 : GTS_FP_CAP;
     for (uint32_t i = threadIdx.x; i < ns; i += GTS_BLOCK) {
       const uint32_t p = e0 + i, x = G.end[p];
-      const GtsVAttr a = va[x];
-      const bool mk = gts_edge_is_marked(G.state[p]) || a.tpoly <= estart[p];
-      const int64_t d = G.dist[p], l = a.len;
-      if (d != (int32_t)d || l != (int32_t)l) s_wide = 1;
-      s_d[i] = (int32_t)d; s_l[i] = (int32_t)l;
+      /* polymorphic end that was stamped no later than this vertex' turn */
+      const bool pe = ((ispoly[x >> 5] >> (x & 31u)) & 1u) && tpoly[x] <= estart[p];
+      const bool mk = gts_edge_is_marked(G.state[p]) || pe;
+      const int64_t d = G.dist[p];
+      const int32_t l = elen[p];
+      if (d != (int32_t)d || l == GTS_ELEN_WIDE) s_wide = 1;
+      s_d[i] = (int32_t)d; s_l[i] = l;
       s_f[i] = (uint8_t)((G.flags[p] & 3u) | (mk ? 0x80u : 0u));
     }
     __syncthreads();
@@ -708,7 +724,7 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 /* live edge: unmarked edge between unmarked vertices.  Hooks the larger root
    under the smaller one, so a component's label is its smallest vertex. */
 __global__ void k_live_union(GtsGraphView G, const uint32_t *estart,
-                             uint8_t *live, uint8_t *touched, uint32_t *parent)
+                             uint8_t *live, uint32_t *parent)
 {
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.m) return;
@@ -721,7 +737,9 @@ __global__ void k_live_union(GtsGraphView G, const uint32_t *estart,
      about the twin from one gather */
   live[p] = (uint8_t)((G.flags[p] & 3u) | (lv ? 0x80u : 0u));
   if (!lv) return;
-  touched[a] = 1; touched[b] = 1;
+  /* (which vertices have a live edge at either end is read off the forest
+     afterwards, k_component_roots: two random byte writes per live edge cost
+     more than the union itself) */
   uint32_t x = a, y = b;
   for (;;) {
     x = uf_find(parent, x); y = uf_find(parent, y);
@@ -731,16 +749,28 @@ __global__ void k_live_union(GtsGraphView G, const uint32_t *estart,
     if (old == x) break;
   }
 }
-__global__ void k_component_vertices(const uint8_t *touched, uint8_t *vstate,
-                                     uint32_t *parent, uint32_t *flag,
+/* a vertex is joined to another one iff it is not its own root or it is the
+   root of some other vertex (has_child); the finds shorten the paths for
+   k_slot_keys on their way */
+__global__ void k_component_roots(uint32_t *parent, uint8_t *has_child, uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const uint32_t r = uf_find(parent, (uint32_t)v);
+  if (r != v) has_child[r] = 1;
+}
+__global__ void k_component_vertices(const uint8_t *has_child, uint8_t *vstate,
+                                     const uint32_t *parent, uint32_t *flag,
                                      uint32_t n, int mode)
 {
   uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
   const bool marked = gts_vertex_is_marked(vstate[v]);
-  const bool in = !marked && touched[v];
+  /* only unmarked vertices are ever joined (a live edge has unmarked ends) */
+  const bool touched = parent[v] != v || has_child[v];
+  const bool in = !marked && touched;
   flag[v] = in ? 1u : 0u;
-  if (!marked && !touched[v])   /* lonesome vertex: algorithms.c:790-806 */
+  if (!marked && !touched)   /* lonesome vertex: algorithms.c:790-806 */
     vstate[v] = mode == GTS_MODE_MAKESCAFFOLD ? GIS_SCAFFOLD : GIS_UNVISITED;
 }
 __global__ void k_slot_keys(const uint32_t *flag, const uint32_t *idx,
@@ -1367,7 +1397,8 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
                                const uint8_t *flags, int on_device, int ismatepair)
 {
   if (!e || (nrec && (!root || !ctg || !dist || !std_dev || !flags))) return GTSG_EINVAL;
-  if (nrec >= (1ull << 31) - 1) return fail(e, GTSG_ELIMIT, "too many records");
+  /* the one-sweep sort keeps counts in 30 bits (gts_prims.hpp) */
+  if (nrec >= GTS_ONESWEEP_MAX_N / 2) return fail(e, GTSG_ELIMIT, "2^29 records or more");
   HIPCHK(hipSetDevice(e->device));
   free_graph(e, false);
   const uint32_t n = e->n;
@@ -1433,7 +1464,7 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
     if (bad) return fail(e, GTSG_EINVAL, "contig id out of range in the records (%u contigs)", n);
   }
   const uint64_t m64 = 2ull * npairs_created;
-  if (m64 >= 0xFFFFFFFEull) return fail(e, GTSG_ELIMIT, "more than 2^32-2 edges");
+  if (m64 >= GTS_ONESWEEP_MAX_N) return fail(e, GTSG_ELIMIT, "2^30 edges or more");
   const uint32_t m = (uint32_t)m64;
   e->m = m;
   if ((rc = dev_alloc(e, &e->row, (size_t)n + 1))) return rc;
@@ -1516,7 +1547,7 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   e->filter_open = false;
   if (!n) return 0;
   int rc;
-  if ((rc = pool_reserve(e, (size_t)m * 2 + (size_t)n * 42 + (8u << 20)))) return rc;
+  if ((rc = pool_reserve(e, (size_t)m * 6 + (size_t)n * 43 + (8u << 20)))) return rc;
   GtsGraphView G = view_of(e);
   GtsFilterParams P;
   P.amb = gts_amb_thresholds(pcutoff);
@@ -1528,12 +1559,13 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   PALLOC(tpoly, uint32_t, n); PALLOC(lasthit, uint32_t, 2 * (size_t)n);
   uint32_t *pending = e->d_scalars + 4;
   PALLOC(vattr, GtsVAttr, n);
+  PALLOC(elen, int32_t, (size_t)m + 1); PALLOC(ispoly, uint32_t, (size_t)n / 32 + 2);
   HIPCHK(hipMemsetAsync(prop, 0, (size_t)m + 1, e->st));
   LAUNCH("filter_pack_vattr", k_pack_vattr, nblk(n), GTS_BLOCK, e->seq_len, e->copy_num, vattr, n);
   /* the degree the hub list was built with: option "hub_degree" set after the
      build takes effect at the next build */
   LAUNCH("filter_pairs", k_filter_pairs, nblk(n), GTS_BLOCK, G, P, vattr, prop, vinfo,
-         e->built_hub_degree);
+         e->built_hub_degree, elen);
   if (e->nhub)
     LAUNCH("filter_pairs_hub", k_filter_pairs_hub, nblk((uint64_t)e->nhub * GTS_WAVE),
            GTS_BLOCK, G, P, prop, vinfo, e->hubs, e->nhub);
@@ -1552,9 +1584,9 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   }
   HIPCHK(hipMemsetAsync(tpoly, 0xFF, (size_t)n * 4, e->st));
   if (m) LAUNCH("filter_tpoly", k_filter_tpoly, nblk(m), GTS_BLOCK, G, e->estart, prop, vinfo, tpoly);
-  LAUNCH("filter_pack_vattr", k_vattr_tpoly, nblk(n), GTS_BLOCK, tpoly, vattr, n);
-  LAUNCH("filter_ovf_init", k_filter_ovf_init, nblk(n), GTS_BLOCK, G, P, vattr, e->estart, vinfo, tpoly,
-         ovf, zero_ovf, e->built_hub_degree);
+  LAUNCH("filter_pack_vattr", k_poly_bitmap, nblk(n), GTS_BLOCK, tpoly, ispoly, n);
+  LAUNCH("filter_ovf_init", k_filter_ovf_init, nblk(n), GTS_BLOCK, G, P, elen, ispoly, e->estart, vinfo,
+         tpoly, ovf, zero_ovf, e->built_hub_degree);
   if (e->nhub && !zero_ovf)
     LAUNCH("filter_ovf_init_hub", k_filter_ovf_init_hub,
            nblk((uint64_t)e->nhub * GTS_WAVE), GTS_BLOCK, G, P, vinfo, tpoly, ovf, e->hubs,
@@ -1722,8 +1754,8 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemsetAsync(touched, 0, n, e->st));
     LAUNCH("iota", k_iota, nblk(n), GTS_BLOCK, parent, (uint64_t)n);
     if (m)
-      LAUNCH("comp_live_union", k_live_union, nblk(m), GTS_BLOCK, G, e->estart, live,
-             touched, parent);
+      LAUNCH("comp_live_union", k_live_union, nblk(m), GTS_BLOCK, G, e->estart, live, parent);
+    LAUNCH("comp_vertices", k_component_roots, nblk(n), GTS_BLOCK, parent, touched, n);
     LAUNCH("comp_vertices", k_component_vertices, nblk(n), GTS_BLOCK, touched, e->vstate,
            parent, flag, n, mode);
     gts_exscan<uint32_t, uint32_t>(flag, idx, n, sctmp, e->d_scalars, e->st);

@@ -3,14 +3,22 @@
   64-lane wavefronts, 256-thread workgroups, LDS-staged digit counters.
 
     * exclusive prefix sums (u32 / u64), reduce-then-scan over 2048-element tiles
-    * stable LSD radix sort of (key, u32 value) pairs, 8-bit digits: per-tile
-      digit histograms -> one scan over [digit][tile] -> stable scatter.  The
-      rank of a key inside its wavefront comes from eight __ballot()s (the
-      lanes holding the same digit) and a popcount of the lower lanes; each
-      wavefront owns a contiguous slice of the tile so ranks follow index order.
+    * stable LSD radix sort of (key, u32 value) pairs, 8-bit digits, "one
+      sweep": ONE up-front pass histograms every digit of every pass; each
+      pass is then a single kernel that reads a pair once and writes it once.
+      A workgroup takes the next tile (atomic ticket, so every earlier tile is
+      already running), ranks its keys, publishes its per-digit counts and
+      finds its global offsets by looking back over the earlier tiles' entries
+      (decoupled look-back: "aggregate" until a tile knows its prefix, then
+      "inclusive prefix"), then scatters through LDS.  The rank of a key
+      inside its wavefront comes from eight __ballot()s (the lanes holding the
+      same digit) and a popcount of the lower lanes; each wavefront owns a
+      contiguous slice of the tile so ranks follow index order: the sort is
+      stable.
 
-  These are HBM-bound streaming passes: per 8-bit pass a pair is read twice
-  (histogram, scatter) and written once.
+  HBM traffic per pair: 8 (or 4) bytes once for the histograms, then per pass
+  one read and one write (2 x 12 B for 64-bit keys) -- the three-kernel
+  version (histogram, scan, scatter per pass) read the keys twice per pass.
 */
 #ifndef GTS_PRIMS_HPP
 #define GTS_PRIMS_HPP
@@ -22,8 +30,6 @@
 #define GTS_WAVE 64
 #define GTS_SCAN_ITEMS 8
 #define GTS_SCAN_TILE (GTS_BLOCK * GTS_SCAN_ITEMS)
-#define GTS_SORT_ITEMS 16
-#define GTS_SORT_TILE (GTS_BLOCK * GTS_SORT_ITEMS)
 
 __device__ __forceinline__ uint32_t gts_lane() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t gts_lanemask_lt()
@@ -146,49 +152,129 @@ __device__ __forceinline__ uint32_t gts_digit(uint64_t key, int shift)
   return (uint32_t)((key & ~(1ull << 63)) >> shift) & 255u;
 }
 
-template <typename K>
-__global__ void __launch_bounds__(GTS_BLOCK)
-k_radix_hist(const K *keys, uint64_t n, int shift, uint32_t *hist,
-             uint32_t ntiles)
+/* look-back state of (tile, digit): flag in the two top bits, count below */
+#define GTS_LB_AGG 0x40000000u      /* the tile's own count */
+#define GTS_LB_PREFIX 0x80000000u   /* count of this and all earlier tiles */
+#define GTS_LB_VALUE 0x3FFFFFFFu
+/* n below 2^30 so that every count fits under the flags */
+#define GTS_ONESWEEP_MAX_N (1ull << 30)
+
+/* global start of digit d's run minus the position of its first element in
+   this tile (lbase), for digit d = threadIdx.x.  L2 caches are per XCD and not
+   coherent with each other: the entries are written and polled with
+   agent-scope atomics, which go past them; an entry carries its data and its
+   flag in one word, so no further ordering is needed. */
+__device__ __forceinline__ uint32_t gts_lookback(uint32_t *status, uint32_t tile, uint32_t d,
+                                                 uint32_t count, uint32_t gbase)
 {
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  const uint64_t base = (uint64_t)blockIdx.x * GTS_SORT_TILE;
-#pragma unroll
-  for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
-    const uint64_t idx = base + (uint64_t)i * GTS_BLOCK + threadIdx.x;
-    if (idx < n) atomicAdd(&h[gts_digit(keys[idx], shift)], 1u);
+  uint32_t *mine = status + (uint64_t)tile * 256 + d;
+  if (tile == 0) {
+    __hip_atomic_store(mine, GTS_LB_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return gbase;
   }
-  __syncthreads();
-  hist[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+  __hip_atomic_store(mine, GTS_LB_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t excl = 0;
+  for (uint32_t t = tile; t-- > 0;) {
+    const uint32_t *p = status + (uint64_t)t * 256 + d;
+    uint32_t v;
+    /* tile t holds an earlier ticket: its workgroup is running and publishes
+       without waiting for anything later */
+    while (((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) &
+            (GTS_LB_AGG | GTS_LB_PREFIX)) == 0)
+      __builtin_amdgcn_s_sleep(1);
+    excl += v & GTS_LB_VALUE;
+    if (v & GTS_LB_PREFIX) break;
+  }
+  __hip_atomic_store(mine, GTS_LB_PREFIX | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return gbase + excl;
 }
 
+/* digit histograms of every pass in one read of the keys: ghist[pass][256] */
 template <typename K>
 __global__ void __launch_bounds__(GTS_BLOCK)
-k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
-                uint64_t n, int shift, const uint32_t *offs, uint32_t ntiles)
+k_onesweep_hist(const K *keys, uint64_t n, uint32_t *ghist, int npasses, int s0, int s1, int s2,
+                int s3, int s4, int s5, int s6, int s7)
 {
-  __shared__ uint32_t cnt[GTS_BLOCK / GTS_WAVE][256];
-  const uint32_t lane = gts_lane(), w = threadIdx.x >> 6;
-  for (int i = 0; i < GTS_BLOCK / GTS_WAVE; ++i) cnt[i][threadIdx.x] = 0;
+  __shared__ uint32_t h[8][256];
+  const int sh[8] = {s0, s1, s2, s3, s4, s5, s6, s7};
+  for (int p = 0; p < npasses; ++p) h[p][threadIdx.x] = 0;
   __syncthreads();
-  const uint64_t wbase = (uint64_t)blockIdx.x * GTS_SORT_TILE +
-                         (uint64_t)w * (GTS_SORT_ITEMS * GTS_WAVE);
-  K key[GTS_SORT_ITEMS];
-  uint32_t val[GTS_SORT_ITEMS], rank[GTS_SORT_ITEMS];
+  for (uint64_t idx = (uint64_t)blockIdx.x * GTS_BLOCK + threadIdx.x; idx < n;
+       idx += (uint64_t)gridDim.x * GTS_BLOCK) {
+    const K k = keys[idx];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      if (p < npasses) atomicAdd(&h[p][gts_digit(k, sh[p])], 1u);
+  }
+  __syncthreads();
+  for (int p = 0; p < npasses; ++p)
+    if (h[p][threadIdx.x]) atomicAdd(&ghist[p * 256 + threadIdx.x], h[p][threadIdx.x]);
+}
+/* ghist[pass][*] -> exclusive prefix, one workgroup per pass */
+__global__ void __launch_bounds__(GTS_BLOCK)
+k_onesweep_bases(uint32_t *ghist)
+{
+  uint32_t total;
+  uint32_t *h = ghist + blockIdx.x * 256;
+  const uint32_t ex = gts_block_exscan<uint32_t>(h[threadIdx.x], total);
+  h[threadIdx.x] = ex;
+}
+
+/* One pass of the sort: a workgroup of GTS_SB threads takes the next tile of
+   GTS_SB x ITEMS pairs.  Each wavefront owns a contiguous slice of the
+   tile and ranks its keys item by item (all lanes at once): the lanes holding
+   the same digit are found with eight ballots, the rank is the wave's running
+   count of the digit plus the number of lower lanes among them.  Threads
+   0..255 then turn the per-wave counts into positions inside the tile and look
+   the global offsets up (gts_lookback); the tile is put in digit order in LDS
+   -- keys, then values through the same buffer -- and written out by
+   consecutive threads, so a digit's run goes out as whole lines. */
+#ifndef GTS_SB
+#define GTS_SB 512
+#endif
+#define GTS_SW (GTS_SB / GTS_WAVE)
+/* pairs per thread: 12 with 64-bit keys, 16 with 32-bit keys (measured on
+   100 M pairs, tools/microbench/sort_bench.hip: 64-bit 4.9 ms for six passes
+   with 12, 5.7 with 16; 32-bit 1.96 ms for three passes with 16, 2.2 with 12) */
+template <typename K> struct GtsSortItems { static const int value = sizeof(K) > 4 ? 12 : 16; };
+
+template <typename K, int ITEMS>
+__global__ void __launch_bounds__(GTS_SB)
+k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
+                uint64_t n, int shift, const uint32_t *gbase, uint32_t *status,
+                uint32_t *ticket)
+{
+  __shared__ uint32_t cnt[GTS_SW][256];
+  __shared__ K s_key[(GTS_SB * ITEMS)];
+  __shared__ uint32_t s_goff[256];
+  __shared__ uint32_t s_wsum[4];
+  __shared__ uint32_t s_tile;
+  const uint32_t lane = gts_lane(), w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  for (uint32_t i = threadIdx.x; i < GTS_SW * 256; i += GTS_SB) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint64_t tbase = (uint64_t)tile * (GTS_SB * ITEMS);
+  const uint64_t wbase = tbase + (uint64_t)w * (ITEMS * GTS_WAVE);
+  K key[ITEMS];
+  uint32_t val[ITEMS], rank[ITEMS];
   const uint64_t lt = gts_lanemask_lt();
 #pragma unroll
-  for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
     const bool valid = idx < n;
     key[i] = valid ? keys[idx] : (K)0;
     val[i] = valid ? vals[idx] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
+    const bool valid = idx < n;
     const uint32_t d = gts_digit(key[i], shift);
     uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const uint64_t bm = __builtin_amdgcn_ballot_w64(valid && ((d >> b) & 1u));
+      const uint64_t bm = __builtin_amdgcn_ballot_w64((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? bm : ~bm;
     }
     uint32_t prev = 0;
@@ -201,138 +287,113 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
     rank[i] = prev + (uint32_t)__popcll(peers & lt);
   }
   __syncthreads();
-  if constexpr (sizeof(K) > 4) {
-    /* 64-bit keys: as below, but keys and values take turns in the same
-       32 KB of LDS (both at once would cost a third of the resident waves) */
-    __shared__ K s_key[GTS_SORT_TILE];
-    __shared__ uint32_t s_goff[256];
-    uint32_t *s_val = (uint32_t *)s_key;
-    {
-      const uint32_t d = threadIdx.x;
-      uint32_t run = 0;
+  {
+    /* thread d < 256: per-wave counts of digit d -> starts inside the digit's
+       run; digit totals -> start of the run in the tile (scan over 256 digits
+       by the first four wavefronts) */
+    const uint32_t d = threadIdx.x;
+    uint32_t run = 0;
+    if (d < 256) {
 #pragma unroll
-      for (int i = 0; i < GTS_BLOCK / GTS_WAVE; ++i) {
+      for (int i = 0; i < GTS_SW; ++i) {
         const uint32_t c = cnt[i][d];
         cnt[i][d] = run;
         run += c;
       }
-      uint32_t total;
-      const uint32_t lbase = gts_block_exscan<uint32_t>(run, total);
-#pragma unroll
-      for (int i = 0; i < GTS_BLOCK / GTS_WAVE; ++i) cnt[i][d] += lbase;
-      s_goff[d] = offs[(uint64_t)d * ntiles + blockIdx.x] - lbase;
     }
+    uint32_t inc = run;
+#pragma unroll
+    for (int off = 1; off < GTS_WAVE; off <<= 1) {
+      const uint32_t o = __shfl_up(inc, off);
+      if (lane >= (uint32_t)off) inc += o;
+    }
+    if (d < 256 && lane == GTS_WAVE - 1) s_wsum[w] = inc;
     __syncthreads();
+    if (d < 256) {
+      uint32_t lbase = inc - run;
+      for (uint32_t i = 0; i < w; ++i) lbase += s_wsum[i];
 #pragma unroll
-    for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
-      const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
-      if (idx < n) s_key[cnt[w][gts_digit(key[i], shift)] + rank[i]] = key[i];
+      for (int i = 0; i < GTS_SW; ++i) cnt[i][d] += lbase;
+      s_goff[d] = gts_lookback(status, tile, d, run, gbase[d]) - lbase;
     }
-    __syncthreads();
-    const uint64_t tbase = (uint64_t)blockIdx.x * GTS_SORT_TILE;
-    const uint32_t tcount = n - tbase < GTS_SORT_TILE ? (uint32_t)(n - tbase) : (uint32_t)GTS_SORT_TILE;
-    uint32_t dst[GTS_SORT_ITEMS];
+  }
+  __syncthreads();
 #pragma unroll
-    for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
-      const uint32_t t = threadIdx.x + (uint32_t)i * GTS_BLOCK;
-      if (t < tcount) {
-        const K k = s_key[t];
-        dst[i] = s_goff[gts_digit(k, shift)] + t;
-        okeys[dst[i]] = k;
-      }
+  for (int i = 0; i < ITEMS; ++i) {
+    const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
+    if (idx < n) {
+      rank[i] += cnt[w][gts_digit(key[i], shift)];   /* position inside the tile */
+      s_key[rank[i]] = key[i];
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  const uint32_t tcount = n - tbase < (GTS_SB * ITEMS) ? (uint32_t)(n - tbase) : (uint32_t)(GTS_SB * ITEMS);
+  uint32_t dst[ITEMS];
 #pragma unroll
-    for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
-      const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
-      if (idx < n) s_val[cnt[w][gts_digit(key[i], shift)] + rank[i]] = val[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
-      const uint32_t t = threadIdx.x + (uint32_t)i * GTS_BLOCK;
-      if (t < tcount) ovals[dst[i]] = s_val[t];
-    }
-  } else {
-    /* 32-bit keys: the tile is first put in digit order in LDS, then written
-       out by consecutive threads: elements of one digit go to consecutive
-       addresses, so every run of a digit is written as whole lines instead of
-       one store per lane into 64 different lines. */
-    __shared__ K s_key[GTS_SORT_TILE];
-    __shared__ uint32_t s_val[GTS_SORT_TILE];
-    __shared__ uint32_t s_goff[256];
-    {
-      /* thread d: per-wave counts of digit d -> starts inside the digit's run;
-         digit totals -> start of the run in the tile (block scan) */
-      const uint32_t d = threadIdx.x;
-      uint32_t run = 0;
-#pragma unroll
-      for (int i = 0; i < GTS_BLOCK / GTS_WAVE; ++i) {
-        const uint32_t c = cnt[i][d];
-        cnt[i][d] = run;
-        run += c;
-      }
-      uint32_t total;
-      const uint32_t lbase = gts_block_exscan<uint32_t>(run, total);
-#pragma unroll
-      for (int i = 0; i < GTS_BLOCK / GTS_WAVE; ++i) cnt[i][d] += lbase;
-      s_goff[d] = offs[(uint64_t)d * ntiles + blockIdx.x] - lbase;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < GTS_SORT_ITEMS; ++i) {
-      const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
-      if (idx < n) {
-        const uint32_t d = gts_digit(key[i], shift);
-        const uint32_t pos = cnt[w][d] + rank[i];
-        s_key[pos] = key[i];
-        s_val[pos] = val[i];
-      }
-    }
-    __syncthreads();
-    const uint64_t tbase = (uint64_t)blockIdx.x * GTS_SORT_TILE;
-    const uint32_t tcount = n - tbase < GTS_SORT_TILE ? (uint32_t)(n - tbase) : (uint32_t)GTS_SORT_TILE;
-    for (uint32_t t = threadIdx.x; t < tcount; t += GTS_BLOCK) {
+  for (int i = 0; i < ITEMS; ++i) {
+    const uint32_t t = threadIdx.x + (uint32_t)i * GTS_SB;
+    if (t < tcount) {
       const K k = s_key[t];
-      const uint32_t dst = s_goff[gts_digit(k, shift)] + t;
-      okeys[dst] = k;
-      ovals[dst] = s_val[t];
+      dst[i] = s_goff[gts_digit(k, shift)] + t;
+      okeys[dst[i]] = k;
     }
+  }
+  __syncthreads();
+  uint32_t *s_val = (uint32_t *)s_key;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
+    if (idx < n) s_val[rank[i]] = val[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const uint32_t t = threadIdx.x + (uint32_t)i * GTS_SB;
+    if (t < tcount) ovals[dst[i]] = s_val[t];
   }
 }
 
-static inline uint64_t gts_sort_tiles(uint64_t n)
+static inline uint64_t gts_sort_tiles(uint64_t n, int items = 12)
 {
-  return (n + GTS_SORT_TILE - 1) / GTS_SORT_TILE;
+  const uint64_t tile = (uint64_t)GTS_SB * (uint64_t)items;
+  return (n + tile - 1) / tile;
 }
-/* u32 elements of scratch needed by gts_radix_sort (histogram + scan tmp) */
+#define GTS_SORT_MAX_PASSES 8
+/* u32 elements of scratch needed by gts_radix_sort: per pass the look-back
+   entries of every tile, the digit histograms of all passes, a ticket per pass */
 static inline uint64_t gts_sort_tmp_elems(uint64_t n)
 {
-  const uint64_t h = 256 * gts_sort_tiles(n);
-  return h + gts_scan_tmp_elems(h) + 8;
+  return (256 * gts_sort_tiles(n) + 256 + 1) * GTS_SORT_MAX_PASSES + 64;
 }
 
-/* Stable sort of n pairs on key bits [shift0 + 8*i) for the given digit
-   shifts.  Ping-pongs between (k0, v0) and (k1, v1); returns 0 if the result
-   is in (k0, v0), 1 if in (k1, v1). */
+/* Stable sort of n (< 2^30) pairs on key bits [shift0 + 8*i) for the given
+   digit shifts (at most GTS_SORT_MAX_PASSES).  Ping-pongs between (k0, v0) and
+   (k1, v1); returns 0 if the result is in (k0, v0), 1 if in (k1, v1), -1 if n
+   is too large. */
 template <typename K>
 static int gts_radix_sort(K *k0, uint32_t *v0, K *k1, uint32_t *v1, uint64_t n,
                           const int *shifts, int npasses, uint32_t *tmp,
                           hipStream_t st)
 {
   if (n == 0) return 0;
-  const uint32_t ntiles = (uint32_t)gts_sort_tiles(n);
-  uint32_t *hist = tmp;
-  uint32_t *scan_tmp = tmp + 256ull * ntiles;
+  if (n >= GTS_ONESWEEP_MAX_N || npasses > GTS_SORT_MAX_PASSES) return -1;
+  const uint32_t ntiles = (uint32_t)gts_sort_tiles(n, GtsSortItems<K>::value);
+  uint32_t *ghist = tmp;                                   /* [npasses][256] */
+  uint32_t *ticket = ghist + 256 * GTS_SORT_MAX_PASSES;    /* [npasses] */
+  uint32_t *status = ticket + 64;                          /* [npasses][ntiles][256] */
+  hipMemsetAsync(tmp, 0, (256ull * GTS_SORT_MAX_PASSES + 64 + 256ull * ntiles * npasses) * 4, st);
+  int sh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = 0; p < npasses; ++p) sh[p] = shifts[p];
+  const uint32_t hgrid = ntiles < 4096 ? ntiles : 4096;
+  k_onesweep_hist<K><<<hgrid, GTS_BLOCK, 0, st>>>(k0, n, ghist, npasses, sh[0], sh[1], sh[2], sh[3],
+                                                  sh[4], sh[5], sh[6], sh[7]);
+  k_onesweep_bases<<<npasses, GTS_BLOCK, 0, st>>>(ghist);
   int cur = 0;
   for (int p = 0; p < npasses; ++p) {
     K *ki = cur ? k1 : k0, *ko = cur ? k0 : k1;
     uint32_t *vi = cur ? v1 : v0, *vo = cur ? v0 : v1;
-    k_radix_hist<K><<<ntiles, GTS_BLOCK, 0, st>>>(ki, n, shifts[p], hist, ntiles);
-    gts_exscan<uint32_t, uint32_t>(hist, hist, 256ull * ntiles, scan_tmp,
-                                   (uint32_t *)nullptr, st);
-    k_radix_scatter<K><<<ntiles, GTS_BLOCK, 0, st>>>(ki, vi, ko, vo, n, shifts[p],
-                                                     hist, ntiles);
+    k_radix_scatter<K, GtsSortItems<K>::value><<<ntiles, GTS_SB, 0, st>>>(ki, vi, ko, vo, n, shifts[p], ghist + 256 * p,
+                                                     status + 256ull * ntiles * p, ticket + p);
     cur ^= 1;
   }
   return cur;

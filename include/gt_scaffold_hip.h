@@ -45,7 +45,7 @@ enum {
   GTSG_EHIP = -2,      /* HIP runtime error */
   GTSG_ENOMEM = -3,
   GTSG_EWALK = -4,     /* a walk exceeded its pop bound (cyclic distance maps) */
-  GTSG_ELIMIT = -5     /* more than 2^31-1 contigs or 2^32-2 edges */
+  GTSG_ELIMIT = -5     /* 2^31 contigs, 2^29 records or 2^30 edges, or more */
 };
 
 /* Engine bound to HIP device `device`.  `stream` is a hipStream_t (NULL: the

@@ -515,3 +515,61 @@ def test_50M_contig_repeat_rich_graph():
     eng.set_option("class_streams", 1)
     bench.run_step(eng, g)
     assert eng.digest() == d0
+
+
+def test_pair_sort_is_stable():
+    """equal keys keep file order through every pass of the one-sweep radix sort:
+    200 000 records over 300 contig pairs, std_dev drawn from four values, so
+    which record of a pair wins a direction (the FIRST with the largest std_dev,
+    ref parser.c:362) and which creates the edges depends on the order of records
+    with equal pair keys; tiles of 4096 records, so every pair spans many tiles
+    and the look-back chain is exercised."""
+    rng = np.random.default_rng(11)
+    n, k = 1000, 200_000
+    a = rng.integers(0, n, 300).astype(np.uint32); b = rng.integers(0, n, 300).astype(np.uint32)
+    pick = rng.integers(0, 300, k)
+    flip = rng.random(k) < 0.5
+    g = dict(seq_len=np.full(n, 1000, np.uint64), astat=np.full(n, 50, np.float32),
+             copy_num=np.ones(n, np.float32),
+             root=np.where(flip, b[pick], a[pick]).astype(np.uint32),
+             ctg=np.where(flip, a[pick], b[pick]).astype(np.uint32),
+             dist=rng.integers(-90, 5000, k).astype(np.int64),
+             std_dev=rng.choice(np.array([1.0, 2.5, 2.5, 7.0], np.float32), k),
+             num_pairs=rng.integers(1, 100, k).astype(np.uint64),
+             flags=rng.integers(0, 4, k).astype(np.uint8))
+    og = oracle_from_inputs(g)
+    eng = engine_from_inputs(g)
+    assert_same_graph(eng, og)
+    # and with the never-replace rule of a mate-pair library (parser.c:297, :362)
+    og2 = OracleGraph.from_records(g["seq_len"], g["astat"], g["copy_num"], g["root"], g["ctg"], g["dist"],
+                                   g["std_dev"], g["num_pairs"], g["flags"], ismatepair=True)
+    eng2 = pkg.engine.Engine(0)
+    eng2.set_contigs(g["seq_len"].astype(np.int64), g["astat"], g["copy_num"])
+    eng2.build_from_records(g["root"], g["ctg"], g["dist"], g["std_dev"], g["num_pairs"].astype(np.int64),
+                            g["flags"], ismatepair=True)
+    assert_same_graph(eng2, og2)
+    assert not np.array_equal(eng.edges()["dist"], eng2.edges()["dist"])
+
+
+def test_contig_ids_out_of_range_are_rejected():
+    g = make_inputs(500, 3)
+    eng = pkg.engine.Engine(0)
+    eng.set_contigs(g["seq_len"].astype(np.int64), g["astat"], g["copy_num"])
+    bad = g["ctg"].copy(); bad[len(bad) // 2] = 500
+    with pytest.raises(pkg.engine.EngineError, match="out of range"):
+        eng.build_from_records(g["root"], bad, g["dist"], g["std_dev"], g["num_pairs"].astype(np.int64), g["flags"])
+    lab = np.arange(500, dtype=np.uint32)
+    with pytest.raises(pkg.engine.EngineError, match="out of range"):
+        eng.label_components(500, g["root"], bad, np.zeros(500, np.uint8), lab)
+    # the engine is still usable
+    eng.build_from_records(g["root"], g["ctg"], g["dist"], g["std_dev"], g["num_pairs"].astype(np.int64), g["flags"])
+    assert eng.ne > 0
+
+
+def test_hub_degree_set_after_build_does_not_change_the_filter():
+    g = make_inputs(4000, 11, p_repeat=0.02, repeat_degree=300, p_chimeric=0.05, p_repeat_unmarked=0.3)
+    og = oracle_from_inputs(g)
+    eng = engine_from_inputs(g)
+    eng.set_option("hub_degree", 4)        # takes effect at the next build
+    og.mark_repeats(); eng.mark_repeats(); og.filter(); eng.filter()
+    assert_same_states(eng, og, "filter")
