@@ -415,6 +415,26 @@ def test_full_size_properties():
             del vs, es, ee
         del eng
     assert digests[0] == digests[1] == digests[2]
+    # the slow path at full size: 10 % of the false links are inversions and
+    # repeated pairs are kept, so components holding them leave the linear walks
+    # for the reference's label-correcting search (create_walk_reference) -- in
+    # the component programs, in the walk tasks and in the select pass.  Two
+    # decompositions, one digest.
+    del g
+    torch.cuda.empty_cache()
+    gen = dict(bench.WORKLOAD["gen"], p_inversion=0.1, unique_pairs=False)
+    g = bench.make_inputs(pkg, n, 1234, "cuda:0", gen)
+    g["num_pairs"] = g["num_pairs"].to(torch.int64)
+    slow = []
+    for opts in (dict(), dict(defer_min_contigs=0, class_streams=1)):
+        eng = pkg.engine.Engine(0)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        bench.run_step(eng, g)
+        slow.append((eng.digest(), eng.stat("slow_walks")))
+        del eng
+    assert slow[0][0] == slow[1][0] and slow[0][1] > 0 and slow[1][1] > 0, slow
+    del g
     # the oracle on a sample of the same generator
     gs = make_inputs(100000, 99, **bench.WORKLOAD["gen"])
     eng, og = run_pipeline(gs, pcutoff=bench.CUTS["pcutoff"], cncutoff=bench.CUTS["cncutoff"],
