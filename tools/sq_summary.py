@@ -27,19 +27,22 @@ def short(name):
 
 def main():
     out, dirs = sys.argv[1], sys.argv[2:]
-    per = defaultdict(lambda: defaultdict(float))
-    launches = defaultdict(lambda: defaultdict(int))
+    # a counter collected in several passes (SQ_WAVES, SQ_WAVE_CYCLES go into every
+    # pass as the denominators) is averaged over the passes that hold it
+    per_pass = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
+    launches = defaultdict(lambda: defaultdict(lambda: defaultdict(int)))
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 k = short(row["Kernel_Name"])
                 c = row["Counter_Name"]
-                per[k][c] += float(row["Counter_Value"])
-                launches[k][c] += 1
+                per_pass[k][c][d] += float(row["Counter_Value"])
+                launches[k][c][d] += 1
     res = {}
-    for k, cs in per.items():
+    for k, byc in per_pass.items():
+        cs = {c: sum(v.values()) / len(v) for c, v in byc.items()}
         r = dict(cs)
-        r["launches"] = max(launches[k].values())
+        r["launches"] = max(max(v.values()) for v in launches[k].values())
         w, wc = cs.get("SQ_WAVES"), cs.get("SQ_WAVE_CYCLES")
         if w and wc:
             r["cycles_per_wave"] = wc * 4 / w
