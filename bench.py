@@ -58,8 +58,8 @@ CUTS = dict(copy_num_cutoff=0.3, astat_cutoff=20.0, pcutoff=0.01, cncutoff=1.5, 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 
 
-# dynamic LDS of the component launches (gts_engine.hip, gts_klass_bytes)
-LDS_CLASSES_KB = (4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 160)
+# the engine's LDS size classes (gts_engine.hip): up to eleven, read back as statistics
+MAX_LDS_CLASSES = 11
 
 
 def algorithmic_bytes(name, n, m, nrec, eng):
@@ -89,7 +89,7 @@ def algorithmic_bytes(name, n, m, nrec, eng):
     if name == "k_components":
         return max(eng.stat("bytes_components_global_mem"), 0)
     if name == "k_components_lds":        # all size classes: bytes of ONE step's launches
-        return sum(max(eng.stat("bytes_components_lds_class%d" % i), 0) for i in range(len(LDS_CLASSES_KB)))
+        return sum(max(eng.stat("bytes_components_lds_class%d" % i), 0) for i in range(MAX_LDS_CLASSES))
     if name == "k_walk_tasks":            # every task stages its component once; one step's launches
         return max(eng.stat("bytes_walk_tasks"), 0)
     return table.get(name)
@@ -388,8 +388,10 @@ def main():
                    component_kernel=dict(
                        walks_fast=eng.stat("fast_walks"), walks_reference=eng.stat("slow_walks"),
                        clean_components=eng.stat("clean_components"),
-                       components_per_lds_class={"%dk" % kb: eng.stat("components_lds_class%d" % i)
-                                                 for i, kb in enumerate(LDS_CLASSES_KB)},
+                       components_per_lds_class={"%dk" % eng.stat("lds_class%d_kb" % i):
+                                                 eng.stat("components_lds_class%d" % i)
+                                                 for i in range(MAX_LDS_CLASSES)
+                                                 if eng.stat("lds_class%d_kb" % i) > 0},
                        components_global_mem=eng.stat("components_global_mem"),
                        **{k: eng.stat(k) for k in
                           ("us_sum_removecycles", "us_max_removecycles", "us_sum_makescaffold_other",

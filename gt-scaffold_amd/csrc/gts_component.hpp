@@ -91,6 +91,8 @@ struct GtsCompView {
      task per terminal, k_walk_tasks runs every walk on its own wavefront,
      the select pass keeps the best walk of every cc (gts_engine.hip) */
   uint32_t defer_min_nv;     /* 0: never defer */
+  uint64_t defer_min_work;   /* defer only if terminals x contigs reaches this: the walks of a
+                                component cost about that many vertex steps when made in place */
   uint8_t *defer_flag;       /* ncomp */
   uint32_t *comp_task0, *comp_ncc, *comp_nterm;   /* ncomp */
   unsigned long long *ntasks, *path_used;         /* device counters */
@@ -322,6 +324,13 @@ struct GtsComponent {
   static GTS_HD int64_t uni_t(int64_t v) { return W::uni64(v); }
   static GTS_HD uint64_t uni_t(uint64_t v) { return (uint64_t)W::uni64((int64_t)v); }
   GTS_HD uint32_t eoff(uint32_t ls) const { return W::uni(M.coff[ls]) - M.e0; }
+  /* flags (low nibble) and state (high nibble) of a compact edge; the packed
+     LDS layout keeps them in one byte */
+  GTS_HD uint32_t edge_bits(uint32_t ce) const
+  {
+    if constexpr (LDS) return *(M.cflags.b + ce);
+    else return (uint32_t)(M.cflags[ce] & 15u) | ((uint32_t)M.cstate[ce] << 4);
+  }
   /* walk_task: the vertices a search labels (see try_defer) */
   GTS_HD void note_labelled(uint32_t v) const
   {
@@ -387,22 +396,22 @@ struct GtsComponent {
             const bool ou = ORIENT && W::bcast(my_o, i) == 2;
             bool has_s = false, has_a = false;
             for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+              /* straight-line (see create_walk_clean): every lane loads, a lane
+                 past the list reads the list's first edge */
               const uint32_t ce = base + lane;
-              bool live = false, sense = false, unv = false;
-              uint32_t nb = 0;
+              const bool in = ce < ee;
+              const uint32_t cec = in ? ce : eb;
+              const uint32_t fl = edge_bits(cec);
+              const bool live = in && !gts_edge_is_marked((uint8_t)(fl >> 4));
+              const bool sense = (fl & GTS_F_SENSE) != 0;
+              const uint32_t nb = M.cend[cec];
+              const bool unv = live && M.vst[nb] == GIS_UNVISITED;
               bool clash = false;
-              if (ce < ee) {
-                const uint32_t fl = M.cflags[ce];
-                live = !gts_edge_is_marked(M.cstate[ce]);
-                sense = (fl & GTS_F_SENSE) != 0;
-                nb = M.cend[ce];
-                unv = live && M.vst[nb] == GIS_UNVISITED;
-                if (ORIENT) {   /* as orient(): every compact edge, whatever the end's state */
-                  const uint32_t ov = (gts_next_dir((uint8_t)fl) != (sense != ou)) ? 2u : 1u;
-                  const uint32_t co = M.gorient[nb];
-                  clash = (fl & GTS_F_UTURN) || nb == cur || (co != 0 && co != ov);
-                  if (co == 0) M.gorient[nb] = (uint8_t)ov;
-                }
+              if (ORIENT) {   /* as orient(): every compact edge, whatever the end's state */
+                const uint32_t ov = (gts_next_dir((uint8_t)fl) != (sense != ou)) ? 2u : 1u;
+                const uint32_t co = M.gorient[nb];
+                clash = in && ((fl & GTS_F_UTURN) || nb == cur || (co != 0 && co != ov));
+                if (in && co == 0) M.gorient[nb] = (uint8_t)ov;
               }
               if (ORIENT && W::ballot(clash)) oriented = false;
               has_s |= W::ballot(live && sense) != 0;
@@ -1303,17 +1312,15 @@ struct GtsComponent {
         const bool ou = W::bcast(my_o, i) == 2;
         for (uint32_t base = eb; base < ee; base += W::WIDTH) {
           const uint32_t ce = base + lane;
-          bool fresh = false, clash = false;
-          uint32_t v = 0, ov = 0;
-          if (ce < ee) {
-            const uint32_t fl = M.cflags[ce];
-            const bool sense = (fl & GTS_F_SENSE) != 0;
-            v = M.cend[ce];
-            ov = (gts_next_dir((uint8_t)fl) != (sense != ou)) ? 2u : 1u;
-            const uint32_t cur = M.gorient[v];
-            clash = (fl & GTS_F_UTURN) || v == u || (cur != 0 && cur != ov);
-            fresh = cur == 0;
-          }
+          const bool in = ce < ee;
+          const uint32_t cec = in ? ce : eb;
+          const uint32_t fl = edge_bits(cec);
+          const bool sense = (fl & GTS_F_SENSE) != 0;
+          const uint32_t v = M.cend[cec];
+          const uint32_t ov = (gts_next_dir((uint8_t)fl) != (sense != ou)) ? 2u : 1u;
+          const uint32_t cur = M.gorient[v];
+          const bool clash = in && ((fl & GTS_F_UTURN) || v == u || (cur != 0 && cur != ov));
+          const bool fresh = in && cur == 0;
           if (W::ballot(clash)) { bad = true; break; }
           const uint64_t fm = W::ballot(fresh);
           if (fresh) {
@@ -1332,9 +1339,9 @@ struct GtsComponent {
   /* arc of D seen from its tail x (forward) or from its head (!forward) */
   GTS_HD bool d_arc(uint32_t ce, bool ox, bool forward) const
   {
-    const uint32_t fl = M.cflags[ce];
+    const uint32_t fl = edge_bits(ce);
     return (((fl & GTS_F_SENSE) != 0) == ox) == forward &&
-           (!gts_edge_is_marked(M.cstate[ce]) || (fl & GTS_F_TWINLIVE));
+           (!gts_edge_is_marked((uint8_t)(fl >> 4)) || (fl & GTS_F_TWINLIVE));
   }
 
   /* Topological order of D for an oriented component (topo / tpos); true if
@@ -1388,14 +1395,13 @@ struct GtsComponent {
           const bool ou = (W::bcast(my_g, i) & 3u) == 2;
           for (uint32_t base = eb; base < ee; base += W::WIDTH) {
             const uint32_t ce = base + lane;
-            bool ready = false;
-            uint32_t v = 0;
-            if (ce < ee && d_arc(ce, ou, fwd)) {   /* out-arcs when peeling sources */
-              v = M.cend[ce];
-              const uint32_t d = deg[v] - 1;
-              deg[v] = d;
-              ready = d == 0;
-            }
+            const bool in = ce < ee;
+            const uint32_t cec = in ? ce : eb;
+            const bool arc = in && d_arc(cec, ou, fwd);   /* out-arcs when peeling sources */
+            const uint32_t v = M.cend[cec];
+            const uint32_t d = deg[v] - 1;
+            if (arc) deg[v] = d;
+            const bool ready = arc && d == 0;
             const uint64_t rm = W::ballot(ready);
             if (ready) Qp[tn + W::popc_below(rm, lane)] = v;
             tn += W::popc(rm);
@@ -1469,30 +1475,31 @@ struct GtsComponent {
       const uint32_t eb = eoff(u), ee = eoff(u + 1);
       bool us = false, ua = false;
       for (uint32_t base = eb; base < ee && !bad; base += W::WIDTH) {
+        /* straight-line: every lane loads (a lane past the list reads the
+           list's first edge) and the predicates are values, so there is one
+           predicated region -- the stores -- instead of three nested ones */
         const uint32_t ce = base + lane;
-        bool live = false, sense = false, arc = false, tie = false, fresh = false;
-        uint32_t v = 0;
-        if (ce < ee) {
-          live = !gts_edge_is_marked(M.cstate[ce]);
-          sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
-          arc = live && sense == du;
-          if (arc) {
-            v = M.cend[ce];
-            const nd_t w = (nd_t)M.cdist[ce];
-            const float cand = (float)(ndu + w);
-            const float old = M.distmap[v];
-            if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
-            if (old == GTS_DIST_UNSET || old > cand) {
-              fresh = old == GTS_DIST_UNSET;
-              M.distmap[v] = cand;
-              M.edgemap[v] = ce;
-              M.par[v] = u;
-              M.nd[v] = u == start ? w : (nd_t)cand;
-              M.plen[v] = (len_t)(plu + (len_t)M.cseq[v]);
-              depth[v] = dpu + 1;
-            } else if (old == cand)
-              tie = true;
-          }
+        const bool in = ce < ee;
+        const uint32_t cec = in ? ce : eb;
+        const uint32_t fs = edge_bits(cec);
+        const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+        const bool sense = (fs & GTS_F_SENSE) != 0;
+        const bool arc = live && sense == du;
+        const uint32_t v = M.cend[cec];
+        const nd_t w = (nd_t)M.cdist[cec];
+        const float cand = (float)(ndu + w);
+        const float old = M.distmap[v];
+        const bool imp = arc && (old == GTS_DIST_UNSET || old > cand);
+        const bool tie = arc && !imp && old == cand;
+        const bool fresh = imp && old == GTS_DIST_UNSET;
+        inexact |= arc && !(cand > -16777216.0f && cand < 16777216.0f);
+        if (imp) {
+          M.distmap[v] = cand;
+          M.edgemap[v] = ce;
+          M.par[v] = u;
+          M.nd[v] = u == start ? w : (nd_t)cand;
+          M.plen[v] = (len_t)(plu + (len_t)M.cseq[v]);
+          depth[v] = dpu + 1;
         }
         us |= W::ballot(live && sense) != 0;
         ua |= W::ballot(live && !sense) != 0;
@@ -1705,6 +1712,7 @@ struct GtsComponent {
     const uint32_t lane = W::lane();
     if (!C.defer_min_nv || nv < C.defer_min_nv) return false;
     if (nterm < 2) { nodefer = 2; return false; }
+    if ((uint64_t)nterm * nv < C.defer_min_work) { nodefer = 1; return false; }
     auto ccoff = M.ccoff;
     uint32_t npend = 0;
     for (uint32_t i = 0; i < ncc; ++i) {

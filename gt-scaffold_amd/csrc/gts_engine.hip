@@ -43,6 +43,7 @@ static const char *const gts_klass_event[2][GTS_NKLASS] = {
    "components_makescaffold_lds32k", "components_makescaffold_lds48k", "components_makescaffold_lds64k",
    "components_makescaffold_lds96k", "components_makescaffold_lds160k"}};
 #define GTS_NSTREAMS 6
+static const char *klass_event(int makescaffold, uint32_t bytes);
 /* device scalars of the class bookkeeping (u32 index into d_scalars, 16 entries each) */
 #define GTS_S_KSIZE 256
 #define GTS_S_KCOUNT 272
@@ -51,6 +52,13 @@ static const char *const gts_klass_event[2][GTS_NKLASS] = {
 #define GTS_S_TQBASE 336
 #define GTS_S_TQCNT 352    /* u64 */
 #define GTS_S_NDEF 384     /* u64 */
+
+static const char *klass_event(int makescaffold, uint32_t bytes)
+{
+  for (int k = 0; k < GTS_NKLASS; ++k)
+    if (gts_klass_bytes[k] == bytes) return gts_klass_event[makescaffold ? 1 : 0][k];
+  return makescaffold ? "components_makescaffold_lds" : "components_removecycles_lds";
+}
 
 #include "../../include/gt_scaffold_hip.h"
 #include "gts_amb_host.h"
@@ -98,10 +106,27 @@ struct GtsgEngine {
   /* options */
   int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
   int64_t walk_pool_entries = 1ll << 26;
-  int64_t class_streams = GTS_NSTREAMS;
+  int64_t class_streams = 6;
+
   int64_t mixed_task_limit = 256;
   int64_t defer_min_contigs = 256, walk_path_entries = 1ll << 24;
+  /* terminals x contigs from which a component's walks fan out.  Made in place
+     they take about 0.12 us per vertex step; a round of tasks costs ~0.5 ms of
+     launches and host round trips, and a component's walks are all its
+     wavefront has to do while the other classes keep the GPU busy.  On the
+     10 M workload (largest component 1012 contigs, at most 72 terminals) no
+     deferral at all is fastest: 55.8 ms per step against 60.0 with every
+     component of 256 contigs deferred (gpurun_out/r02m) */
+  int64_t defer_min_work = 1ll << 17;
   int64_t fast_walks = 1, lds_components = 1;
+  /* walks of global-memory components fan out only on request: the components
+     that end up there on the 50 M workload are scaffolds tied together by an
+     unmarked hub, where every accepted cc revives an arc out of the hub and
+     makes the later ccs' walks stale -- 125 rounds instead of 24, 895 instead
+     of 732 ms per step (gpurun_out/r02l) */
+  int64_t defer_global_components = 0;
+  int64_t global_task_pool_mb = 2048;   /* scratch slabs of the walks deferred from global-memory components */
+  char *gtask_pool = nullptr;
   int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
   /* profiling */
   struct Pending { const char *name; hipEvent_t a, b; };
@@ -952,11 +977,15 @@ struct GtsWave64 {
    LDS footprint, [first, first + count) is the slice of this launch.
    Global-memory variant: any component size. */
 __global__ void __launch_bounds__(GTS_WAVE)
-k_components(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode)
+k_components(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
+             int defer_global)
 {
   if (blockIdx.x >= count) return;
   const uint32_t c = order[first + blockIdx.x];
-  C.defer_min_nv = 0;   /* deferred walks are staged in LDS: not for this class */
+  /* a component of this class defers its walks only on request (option
+     "defer_global_components"): its tasks run from global memory,
+     k_walk_tasks_global */
+  if (!defer_global) C.defer_min_nv = 0;
   const GtsCompMem M = GtsComponent<GtsWave64>::global_mem(C, c);
   GtsComponent<GtsWave64> prog(C, M, c);
   prog.run(mode);
@@ -1068,6 +1097,42 @@ k_walk_tasks_mixed(GtsCompView C, GtsTaskPrefix P)
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.walk_task(t);
 }
+/* Deferred walks of the components that run from global memory (too large or
+   too wide for the LDS layout): one wavefront per pending walk, the
+   component's graph, vertex states and analysis read in place (nothing writes
+   them during a round), the walk's scratch in a slab of its own -- the
+   component's scratch arrays in the workspace are one set, and the walks of a
+   component run side by side.  bytes per vertex of a slab: GTS_SLAB_BYTES. */
+#define GTS_SLAB_BYTES 72u
+__global__ void __launch_bounds__(GTS_WAVE)
+k_walk_tasks_global(GtsCompView C, uint32_t klass, uint32_t first, uint32_t count, char *slabs,
+                    uint64_t slab_stride)
+{
+  if (blockIdx.x >= count) return;
+  const uint32_t t = C.tq[C.tq_base[klass] + first + blockIdx.x];
+  const uint32_t c = C.task_comp[t];
+  GtsCompMem M = GtsComponent<GtsWave64>::global_mem(C, c);
+  const uint32_t nv = M.nv, lane = threadIdx.x;
+  const uint64_t nva = ((uint64_t)nv + 3) & ~3ull;   /* keeps every array 8-byte aligned */
+  char *p = slabs + (uint64_t)blockIdx.x * slab_stride;
+  M.nd = (int64_t *)p; p += nva * 8;
+  M.plen = (uint64_t *)p; p += nva * 8;
+  uint32_t *u = (uint32_t *)p;
+  M.queue = u; u += nva; M.visited = u; u += nva; M.st_v = u; u += nva; M.st_par = u; u += nva;
+  M.st_cur = u; u += nva; M.edgemap = u; u += nva; M.par = u; u += nva; M.lastpop = u; u += nva;
+  M.wterm = u; u += nva; M.touched = u; u += nva; M.cc_best = u; u += nva;
+  M.distmap = (float *)u; u += nva;
+  uint8_t *b = (uint8_t *)u;
+  M.st_dir = b; b += nva; M.tight = b;
+  /* what the component's own arrays guarantee between walks (the rest is
+     written before it is read; walk_task clears st_dir, tight and the position
+     bitmap in st_cur) */
+  for (uint32_t s = lane; s < nv; s += GTS_WAVE) { M.distmap[s] = GTS_DIST_UNSET; M.lastpop[s] = 0; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  GtsComponent<GtsWave64> prog(C, M, c);
+  prog.walk_task(t);
+}
+
 __global__ void __launch_bounds__(GTS_WAVE)
 k_select_walks(GtsCompView C, uint32_t ndeferred)
 {
@@ -1306,7 +1371,8 @@ void gtsg_destroy(GtsgEngine *e)
   hipStreamSynchronize(e->st);
   collect_times(e);
   free_graph(e, true);
-  void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->vtime, e->pool, e->d_scalars};
+  void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->vtime, e->pool, e->d_scalars,
+                  e->gtask_pool};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto ev : e->free_events) hipEventDestroy(ev);
   for (int k = 0; k < GTS_NSTREAMS; ++k) if (e->side[k]) hipStreamDestroy(e->side[k]);
@@ -1328,9 +1394,13 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "fast_walks")) e->fast_walks = value != 0;
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
+  else if (!strcmp(name, "defer_min_work") && value >= 0) e->defer_min_work = value;
   else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NSTREAMS) e->class_streams = value;
   else if (!strcmp(name, "mixed_task_limit") && value >= 0) e->mixed_task_limit = value;
+
   else if (!strcmp(name, "walk_path_entries") && value >= 1) e->walk_path_entries = value;
+  else if (!strcmp(name, "global_task_pool_mb") && value >= 0) e->global_task_pool_mb = value;
+  else if (!strcmp(name, "defer_global_components")) e->defer_global_components = value != 0;
   else if (!strcmp(name, "profile")) e->profile = (int)value;
   else return fail(e, GTSG_EINVAL, "unknown option %s", name);
   return 0;
@@ -1853,11 +1923,12 @@ static int run_components(GtsgEngine *e, int mode)
            (uint64_t)nslots);
     /* components by decreasing LDS footprint; size classes of the LDS launches */
     const uint32_t *klass_h = gts_klass_bytes;
+    const uint32_t nklass = GTS_NKLASS;
     uint32_t *klass_d = e->d_scalars + GTS_S_KSIZE, *klass_count = e->d_scalars + GTS_S_KCOUNT;
     HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_KSIZE, 0, (GTS_S_NDEF + 4 - GTS_S_KSIZE) * 4, e->st));
-    HIPCHK(hipMemcpyAsync(klass_d, klass_h, sizeof gts_klass_bytes, hipMemcpyHostToDevice, e->st));
+    HIPCHK(hipMemcpyAsync(klass_d, klass_h, nklass * sizeof(uint32_t), hipMemcpyHostToDevice, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
-           ncomp, comp_wide, comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? GTS_NKLASS : 0), klass_count,
+           ncomp, comp_wide, comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? nklass : 0), klass_count,
            (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS);
     LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + GTS_S_KSLOTS, e->d_scalars + GTS_S_TQBASE);
     const uint32_t *order;
@@ -1870,6 +1941,11 @@ static int run_components(GtsgEngine *e, int mode)
     uint64_t kbytes[GTS_NKLASS + 1];
     HIPCHK(hipMemcpyAsync(kcount, klass_count, sizeof kcount, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(kbytes, e->d_scalars + GTS_S_KBYTES, sizeof kbytes, hipMemcpyDeviceToHost, e->st));
+    /* largest component: sizes the scratch slabs of walks deferred from global memory */
+    uint32_t maxcomp = 0;
+    HIPCHK(hipMemsetAsync(e->d_scalars + 7, 0, 4, e->st));
+    LAUNCH("comp_max_size", k_max_u32_diff, nblk(ncomp), GTS_BLOCK, comp_off, ncomp, e->d_scalars + 7);
+    HIPCHK(hipMemcpyAsync(&maxcomp, e->d_scalars + 7, 4, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
     HIPCHK(hipMemsetAsync(e->d_scalars + 12, 0, 16, e->st));
     LAUNCH("comp_max_size", k_max_u32_diff, nblk(ncomp), GTS_BLOCK, comp_off, ncomp,
@@ -1888,6 +1964,7 @@ static int run_components(GtsgEngine *e, int mode)
     C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat; C.stat_clean = stat_clean;
     C.gorient = s_gorient; C.topo = s_topo; C.tpos = s_tpos;
     C.defer_min_nv = mode == GTS_MODE_MAKESCAFFOLD && e->lds_components ? (uint32_t)e->defer_min_contigs : 0u;
+    C.defer_min_work = (uint64_t)e->defer_min_work;
     C.defer_flag = defer_flag; C.comp_task0 = comp_task0; C.comp_ncc = comp_ncc; C.comp_nterm = comp_nterm;
     C.ntasks = (unsigned long long *)(e->d_scalars + 128); C.path_used = (unsigned long long *)(e->d_scalars + 130);
     C.task_bytes = (unsigned long long *)(e->d_scalars + GTS_S_NDEF + 2);
@@ -1907,14 +1984,20 @@ static int run_components(GtsgEngine *e, int mode)
       const char *kname = mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold"
                                                         : "components_removecycles";
       uint32_t first = 0;
-      const uint32_t nk = e->lds_components ? GTS_NKLASS : 0;
+      const uint32_t nk = e->lds_components ? nklass : 0;
+      for (int k = 0; k < GTS_NKLASS; ++k) {
+        e->stats["components_lds_class" + std::to_string(k)] = 0;
+        e->stats["bytes_components_lds_class" + std::to_string(k)] = 0;
+        e->stats["lds_class" + std::to_string(k) + "_kb"] = k < (int)nk ? (int64_t)(klass_h[k] / 1024) : -1;
+      }
       /* profile: the span of the overlapped class launches, fork -> last join,
          as one entry next to the per-launch entries */
       hipEvent_t span_a = nullptr, span_b = nullptr;
       if (e->profile) { span_a = get_event(e); span_b = get_event(e); hipEventRecord(span_a, e->st); }
       HIPCHK(hipEventRecord(e->ev_fork, e->st));
       if (kcount[nk]) {
-        LAUNCH(kname, k_components, kcount[nk], GTS_WAVE, C, order, first, kcount[nk], mode);
+        LAUNCH(kname, k_components, kcount[nk], GTS_WAVE, C, order, first, kcount[nk], mode,
+               (int)e->defer_global_components);
         first += kcount[nk];
       }
       /* the size classes are independent: fork them onto side streams so the
@@ -1931,8 +2014,9 @@ static int run_components(GtsgEngine *e, int mode)
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
         k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode);
         if (e->profile) { hipEventRecord(_b, ss);
-                          e->pending.push_back({gts_klass_event[mode == GTS_MODE_MAKESCAFFOLD][k], _a, _b}); }
+                          e->pending.push_back({klass_event(mode == GTS_MODE_MAKESCAFFOLD, klass_h[k]), _a, _b}); }
         HIPCHK(hipEventRecord(e->ev_join[k], ss));
+
         e->stats["components_lds_class" + std::to_string(k)] = kcount[k];
         first += kcount[k];
       }
@@ -1956,12 +2040,15 @@ static int run_components(GtsgEngine *e, int mode)
         HIPCHK(hipMemcpyAsync(pend, e->d_scalars + GTS_S_TQCNT, sizeof pend, hipMemcpyDeviceToHost, e->st));
         HIPCHK(hipMemcpyAsync(&ndef, e->d_scalars + GTS_S_NDEF, 8, hipMemcpyDeviceToHost, e->st));
         if ((rc = read_u64(e, (uint64_t *)(e->d_scalars + 128), &ntasks))) return rc;
+        const uint64_t slab_stride = ((((uint64_t)maxcomp + 3) & ~3ull) * GTS_SLAB_BYTES + 255) & ~255ull;
         for (;; ++rounds) {
           uint64_t total = 0;
           for (uint32_t k = 0; k < nk; ++k) total += pend[k];
-          if (!total) break;
-          walks_run += total;
-          if (total <= (uint64_t)e->mixed_task_limit) {
+          /* pending walks of components that run from global memory (class nk) */
+          const uint64_t gpend = e->lds_components ? pend[nk] : 0;
+          if (!total && !gpend) break;
+          walks_run += total + gpend;
+          if (total && total <= (uint64_t)e->mixed_task_limit) {
             /* few walks: one launch, no waiting for a queue per class */
             GtsTaskPrefix P;
             uint32_t acc = 0, kmax = 0;
@@ -1979,6 +2066,20 @@ static int run_components(GtsgEngine *e, int mode)
           }
           for (uint32_t k = 0; k < nk; ++k) task_launches += pend[k] != 0;
           HIPCHK(hipEventRecord(e->ev_fork, e->st));
+          if (gpend) {
+            /* on the main stream, next to the class launches on the side streams;
+               as many walks at a time as the slab pool holds */
+            uint64_t cap = ((uint64_t)e->global_task_pool_mb << 20) / slab_stride;
+            if (cap < 1) cap = 1;
+            if (cap > gpend) cap = gpend;
+            if ((rc = dev_alloc(e, &e->gtask_pool, (size_t)(cap * slab_stride)))) return rc;
+            for (uint64_t first = 0; first < gpend; first += cap) {
+              const uint32_t cnt = (uint32_t)(gpend - first < cap ? gpend - first : cap);
+              ++task_launches;
+              LAUNCH("components_walk_tasks_global", k_walk_tasks_global, cnt, GTS_WAVE, C, (uint32_t)nk,
+                     (uint32_t)first, cnt, e->gtask_pool, slab_stride);
+            }
+          }
           for (int k = (int)nk - 1; k >= 0; --k) {
             if (!pend[k]) continue;
             hipStream_t ss = e->side[((int)nk - 1 - k) % (int)e->class_streams];

@@ -161,10 +161,14 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      for every walk), "lds_components" (default 1; 0 runs every component
      from global memory), "defer_min_contigs" (default 256; components with at
      least that many contigs hand their walks to one workgroup per terminal,
-     0 = never), "class_streams" (default 6: side streams the LDS size classes
+     0 = never) and "defer_min_work" (default 2^17: ... and with at least that
+     many terminals x contigs), "class_streams" (default 6: side streams the LDS size classes
      are launched on), "mixed_task_limit" (default 256: a round with at most
      that many pending walks is one launch for all classes), "walk_path_entries" (default 2^24, pool for the tasks' walks;
-     grows by itself like the walk queues) */
+     grows by itself like the walk queues), "defer_global_components" (default 0; 1: components
+     that run from global memory hand their walks out, too),
+     "global_task_pool_mb" (default 2048: scratch slabs of those walks; fewer
+     slabs than pending walks = several launches per round) */
 
 /* per-kernel timing collected with hipEvents on the engine's stream while
    option "profile" is 1.  Fills up to cap entries, returns the number of

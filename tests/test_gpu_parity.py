@@ -164,6 +164,13 @@ def test_values_the_packed_lds_layout_cannot_carry(what):
         g["seq_len"] = g["seq_len"] + (1 << 29)
     eng, _ = run_pipeline(g, ocutoff=400 if what == "distances" else 1 << 40)
     assert eng.stat("components_global_mem") > 0
+    # the same with the walks of those components deferred: tasks that run from
+    # global memory on scratch slabs of their own (k_walk_tasks_global), one
+    # slab at a time and all at once
+    for pool_mb in (0, 64):
+        eng2, _ = run_pipeline(g, ocutoff=400 if what == "distances" else 1 << 40, defer_min_contigs=3,
+                               defer_min_work=0, defer_global_components=1, global_task_pool_mb=pool_mb)
+        assert eng2.stat("walk_tasks") > 0 and eng2.digest() == eng.digest()
 
 
 @pytest.mark.parametrize("seed", range(3))
@@ -173,13 +180,13 @@ def test_deferred_walk_tasks(seed):
     kw = dict(p_chimeric=0.08, p_inversion=0.0, p_bubble=0.05, links_per_side=4,
               unique_pairs=True) if seed else dict(p_chimeric=0.03)
     g = make_inputs(8000, 1200 + seed, **kw)
-    eng, _ = run_pipeline(g, defer_min_contigs=3)
+    eng, _ = run_pipeline(g, defer_min_contigs=3, defer_min_work=0)
     assert eng.stat("walk_tasks") > 0 and eng.stat("walk_task_rounds") >= 1
     eng0, _ = run_pipeline(g, defer_min_contigs=0)
     assert eng0.stat("walk_tasks") == 0
     assert eng.digest() == eng0.digest()
     # a pool too small for any component: every component walks in place
-    eng1, _ = run_pipeline(g, defer_min_contigs=3, walk_path_entries=1)
+    eng1, _ = run_pipeline(g, defer_min_contigs=3, defer_min_work=0, walk_path_entries=1)
     assert eng1.digest() == eng0.digest()
 
 
@@ -382,7 +389,7 @@ def test_full_size_properties():
     g = bench.make_inputs(pkg, n, 1234, "cuda:0", bench.WORKLOAD["gen"])
     g["num_pairs"] = g["num_pairs"].to(torch.int64)
     digests = []
-    for opts in (dict(), dict(defer_min_contigs=0, class_streams=1), dict(defer_min_contigs=96, mixed_task_limit=0)):
+    for opts in (dict(), dict(defer_min_contigs=0, class_streams=1), dict(defer_min_contigs=96, defer_min_work=0, mixed_task_limit=0)):
         eng = pkg.engine.Engine(0)
         for k, v in opts.items():
             eng.set_option(k, v)
