@@ -27,7 +27,12 @@
 #include <vector>
 
 #define GTS_NKLASS 11
-/* LDS size classes of the component launches (bytes of dynamic LDS) */
+/* LDS size classes of the component launches (bytes of dynamic LDS).  (Coarser
+   tables measured worse: nine classes -- 48 K with 64 K, 96 K with 160 K, whose
+   few hundred components have room either way -- 59.3 against 55.5 ms per step:
+   a workgroup that asks for a CU's whole LDS waits until one has drained
+   completely, which the small classes' workgroups prevent for milliseconds;
+   seven classes 60.8 ms.) */
 static const uint32_t gts_klass_bytes[GTS_NKLASS] = {4096, 6144, 8192, 12288, 16384, 24576, 32768,
                                                     49152, 65536, 98304, 163840};
 /* profile-event names of the class launches: string literals, so the pointers
@@ -106,7 +111,7 @@ struct GtsgEngine {
   /* options */
   int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
   int64_t walk_pool_entries = 1ll << 26;
-  int64_t class_streams = 6;
+  int64_t class_streams = GTS_NSTREAMS;
 
   int64_t mixed_task_limit = 256;
   int64_t defer_min_contigs = 256, walk_path_entries = 1ll << 24;
@@ -385,6 +390,12 @@ __global__ void k_emit_edges(const uint32_t *is_creator, const uint32_t *jidx,
     b.flags = (twin_dir ? GTS_F_SENSE : 0u) | (same ? GTS_F_SAME : 0u);
   } else
     b.flags = flags[bw] & 3u;
+  /* both edges of the pair are in hand here: the "u-turn" mark of an edge (its
+     twin would be followed right after it, gts_defs.h) is a function of the two
+     flag pairs and rides along as bit 2 of the stored flags, so the component
+     compaction does not have to fetch the twin's flags per edge */
+  if (((b.flags & GTS_F_SENSE) != 0) == gts_next_dir((uint8_t)a.flags)) a.flags |= GTS_F_UTURN;
+  if (((a.flags & GTS_F_SENSE) != 0) == gts_next_dir((uint8_t)b.flags)) b.flags |= GTS_F_UTURN;
   estart[e0] = r; estart[e0 + 1] = c;
   ids[e0] = (uint32_t)e0; ids[e0 + 1] = (uint32_t)e0 + 1u;   /* values of the CSR sort */
   rec[e0] = a; rec[e0 + 1] = b;
@@ -878,7 +889,7 @@ __global__ void k_compact_count(const uint32_t *row, const uint32_t *ipos,
   const uint32_t v = slot_v[s];
   cnt[s] = ipos[row[v + 1]] - ipos[row[v]];
 }
-__global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart, const uint8_t *live,
+__global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
                                const uint32_t *incl, const uint32_t *ipos,
                                const uint32_t *slot_of, const uint32_t *slot_base,
                                const uint32_t *coff, const uint32_t *slot_comp,
@@ -891,15 +902,17 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart, const uin
   if (!incl[p]) { cmap[p] = GTS_NONE; return; }
   const uint32_t a = estart[p], s = slot_of[a], base = slot_base[s];
   const uint32_t k = coff[s] + (ipos[p] - ipos[G.row[a]]);
-  const uint8_t f = G.flags[p], ft = live[G.twin[p]];   /* twin: flags + live bit */
-  const bool uturn = ((ft & GTS_F_SENSE) != 0) == gts_next_dir(f);
+  /* flags with the u-turn bit from the build.  An included edge's twin is live
+     or the edge is live itself; GTS_F_TWINLIVE matters only while the edge is
+     marked (d_arc) and is cleared with the twin's CYCLIC mark, the only way a
+     live edge dies (mark_vertex_cyclic takes both): set for every edge. */
+  const uint8_t f = G.flags[p];
   cstart[k] = s - base; cend[k] = slot_of[G.end[p]] - base;
   const int64_t d = G.dist[p];
   /* the LDS layout adds up to 4095 distances in 32 bits (nd_t) */
   if (d >= (1 << 19) || d <= -(1 << 19)) comp_wide[slot_comp[s]] = 1;
   cdist[k] = d;
-  cflags[k] = (uint8_t)((f & 3u) | (uturn ? GTS_F_UTURN : 0u) |
-                        ((ft & 0x80u) ? GTS_F_TWINLIVE : 0u));
+  cflags[k] = (uint8_t)((f & 7u) | GTS_F_TWINLIVE);
   cgpos[k] = (uint32_t)p; cstate[k] = G.state[p];
   cmap[p] = k;
 }
@@ -1261,7 +1274,7 @@ __global__ void k_edges_by_id(const uint32_t *eid, const uint32_t *estart,
   if (p >= m) return;
   const uint32_t id = eid[p];
   ostart[id] = estart[p]; oend[id] = eend[p]; odist[id] = dist[p];
-  osd[id] = sd[p]; onp[id] = np[p]; oflags[id] = flags[p];
+  osd[id] = sd[p]; onp[id] = np[p]; oflags[id] = flags[p] & 3u;   /* (bit 2 is internal) */
 }
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -1880,7 +1893,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cflags, uint8_t, (size_t)nce + 1); PALLOC(cstate, uint8_t, (size_t)nce + 1);
     PALLOC(cmap, uint32_t, (size_t)m + 1);
     if (m)
-      LAUNCH("comp_compact_fill", k_compact_fill, nblk(m), GTS_BLOCK, G, e->estart, live, incl, ipos,
+      LAUNCH("comp_compact_fill", k_compact_fill, nblk(m), GTS_BLOCK, G, e->estart, incl, ipos,
              slot_of, slot_base, coff, slot_comp, comp_wide, cstart, cend, cdist, cflags, cgpos,
              cstate, cmap);
     /* walk queue pool of the reference search */
