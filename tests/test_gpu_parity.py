@@ -281,6 +281,31 @@ def test_file_api_on_synthetic_files(tmp_path):
     assert np.array_equal(lens, og.scaffolds()[3])
 
 
+def test_file_api_at_100k_contigs(tmp_path):
+    """BASELINE configs[1] as stated: a synthetic 100 k-contig / ~1 M-edge graph
+    as .fa / .de / .astat FILES in the reference's formats, parsed by the oracle
+    and by the drop-in C API; .dot after every stage and .scaf byte-identical."""
+    import filecmp
+    g = make_inputs(100000, 5, contig_median=320, links_per_side=5, p_repeat=0.03, repeat_degree=43,
+                    p_inversion=0.0, unique_pairs=True)
+    pkg.synth.write_files(g, str(tmp_path / "syn"))
+    fa, de, astat = [str(tmp_path / ("syn" + x)) for x in (".fa", ".de", ".astat")]
+    og = OracleGraph.from_files(fa, de)
+    G = pkg.engine.ScaffolderGraph.from_files(fa, de)
+    assert (G.nv, G.ne) == (og.nv, og.ne) and og.nv > 60000 and og.ne > 500000
+    og.mark_repeats_file(astat); G.mark_repeats(astat)
+    for name, fo, fe in (("mark_repeats", None, None), ("filter", og.filter, G.filter),
+                         ("removecycles", og.removecycles, G.removecycles),
+                         ("makescaffold", lambda: og.makescaffold(True), G.makescaffold)):
+        if fo:
+            fo(); fe()
+        og.print_dot(str(tmp_path / "o.dot")); G.print_dot(str(tmp_path / "e.dot"))
+        assert filecmp.cmp(tmp_path / "o.dot", tmp_path / "e.dot", shallow=False), name
+    og.write_scaffold(str(tmp_path / "o.scaf"))
+    G.write_scaffold(str(tmp_path / "e.scaf"))
+    assert filecmp.cmp(tmp_path / "o.scaf", tmp_path / "e.scaf", shallow=False)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_pipeline_matches_unsharded_oracle(world):
     """The multi-GPU path rehearsed on one GPU: `world` engines, records split by
