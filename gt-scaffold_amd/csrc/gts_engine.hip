@@ -1767,6 +1767,113 @@ __global__ void k_label_flatten(uint32_t *parent, uint32_t n)
   uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v < n) parent[v] = uf_find(parent, (uint32_t)v);
 }
+/* ---- routing of records to the shard that owns their component (multi-GPU) ----
+   A record travels as four 64-bit words (gt-scaffold_amd/dist.py, pack_records):
+     word 0: root | sense << 31 | ctg << 32 | same << 63
+     word 1: dist        word 2: num_pairs
+     word 3: global record index | bits(std_dev) << 32 */
+__global__ void k_route_dest(const uint32_t *root, const uint32_t *ctg, const int8_t *owner,
+                             uint32_t world, uint32_t *dest, uint32_t *idx, uint64_t nrec,
+                             uint32_t n, uint32_t *bad)
+{
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nrec) return;
+  const uint32_t a = root[k], b = ctg[k];
+  if (a >= n || b >= n) { *bad = 1; dest[k] = 0; idx[k] = (uint32_t)k; return; }
+  /* owner < 0: a repeat contig, shared by the shards; the record follows its
+     other contig; both repeats: any rank, the same for every record of the pair */
+  const int oa = owner[a], ob = owner[b];
+  dest[k] = oa >= 0 ? (uint32_t)oa : ob >= 0 ? (uint32_t)ob : (a < b ? a : b) % world;
+  idx[k] = (uint32_t)k;
+}
+__global__ void k_route_rows(const uint32_t *perm, const uint32_t *root, const uint32_t *ctg,
+                             const int64_t *dist, const float *sd, const int64_t *np,
+                             const uint8_t *flags, uint64_t k0, uint64_t *rows, uint64_t nrec)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrec) return;
+  const uint32_t k = perm[i];
+  const uint64_t f = flags[k];
+  ulonglong2 lo, hi;
+  lo.x = (uint64_t)root[k] | ((f & 1ull) << 31) | ((uint64_t)ctg[k] << 32) | (((f >> 1) & 1ull) << 63);
+  lo.y = (uint64_t)dist[k];
+  hi.x = np ? (uint64_t)np[k] : 0ull;
+  hi.y = (k0 + k) | ((uint64_t)__float_as_uint(sd[k]) << 32);
+  ((ulonglong2 *)rows)[2 * i] = lo;
+  ((ulonglong2 *)rows)[2 * i + 1] = hi;
+}
+/* rows -> record arrays; loc_of (may be null) turns whole-graph contig ids into
+   the shard's local numbers on the way */
+__global__ void k_route_unpack(const uint64_t *rows, const uint32_t *loc_of, uint32_t *root,
+                               uint32_t *ctg, int64_t *dist, float *sd, int64_t *np,
+                               uint8_t *flags, uint64_t *kidx, uint64_t nrec)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrec) return;
+  const ulonglong2 lo = ((const ulonglong2 *)rows)[2 * i], hi = ((const ulonglong2 *)rows)[2 * i + 1];
+  const uint32_t a = (uint32_t)lo.x & 0x7FFFFFFFu, b = (uint32_t)(lo.x >> 32) & 0x7FFFFFFFu;
+  root[i] = loc_of ? loc_of[a] : a;
+  ctg[i] = loc_of ? loc_of[b] : b;
+  flags[i] = (uint8_t)(((lo.x >> 31) & 1ull) | (((lo.x >> 63) & 1ull) << 1));
+  dist[i] = (int64_t)lo.y; np[i] = (int64_t)hi.x;
+  sd[i] = __uint_as_float((uint32_t)(hi.y >> 32));
+  kidx[i] = hi.y & 0xFFFFFFFFull;
+}
+
+int gtsg_route_pack(GtsgEngine *e, uint64_t nrec, const uint32_t *root, const uint32_t *ctg,
+                    const int64_t *dist, const float *std_dev, const int64_t *num_pairs,
+                    const uint8_t *flags, uint64_t first_index, uint64_t n_contigs,
+                    const int8_t *owner, uint32_t world, uint64_t *rows, uint64_t *counts)
+{
+  if (!e || !counts || world < 1 || world > 127 ||
+      (nrec && (!root || !ctg || !dist || !std_dev || !flags || !owner || !rows)))
+    return GTSG_EINVAL;
+  if (nrec >= GTS_ONESWEEP_MAX_N || first_index + nrec >= (1ull << 32) || n_contigs >= (1ull << 31))
+    return fail(e, GTSG_ELIMIT, "too many records for one routing call");
+  HIPCHK(hipSetDevice(e->device));
+  for (uint32_t r = 0; r < world; ++r) counts[r] = 0;
+  if (!nrec) return 0;
+  int rc;
+  if ((rc = pool_reserve(e, nrec * 16 + gts_sort_tmp_elems(nrec) * 4 + (1u << 20)))) return rc;
+  PALLOC(d0, uint32_t, nrec); PALLOC(d1, uint32_t, nrec);
+  PALLOC(i0, uint32_t, nrec); PALLOC(i1, uint32_t, nrec);
+  PALLOC(stmp, uint32_t, gts_sort_tmp_elems(nrec));
+  HIPCHK(hipMemsetAsync(e->d_scalars + 6, 0, 4, e->st));
+  LAUNCH("route_dest", k_route_dest, nblk(nrec), GTS_BLOCK, root, ctg, owner, world, d0, i0, nrec,
+         (uint32_t)n_contigs, e->d_scalars + 6);
+  /* one stable 8-bit pass by destination keeps the file order inside a destination;
+     its digit histogram (exclusive prefix after the sort) gives the counts */
+  const int shift0 = 0;
+  int where;
+  { ProfScope ps(e, "route_sort");
+    where = gts_radix_sort<uint32_t>(d0, i0, d1, i1, nrec, &shift0, 1, stmp, e->st); }
+  if (where < 0) return fail(e, GTSG_ELIMIT, "too many records for one routing call");
+  LAUNCH("route_rows", k_route_rows, nblk(nrec), GTS_BLOCK, where ? i1 : i0, root, ctg, dist, std_dev,
+         num_pairs, flags, first_index, rows, nrec);
+  uint32_t base[256], bad = 0;
+  HIPCHK(hipMemcpyAsync(base, stmp, sizeof base, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(hipMemcpyAsync(&bad, e->d_scalars + 6, 4, hipMemcpyDeviceToHost, e->st));
+  if ((rc = sync_stream(e))) return rc;
+  if (bad) return fail(e, GTSG_EINVAL, "contig id out of range in the records");
+  for (uint32_t r = 0; r < world; ++r)
+    counts[r] = (r + 1 < 256 ? base[r + 1] : (uint32_t)nrec) - base[r];
+  counts[world - 1] = nrec - base[world - 1];
+  return 0;
+}
+
+int gtsg_route_unpack(GtsgEngine *e, uint64_t nrec, const uint64_t *rows, const uint32_t *loc_of,
+                      uint32_t *root, uint32_t *ctg, int64_t *dist, float *std_dev,
+                      int64_t *num_pairs, uint8_t *flags, uint64_t *index)
+{
+  if (!e || (nrec && (!rows || !root || !ctg || !dist || !std_dev || !num_pairs || !flags || !index)))
+    return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  if (nrec)
+    LAUNCH("route_unpack", k_route_unpack, nblk(nrec), GTS_BLOCK, rows, loc_of, root, ctg, dist, std_dev,
+           num_pairs, flags, index, nrec);
+  return sync_stream(e);
+}
+
 int gtsg_label_components(GtsgEngine *e, uint64_t n, uint64_t nrec, const uint32_t *root,
                           const uint32_t *ctg, const uint8_t *skip, uint32_t *labels,
                           int on_device)

@@ -91,6 +91,8 @@ class ThreadComm:
 
     def all_reduce(self, t, op):
         s = self.s
+        if self.world == 1:
+            return t
         s.slots[self.rank] = t.clone()
         s.barrier.wait()
         st = torch.stack([x.to(t.device) for x in s.slots])
@@ -179,8 +181,30 @@ def plan_owners(comm, n, labels, skip, root, ctg):
     return owner, load
 
 
+def route_records_engine(comm, eng, owner, rec, loc_of):
+    """Step 3 with the engine's HIP kernels (gtsg_route_pack / _unpack): the
+    destination of every record, one stable 8-bit sort pass by destination and
+    the 32-byte rows in one sweep; after the all_to_all the rows are unpacked
+    straight into the shard's local contig numbers.  rec["k"] must be a run of
+    consecutive indices (a chunk of the record file)."""
+    k = rec["k"]
+    first = int(k[0]) if k.numel() else 0
+    r = dict(root=rec["root"].to(torch.int32).contiguous(), ctg=rec["ctg"].to(torch.int32).contiguous(),
+             dist=rec["dist"].to(torch.int64).contiguous(), std_dev=rec["std_dev"].to(torch.float32).contiguous(),
+             num_pairs=rec["num_pairs"].to(torch.int64).contiguous(), flags=rec["flags"].to(torch.uint8).contiguous())
+    rows, counts = eng.route_pack(r, first, owner.to(torch.int8), comm.world)
+    rows = comm.exchange_rows(rows, counts)
+    out = eng.route_unpack(rows.contiguous(), loc_of)
+    kk = out["k"]
+    if kk.numel() > 1 and not bool((kk[1:] >= kk[:-1]).all()):   # chunks dealt in file order arrive sorted
+        o = torch.argsort(kk, stable=True)
+        out = {name: t[o] for name, t in out.items()}
+    return out
+
+
 def route_records(comm, owner, skip, rec):
-    """Step 3.  rec: dict of equally long 1-D tensors (root, ctg, dist, std_dev,
+    """Step 3 in torch (CPU tests, or records that are not a chunk of the
+    file).  rec: dict of equally long 1-D tensors (root, ctg, dist, std_dev,
     num_pairs, flags, k = global record index).  One packed all_to_all; returns
     this rank's records sorted by k (= file order)."""
     root, ctg = rec["root"].to(torch.int64), rec["ctg"].to(torch.int64)
@@ -204,12 +228,17 @@ def route_records(comm, owner, skip, rec):
 
 
 def engine_label_fn(eng):
-    """label_fn backed by the engine's HIP kernels (gtsg_label_components)."""
+    """label_fn backed by the engine's HIP kernels (gtsg_label_components); the
+    records and the skip mask are converted once, not per round."""
+    cache = {}
+
     def fn(labels, root, ctg, skip):
+        key = (root.data_ptr(), ctg.data_ptr(), skip.data_ptr())
+        if cache.get("key") != key:
+            cache.update(key=key, root=root.to(torch.int32).contiguous(), ctg=ctg.to(torch.int32).contiguous(),
+                         skip=skip.to(torch.uint8).contiguous())
         lab = labels.contiguous()
-        eng.label_components(lab.numel(), root.to(torch.int32).contiguous(),
-                             ctg.to(torch.int32).contiguous(),
-                             skip.to(torch.uint8).contiguous(), lab)
+        eng.label_components(lab.numel(), cache["root"], cache["ctg"], cache["skip"], lab)
         return lab
     return fn
 
@@ -242,17 +271,23 @@ def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None, timers=None):
     lap("label")
     owner, load = plan_owners(comm, n, labels, skip, root, ctg)
     lap("plan")
-    mine = route_records(comm, owner, skip, rec)
-    lap("route")
     # local numbering: owned + repeat contigs, in id order
     member = (owner == comm.rank) | skip
     local = torch.nonzero(member).flatten()
-    loc_of = torch.cumsum(member.to(torch.int64), 0) - 1
+    loc_of = torch.cumsum(member.to(torch.int32), 0, dtype=torch.int32) - 1
+    k = rec["k"]
+    chunk = k.numel() == 0 or int(k[-1]) - int(k[0]) + 1 == k.numel()
+    if dev.type == "cuda" and chunk and hasattr(eng, "route_pack"):
+        mine = route_records_engine(comm, eng, owner, rec, loc_of)
+    else:
+        mine = route_records(comm, owner, skip, rec)
+        mine["root"], mine["ctg"] = loc_of[mine["root"]], loc_of[mine["ctg"]]
+    lap("route")
     eng.set_contigs(contigs["seq_len"][local].contiguous(), contigs["astat"][local].contiguous(),
                     contigs["copy_num"][local].contiguous())
     eng.set_vertex_times(local.to(torch.int32).contiguous())
-    eng.build_from_records(loc_of[mine["root"]].to(torch.int32).contiguous(),
-                           loc_of[mine["ctg"]].to(torch.int32).contiguous(),
+    eng.build_from_records(mine["root"].to(torch.int32).contiguous(),
+                           mine["ctg"].to(torch.int32).contiguous(),
                            mine["dist"].contiguous(), mine["std_dev"].contiguous(),
                            mine["num_pairs"].contiguous(), mine["flags"].contiguous())
     eng.mark_repeats(True, cuts["copy_num_cutoff"], cuts["astat_cutoff"])
@@ -260,7 +295,7 @@ def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None, timers=None):
     # latest-hit times of the repeat contigs' edges: whole-graph ids, MAX over
     # the shards (every rank holds all repeat contigs, so a rank without any
     # vertex means there is no repeat and nothing to combine)
-    rep_loc = loc_of[torch.nonzero(skip).flatten()]
+    rep_loc = loc_of[torch.nonzero(skip).flatten()].to(torch.int64)
     if local.numel():
         eng.filter_begin(cuts["pcutoff"], cuts["cncutoff"], cuts["ocutoff"])
         lasthit = torch.empty(2 * local.numel(), dtype=torch.int32, device=dev)

@@ -19,7 +19,8 @@ SYMBOLS = [
     "gtsg_removecycles", "gtsg_makescaffold", "gtsg_num_vertices", "gtsg_num_edges",
     "gtsg_get_vertex_states", "gtsg_get_edge_states", "gtsg_get_edges", "gtsg_state_digest",
     "gtsg_set_option", "gtsg_selftest_ambiguous", "gtsg_filter_begin", "gtsg_filter_end",
-    "gtsg_filter_get_lasthit", "gtsg_filter_set_lasthit", "gtsg_label_components", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
+    "gtsg_filter_get_lasthit", "gtsg_filter_set_lasthit", "gtsg_label_components",
+    "gtsg_route_pack", "gtsg_route_unpack", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
 ]
 
 
@@ -69,6 +70,9 @@ def lib():
         L.gtsg_filter_get_lasthit.argtypes = [vp, vp, ci]
         L.gtsg_filter_set_lasthit.argtypes = [vp, vp, ci]
         L.gtsg_label_components.argtypes = [vp, u64, u64, vp, vp, vp, vp, ci]
+        L.gtsg_route_pack.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, u64, u64, vp, C.c_uint32, vp,
+                                      C.POINTER(u64)]
+        L.gtsg_route_unpack.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gtsg_removecycles.argtypes = [vp]
         L.gtsg_makescaffold.argtypes = [vp]
         L.gtsg_num_vertices.argtypes = [vp]
@@ -256,6 +260,43 @@ class Engine:
         self._sync_producer(a)
         self._chk(self._L.gtsg_label_components(self._h, int(n), len(root), a[0][0], a[1][0], a[2][0],
                                                 a[3][0], self._same_side([x[1] for x in a])))
+
+    def route_pack(self, rec, first_index, owner8, world):
+        """rec: device tensors root / ctg (int32), dist, num_pairs (int64), std_dev
+        (float32), flags (uint8); owner8: int8 per contig (negative = shared).
+        Returns (rows [n, 4] int64 grouped by destination, counts per rank)."""
+        import torch
+        n = rec["root"].numel()
+        rows = torch.empty((n, 4), dtype=torch.int64, device=rec["root"].device)
+        counts = (C.c_uint64 * world)()
+        a = [_ptr(rec[k], dt) for k, dt in (("root", np.uint32), ("ctg", np.uint32), ("dist", np.int64),
+                                            ("std_dev", np.float32), ("num_pairs", np.int64),
+                                            ("flags", np.uint8))]
+        po, do, ko = _ptr(owner8, np.int8)
+        pr, dr, kr = _ptr(rows, np.int64)
+        self._sync_producer(a + [(po, do), (pr, dr)])
+        self._chk(self._L.gtsg_route_pack(self._h, n, *[x[0] for x in a], int(first_index),
+                                          owner8.numel(), po, int(world), pr, counts))
+        return rows, [int(c) for c in counts]
+
+    def route_unpack(self, rows, loc_of=None):
+        """rows [n, 4] int64 (device) -> dict of device tensors; loc_of: int32 per
+        contig, whole-graph id -> local number (or None)."""
+        import torch
+        n, dev = rows.shape[0], rows.device
+        out = dict(root=torch.empty(n, dtype=torch.int32, device=dev), ctg=torch.empty(n, dtype=torch.int32, device=dev),
+                   dist=torch.empty(n, dtype=torch.int64, device=dev),
+                   std_dev=torch.empty(n, dtype=torch.float32, device=dev),
+                   num_pairs=torch.empty(n, dtype=torch.int64, device=dev),
+                   flags=torch.empty(n, dtype=torch.uint8, device=dev),
+                   k=torch.empty(n, dtype=torch.int64, device=dev))
+        pr, dr, kr = _ptr(rows, np.int64)
+        pl = _ptr(loc_of, np.uint32)[0] if loc_of is not None else None
+        self._sync_producer([(pr, dr)])
+        self._chk(self._L.gtsg_route_unpack(self._h, n, pr, pl, *[C.c_void_p(out[k].data_ptr()) for k in
+                                                                   ("root", "ctg", "dist", "std_dev",
+                                                                    "num_pairs", "flags", "k")]))
+        return out
 
     # ---- results ----
     @property

@@ -122,6 +122,26 @@ int gtsg_label_components(GtsgEngine *e, uint64_t n, uint64_t n_records,
                           const uint32_t *root, const uint32_t *ctg,
                           const uint8_t *skip, uint32_t *labels, int on_device);
 
+/* Component-partition step, routing: the records of this shard, packed into
+   four 64-bit words each and grouped by the rank that owns their component
+   (file order kept inside a group), ready for one all_to_all; and back.  All
+   array arguments are DEVICE pointers; counts[world] is a host array.
+     owner[c]  rank of contig c, negative for a repeat contig (shared: the record
+               follows its other contig)
+     first_index  global index (= position in the .de file) of this shard's
+               first record
+   unpack: loc_of (may be NULL) maps whole-graph contig ids to the shard's
+   local numbers; index[] receives the global record indices. */
+int gtsg_route_pack(GtsgEngine *e, uint64_t n_records, const uint32_t *root,
+                    const uint32_t *ctg, const int64_t *dist, const float *std_dev,
+                    const int64_t *num_pairs, const uint8_t *flags,
+                    uint64_t first_index, uint64_t n_contigs, const int8_t *owner,
+                    uint32_t world, uint64_t *rows, uint64_t *counts);
+int gtsg_route_unpack(GtsgEngine *e, uint64_t n_rows, const uint64_t *rows,
+                      const uint32_t *loc_of, uint32_t *root, uint32_t *ctg,
+                      int64_t *dist, float *std_dev, int64_t *num_pairs,
+                      uint8_t *flags, uint64_t *index);
+
 /* ref gt_scaffolder_removecycles, algorithms.c:495-578 */
 int gtsg_removecycles(GtsgEngine *e);
 /* ref gt_scaffolder_makescaffold, algorithms.c:767-868 */
