@@ -625,3 +625,41 @@ def test_hub_degree_set_after_build_does_not_change_the_filter():
     eng.set_option("hub_degree", 4)        # takes effect at the next build
     og.mark_repeats(); eng.mark_repeats(); og.filter(); eng.filter()
     assert_same_states(eng, og, "filter")
+
+
+def test_route_kernels_match_the_torch_packing():
+    """gtsg_route_pack / _unpack against dist.pack_records + a stable sort by
+    destination: same 32-byte rows in the same order, same counts; unpacking
+    gives the records back (with and without local renumbering)."""
+    import torch
+    d = pkg.dist
+    rng = np.random.default_rng(4)
+    n, k, world = 5000, 300_000, 5
+    dev = "cuda:0"
+    rec = dict(root=torch.from_numpy(rng.integers(0, n, k).astype(np.int32)).to(dev),
+               ctg=torch.from_numpy(rng.integers(0, n, k).astype(np.int32)).to(dev),
+               dist=torch.from_numpy(rng.integers(-2**40, 2**40, k)).to(dev),
+               std_dev=torch.from_numpy((rng.random(k) * 100).astype(np.float32)).to(dev),
+               num_pairs=torch.from_numpy(rng.integers(0, 2**40, k)).to(dev),
+               flags=torch.from_numpy(rng.integers(0, 4, k).astype(np.uint8)).to(dev))
+    first = 123_456
+    rec["k"] = torch.arange(first, first + k, dtype=torch.int64, device=dev)
+    owner = torch.from_numpy(rng.integers(-1, world, n)).to(dev)        # -1: shared (repeat) contig
+    eng = pkg.engine.Engine(0)
+    rows, counts = eng.route_pack(rec, first, owner.to(torch.int8), world)
+    a, b = rec["root"].long(), rec["ctg"].long()
+    dest = torch.where(owner[a] >= 0, owner[a], torch.where(owner[b] >= 0, owner[b], torch.minimum(a, b) % world))
+    order = torch.sort(dest, stable=True)[1]
+    assert torch.equal(rows, d.pack_records(rec)[order])
+    assert counts == torch.bincount(dest, minlength=world).tolist()
+    back = eng.route_unpack(rows)
+    for name in ("root", "ctg", "dist", "num_pairs", "flags", "k"):
+        assert torch.equal(back[name].long(), rec[name][order].long()), name
+    assert torch.equal(back["std_dev"].view(torch.int32), rec["std_dev"][order].view(torch.int32))
+    loc_of = torch.from_numpy(rng.permutation(n).astype(np.int32)).to(dev)
+    back2 = eng.route_unpack(rows, loc_of)
+    assert torch.equal(back2["root"].long(), loc_of[a[order]].long())
+    assert torch.equal(back2["ctg"].long(), loc_of[b[order]].long())
+    bad = dict(rec); bad["ctg"] = rec["ctg"].clone(); bad["ctg"][7] = n
+    with pytest.raises(pkg.engine.EngineError, match="out of range"):
+        eng.route_pack(bad, first, owner.to(torch.int8), world)
