@@ -530,17 +530,34 @@ k_filter_pairs(GtsGraphView G, GtsFilterParams P, const GtsVAttr *va, uint8_t *p
   /* every edge of the block: the end vertex' length also goes to elen[] in
      edge order, so that the overlap pass (k_filter_ovf_init) reads it back
      coalesced instead of gathering the vertex record a second time */
-  for (uint32_t i = threadIdx.x; i < e1 - e0; i += GTS_BLOCK) {
-    const uint32_t p = e0 + i, x = G.end[p];
-    const GtsVAttr a = va[x];
-    const int64_t l = a.len;
-    const bool lw = l != (int32_t)l || (int32_t)l == GTS_ELEN_WIDE;
-    elen[p] = lw ? GTS_ELEN_WIDE : (int32_t)l;
-    if (i < ns) {
-      const int64_t d = G.dist[p];
-      if (d != (int32_t)d || lw) s_wide = 1;
-      s_d[i] = (int32_t)d; s_s[i] = G.sd[p]; s_f[i] = G.flags[p];
-      s_c[i] = a.cn; s_l[i] = (int32_t)l;
+  /* four edges per thread and trip: the four dependent gathers of the end
+     vertices' records are in flight together (a 60 KB workgroup leaves a CU with
+     eight wavefronts, one gather each is too little to hide their latency) */
+  const uint32_t ne_blk = e1 - e0;
+  for (uint32_t i0 = threadIdx.x; i0 < ne_blk; i0 += 4 * GTS_BLOCK) {
+    uint32_t xs[4];
+    GtsVAttr as[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t i = i0 + j * GTS_BLOCK;
+      xs[j] = i < ne_blk ? G.end[e0 + i] : G.end[e0];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) as[j] = va[xs[j]];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t i = i0 + j * GTS_BLOCK;
+      if (i >= ne_blk) continue;
+      const uint32_t p = e0 + i;
+      const int64_t l = as[j].len;
+      const bool lw = l != (int32_t)l || (int32_t)l == GTS_ELEN_WIDE;
+      elen[p] = lw ? GTS_ELEN_WIDE : (int32_t)l;
+      if (i < ns) {
+        const int64_t d = G.dist[p];
+        if (d != (int32_t)d || lw) s_wide = 1;
+        s_d[i] = (int32_t)d; s_s[i] = G.sd[p]; s_f[i] = G.flags[p];
+        s_c[i] = as[j].cn; s_l[i] = (int32_t)l;
+      }
     }
   }
   __syncthreads();
@@ -1656,12 +1673,17 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
   PALLOC(proposed, uint8_t, (size_t)n + 1);
   HIPCHK(hipMemsetAsync(proposed, 0, (size_t)n + 1, e->st));
   if (m) LAUNCH("filter_active_round", k_filter_proposed, nblk(m), GTS_BLOCK, G, e->estart, prop, proposed);
+  /* The rounds of a fixpoint are idempotent once it is reached (a settled
+     vertex returns at once), and a host round trip costs more than a round
+     that finds nothing to do: several rounds per look at the flag. */
   for (;;) {
     uint32_t h = 0;
-    HIPCHK(hipMemsetAsync(pending, 0, 4, e->st));
-    LAUNCH("filter_active_round", k_filter_active_round, nblk(n), GTS_BLOCK, G, prop, proposed, vinfo,
-           pending);
-    ++rounds_p;
+    for (int r = 0; r < 3; ++r) {
+      HIPCHK(hipMemsetAsync(pending, 0, 4, e->st));
+      LAUNCH("filter_active_round", k_filter_active_round, nblk(n), GTS_BLOCK, G, prop, proposed, vinfo,
+             pending);
+      ++rounds_p;
+    }
     if ((rc = read_u32(e, pending, &h))) return rc;
     if (!h) break;
   }
@@ -1676,10 +1698,12 @@ int gtsg_filter_begin(GtsgEngine *e, float pcutoff, float cncutoff, int64_t ocut
            e->nhub);
   for (;;) {
     uint32_t h = 0;
-    HIPCHK(hipMemsetAsync(pending, 0, 4, e->st));
-    LAUNCH("filter_hit_round", k_filter_hit_round, nblk(n), GTS_BLOCK, G, ovf, zero_ovf,
-           pending);
-    ++rounds_i;
+    for (int r = 0; r < 4; ++r) {
+      HIPCHK(hipMemsetAsync(pending, 0, 4, e->st));
+      LAUNCH("filter_hit_round", k_filter_hit_round, nblk(n), GTS_BLOCK, G, ovf, zero_ovf,
+             pending);
+      ++rounds_i;
+    }
     if ((rc = read_u32(e, pending, &h))) return rc;
     if (!h) break;
   }
