@@ -330,7 +330,7 @@ __global__ void k_pair_keys(const uint32_t *root, const uint32_t *ctg,
    of a pair and creators that lose a direction are written here, and which
    root a record was listed from is read off bit 63 of its key. */
 __global__ void k_pair_segments(const uint64_t *keys, const uint32_t *recs,
-                                const float *sd, uint32_t *is_creator,
+                                const float *sd, uint8_t *is_creator,
                                 uint32_t *fwd_win, uint32_t *bwd_win, uint64_t nrec,
                                 int never_replace)
 {
@@ -365,7 +365,7 @@ struct __attribute__((aligned(32))) GtsEdgeRec {
   uint32_t pad;
 };
 
-__global__ void k_emit_edges(const uint32_t *is_creator, const uint32_t *jidx,
+__global__ void k_emit_edges(const uint8_t *is_creator, const uint32_t *jidx,
                              const uint32_t *fwd_win, const uint32_t *bwd_win,
                              const uint32_t *root, const uint32_t *ctg,
                              const int64_t *dist, const float *sd,
@@ -890,12 +890,12 @@ __global__ void k_slot_bases(const uint32_t *head, const uint32_t *cidx,
    per edge position; the rank of an edge among the included edges of its
    vertex comes from one prefix sum over all positions. */
 __global__ void k_compact_flags(const uint8_t *live, const uint32_t *twin,
-                                uint32_t *incl, uint32_t m)
+                                uint8_t *incl, uint32_t m)
 {
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= m) return;
   /* the twin is looked up only for an edge that is not live itself */
-  incl[p] = (live[p] & 0x80u) ? 1u : (live[twin[p]] & 0x80u) ? 1u : 0u;
+  incl[p] = (live[p] & 0x80u) ? 1 : (live[twin[p]] & 0x80u) ? 1 : 0;
 }
 __global__ void k_compact_count(const uint32_t *row, const uint32_t *ipos,
                                 const uint32_t *slot_v, uint32_t *cnt,
@@ -907,7 +907,7 @@ __global__ void k_compact_count(const uint32_t *row, const uint32_t *ipos,
   cnt[s] = ipos[row[v + 1]] - ipos[row[v]];
 }
 __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
-                               const uint32_t *incl, const uint32_t *ipos,
+                               const uint8_t *incl, const uint32_t *ipos,
                                const uint32_t *slot_of, const uint32_t *slot_base,
                                const uint32_t *coff, const uint32_t *slot_comp,
                                uint8_t *comp_wide, uint32_t *cstart,
@@ -1529,7 +1529,8 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
     }
   }
   uint32_t npairs_created = 0;
-  uint32_t *is_creator = nullptr, *jidx = nullptr, *fwd = nullptr, *bwd = nullptr;
+  uint8_t *is_creator = nullptr;   /* one byte per record: a quarter of the fill, scan and emit traffic */
+  uint32_t *jidx = nullptr, *fwd = nullptr, *bwd = nullptr;
   if (nrec) {
     PALLOC(k0, uint64_t, nrec); PALLOC(k1, uint64_t, nrec);
     PALLOC(v0, uint32_t, nrec); PALLOC(v1, uint32_t, nrec);
@@ -1547,17 +1548,18 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
     uint64_t *ks = where ? k1 : k0;
     uint32_t *vs = where ? v1 : v0;
     /* reuse the other value buffer and fresh arrays for the segment fold */
-    is_creator = where ? v0 : v1;
+    PALLOC(t_isc, uint8_t, nrec);
+    is_creator = t_isc;
     PALLOC(t_fwd, uint32_t, nrec); PALLOC(t_bwd, uint32_t, nrec);
     PALLOC(t_jidx, uint32_t, nrec);
     PALLOC(sctmp, uint32_t, gts_scan_tmp_elems(nrec));
     fwd = t_fwd; bwd = t_bwd; jidx = t_jidx;
-    LAUNCH("fill", k_fill<uint32_t>, nblk(nrec), GTS_BLOCK, is_creator, 1u, (uint64_t)nrec);
+    HIPCHK(hipMemsetAsync(is_creator, 1, nrec, e->st));
     HIPCHK(hipMemsetAsync(fwd, 0xFF, nrec * 4, e->st));
     LAUNCH("build_pair_segments", k_pair_segments, nblk(nrec), GTS_BLOCK, ks, vs, d_sd,
            is_creator, fwd, bwd, nrec, ismatepair ? 1 : 0);
     { ProfScope ps(e, "build_scan_creators");
-      gts_exscan<uint32_t, uint32_t>(is_creator, jidx, nrec, sctmp, e->d_scalars, e->st); }
+      gts_exscan<uint8_t, uint32_t>(is_creator, jidx, nrec, sctmp, e->d_scalars, e->st); }
     uint32_t bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, e->d_scalars + 6, 4, hipMemcpyDeviceToHost, e->st));
     if ((rc = read_u32(e, e->d_scalars, &npairs_created))) return rc;
@@ -2010,9 +2012,9 @@ static int run_components(GtsgEngine *e, int mode)
     LAUNCH("comp_slot_bases", k_slot_bases, nblk(nslots), GTS_BLOCK, head, cidx, comp_off, cseq,
            slot_base, slot_comp, comp_wide, comp_len, nslots);
     PALLOC(coff, uint32_t, (size_t)nslots + 1);
-    PALLOC(incl, uint32_t, (size_t)m + 1); PALLOC(ipos, uint32_t, (size_t)m + 2);
+    PALLOC(incl, uint8_t, (size_t)m + 1); PALLOC(ipos, uint32_t, (size_t)m + 2);
     if (m) LAUNCH("comp_compact_flags", k_compact_flags, nblk(m), GTS_BLOCK, live, e->twin, incl, m);
-    gts_exscan<uint32_t, uint32_t>(incl, ipos, m, sctmp, ipos + m, e->st);
+    gts_exscan<uint8_t, uint32_t>(incl, ipos, m, sctmp, ipos + m, e->st);
     LAUNCH("comp_compact_count", k_compact_count, nblk(nslots), GTS_BLOCK, e->row, ipos, slot_v,
            coff, nslots);
     gts_exscan<uint32_t, uint32_t>(coff, coff, nslots, sctmp, e->d_scalars, e->st);
