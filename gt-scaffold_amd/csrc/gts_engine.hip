@@ -330,7 +330,7 @@ __global__ void k_pair_keys(const uint32_t *root, const uint32_t *ctg,
    of a pair and creators that lose a direction are written here, and which
    root a record was listed from is read off bit 63 of its key. */
 __global__ void k_pair_segments(const uint64_t *keys, const uint32_t *recs,
-                                const float *sd, uint8_t *is_creator,
+                                const float *sd, uint8_t *is_creator, uint8_t *replaced,
                                 uint32_t *fwd_win, uint32_t *bwd_win, uint64_t nrec,
                                 int never_replace)
 {
@@ -353,7 +353,9 @@ __global__ void k_pair_segments(const uint64_t *keys, const uint32_t *recs,
     if (selfloop || ((kj ^ key) >> 63) == 0) { if (fsd < s) { fsd = s; fw = k; } }   /* same root */
     else { if (bsd < s) { bsd = s; bw = k; } }
   }
-  if (fw != k0 || bw != k0) { fwd_win[k0] = fw; bwd_win[k0] = bw; }
+  /* a direction was taken over by a later record (rare): only then are the two
+     winner entries written -- and read (replaced[] is one byte per record) */
+  if (fw != k0 || bw != k0) { fwd_win[k0] = fw; bwd_win[k0] = bw; replaced[k0] = 1; }
 }
 
 struct __attribute__((aligned(32))) GtsEdgeRec {
@@ -365,7 +367,7 @@ struct __attribute__((aligned(32))) GtsEdgeRec {
   uint32_t pad;
 };
 
-__global__ void k_emit_edges(const uint8_t *is_creator, const uint32_t *jidx,
+__global__ void k_emit_edges(const uint8_t *is_creator, const uint8_t *replaced, const uint32_t *jidx,
                              const uint32_t *fwd_win, const uint32_t *bwd_win,
                              const uint32_t *root, const uint32_t *ctg,
                              const int64_t *dist, const float *sd,
@@ -373,11 +375,12 @@ __global__ void k_emit_edges(const uint8_t *is_creator, const uint32_t *jidx,
                              uint32_t *estart, uint32_t *ids, GtsEdgeRec *rec, uint64_t nrec)
 {
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nrec || !is_creator[k]) return;
+  if (k >= nrec) return;
+  if (!is_creator[k]) return;
   const uint64_t e0 = 2ull * jidx[k];
   const uint32_t r = root[k], c = ctg[k];
-  uint32_t fw = fwd_win[k], bw = bwd_win[k];
-  if (fw == GTS_NONE) { fw = (uint32_t)k; bw = (uint32_t)k; }   /* nothing replaced */
+  uint32_t fw = (uint32_t)k, bw = (uint32_t)k;
+  if (replaced[k]) { fw = fwd_win[k]; bw = bwd_win[k]; }
   GtsEdgeRec a, b;
   a.dist = dist[fw]; a.npairs = npairs ? npairs[fw] : 0; a.end = c;
   a.sd = sd[fw]; a.flags = flags[fw] & 3u; a.pad = 0;
@@ -1529,7 +1532,7 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
     }
   }
   uint32_t npairs_created = 0;
-  uint8_t *is_creator = nullptr;   /* one byte per record: a quarter of the fill, scan and emit traffic */
+  uint8_t *is_creator = nullptr, *replaced = nullptr;   /* one byte per record */
   uint32_t *jidx = nullptr, *fwd = nullptr, *bwd = nullptr;
   if (nrec) {
     PALLOC(k0, uint64_t, nrec); PALLOC(k1, uint64_t, nrec);
@@ -1548,16 +1551,16 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
     uint64_t *ks = where ? k1 : k0;
     uint32_t *vs = where ? v1 : v0;
     /* reuse the other value buffer and fresh arrays for the segment fold */
-    PALLOC(t_isc, uint8_t, nrec);
-    is_creator = t_isc;
+    PALLOC(t_isc, uint8_t, nrec); PALLOC(t_rep, uint8_t, nrec);
+    is_creator = t_isc; replaced = t_rep;
+    HIPCHK(hipMemsetAsync(replaced, 0, nrec, e->st));
     PALLOC(t_fwd, uint32_t, nrec); PALLOC(t_bwd, uint32_t, nrec);
     PALLOC(t_jidx, uint32_t, nrec);
     PALLOC(sctmp, uint32_t, gts_scan_tmp_elems(nrec));
     fwd = t_fwd; bwd = t_bwd; jidx = t_jidx;
     HIPCHK(hipMemsetAsync(is_creator, 1, nrec, e->st));
-    HIPCHK(hipMemsetAsync(fwd, 0xFF, nrec * 4, e->st));
     LAUNCH("build_pair_segments", k_pair_segments, nblk(nrec), GTS_BLOCK, ks, vs, d_sd,
-           is_creator, fwd, bwd, nrec, ismatepair ? 1 : 0);
+           is_creator, replaced, fwd, bwd, nrec, ismatepair ? 1 : 0);
     { ProfScope ps(e, "build_scan_creators");
       gts_exscan<uint8_t, uint32_t>(is_creator, jidx, nrec, sctmp, e->d_scalars, e->st); }
     uint32_t bad = 0;
@@ -1582,21 +1585,23 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
   if ((rc = dev_alloc(e, &e->state, m))) return rc;
   HIPCHK(hipMemsetAsync(e->vstate, GIS_UNVISITED, n ? n : 1, e->st));
   if (m) {
-    PALLOC(es0, uint32_t, m); PALLOC(es1, uint32_t, m);
-    PALLOC(id0, uint32_t, m); PALLOC(id1, uint32_t, m);
-    PALLOC(rec, GtsEdgeRec, m);
-    PALLOC(stmp2, uint32_t, gts_sort_tmp_elems(m));
-    LAUNCH("build_emit_edges", k_emit_edges, nblk(nrec), GTS_BLOCK, is_creator, jidx, fwd,
-           bwd, d_root, d_ctg, d_dist, d_sd, d_np, d_flags, es0, id0, rec, nrec);
     const int vb = bits_for(n);
     int shifts[4], np = 0;
     for (int s = 0; s < vb; s += 8) shifts[np++] = s;
+    /* the sort ping-pongs between two pairs of buffers; the persistent arrays
+       are the pair its last pass writes to, so nothing is copied afterwards */
+    PALLOC(es_t, uint32_t, m); PALLOC(id_t, uint32_t, m);
+    uint32_t *es0 = (np & 1) ? es_t : e->estart, *id0 = (np & 1) ? id_t : e->eid;
+    uint32_t *es1 = (np & 1) ? e->estart : es_t, *id1 = (np & 1) ? e->eid : id_t;
+    PALLOC(rec, GtsEdgeRec, m);
+    PALLOC(stmp2, uint32_t, gts_sort_tmp_elems(m));
+    LAUNCH("build_emit_edges", k_emit_edges, nblk(nrec), GTS_BLOCK, is_creator, replaced, jidx, fwd,
+           bwd, d_root, d_ctg, d_dist, d_sd, d_np, d_flags, es0, id0, rec, nrec);
     int where;
     { ProfScope ps(e, "build_sort_csr");
       where = gts_radix_sort<uint32_t>(es0, id0, es1, id1, m, shifts, np, stmp2, e->st); }
-    const uint32_t *ss = where ? es1 : es0, *perm = where ? id1 : id0;
-    HIPCHK(hipMemcpyAsync(e->estart, ss, (size_t)m * 4, hipMemcpyDeviceToDevice, e->st));
-    HIPCHK(hipMemcpyAsync(e->eid, perm, (size_t)m * 4, hipMemcpyDeviceToDevice, e->st));
+    if (where < 0 || (where ? es1 : es0) != e->estart)
+      return fail(e, GTSG_EHIP, "CSR sort ended in the wrong buffer");
     LAUNCH("build_row_offsets", k_row_offsets, nblk((uint64_t)m + 1), GTS_BLOCK, e->estart,
            e->row, n, m);
     LAUNCH("build_gather_csr", k_gather_csr, nblk(m), GTS_BLOCK, e->eid, rec, e->eend,
