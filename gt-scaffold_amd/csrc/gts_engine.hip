@@ -780,7 +780,7 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 /* live edge: unmarked edge between unmarked vertices.  Hooks the larger root
    under the smaller one, so a component's label is its smallest vertex. */
 __global__ void k_live_union(GtsGraphView G, const uint32_t *estart,
-                             uint8_t *live, uint32_t *parent)
+                             uint8_t *incl, uint32_t *parent)
 {
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= G.m) return;
@@ -789,9 +789,10 @@ __global__ void k_live_union(GtsGraphView G, const uint32_t *estart,
      edges and their twins (mark_vertex, algorithms.c:76-87), and no edge ever
      goes back from a marked state */
   const bool lv = !gts_edge_is_marked(G.state[p]);
-  /* bit 7: live; low bits: the edge's flags, so that k_compact_fill gets both
-     about the twin from one gather */
-  live[p] = (uint8_t)((G.flags[p] & 3u) | (lv ? 0x80u : 0u));
+  /* an edge enters the compact graph if it or its twin is live: marking a walk
+     edge's twin SCAFFOLD (algorithms.c:842-845) revives a marked twin.  The
+     twin is looked up only for an edge that is not live itself. */
+  incl[p] = lv ? 1 : !gts_edge_is_marked(G.state[G.twin[p]]) ? 1 : 0;
   if (!lv) return;
   /* (which vertices have a live edge at either end is read off the forest
      afterwards, k_component_roots: two random byte writes per live edge cost
@@ -888,18 +889,9 @@ __global__ void k_slot_bases(const uint32_t *head, const uint32_t *cidx,
   const uint32_t nc = __shfl_down(c, 1);
   if (lane == 63u || nc != c || s + 1 == nslots) atomicAdd(&comp_len[c], sum);
 }
-/* an edge enters the compact graph if it or its twin is live: marking a walk
-   edge's twin SCAFFOLD (algorithms.c:842-845) revives a marked twin.  One lane
-   per edge position; the rank of an edge among the included edges of its
-   vertex comes from one prefix sum over all positions. */
-__global__ void k_compact_flags(const uint8_t *live, const uint32_t *twin,
-                                uint8_t *incl, uint32_t m)
-{
-  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= m) return;
-  /* the twin is looked up only for an edge that is not live itself */
-  incl[p] = (live[p] & 0x80u) ? 1 : (live[twin[p]] & 0x80u) ? 1 : 0;
-}
+/* (which edges enter the compact graph: k_live_union; the rank of an edge
+   among the included edges of its vertex comes from one prefix sum over all
+   positions) */
 __global__ void k_compact_count(const uint32_t *row, const uint32_t *ipos,
                                 const uint32_t *slot_v, uint32_t *cnt,
                                 uint32_t nslots)
@@ -1969,13 +1961,13 @@ static int run_components(GtsgEngine *e, int mode)
     snap_v = sv; snap_e = se;
     HIPCHK(hipMemcpyAsync(snap_v, e->vstate, n, hipMemcpyDeviceToDevice, e->st));
     if (m) HIPCHK(hipMemcpyAsync(snap_e, e->state, m, hipMemcpyDeviceToDevice, e->st));
-    PALLOC(live, uint8_t, (size_t)m + 1); PALLOC(touched, uint8_t, n);
+    PALLOC(incl, uint8_t, (size_t)m + 1); PALLOC(touched, uint8_t, n);
     PALLOC(parent, uint32_t, n); PALLOC(flag, uint32_t, n); PALLOC(idx, uint32_t, n);
     PALLOC(sctmp, uint32_t, gts_scan_tmp_elems((uint64_t)n + m + 16));
     HIPCHK(hipMemsetAsync(touched, 0, n, e->st));
     LAUNCH("iota", k_iota, nblk(n), GTS_BLOCK, parent, (uint64_t)n);
     if (m)
-      LAUNCH("comp_live_union", k_live_union, nblk(m), GTS_BLOCK, G, e->estart, live, parent);
+      LAUNCH("comp_live_union", k_live_union, nblk(m), GTS_BLOCK, G, e->estart, incl, parent);
     LAUNCH("comp_vertices", k_component_roots, nblk(n), GTS_BLOCK, parent, touched, n);
     LAUNCH("comp_vertices", k_component_vertices, nblk(n), GTS_BLOCK, touched, e->vstate,
            parent, flag, n, mode);
@@ -2017,8 +2009,7 @@ static int run_components(GtsgEngine *e, int mode)
     LAUNCH("comp_slot_bases", k_slot_bases, nblk(nslots), GTS_BLOCK, head, cidx, comp_off, cseq,
            slot_base, slot_comp, comp_wide, comp_len, nslots);
     PALLOC(coff, uint32_t, (size_t)nslots + 1);
-    PALLOC(incl, uint8_t, (size_t)m + 1); PALLOC(ipos, uint32_t, (size_t)m + 2);
-    if (m) LAUNCH("comp_compact_flags", k_compact_flags, nblk(m), GTS_BLOCK, live, e->twin, incl, m);
+    PALLOC(ipos, uint32_t, (size_t)m + 2);
     gts_exscan<uint8_t, uint32_t>(incl, ipos, m, sctmp, ipos + m, e->st);
     LAUNCH("comp_compact_count", k_compact_count, nblk(nslots), GTS_BLOCK, e->row, ipos, slot_v,
            coff, nslots);
