@@ -120,15 +120,14 @@ def kernel_groups(kt):
 
 # bench-event name -> kernel names in the rocprofv3 --pmc passes
 PMC_NAMES = {
-    "build_sort_pairs": ["k_radix_hist<unsigned long>", "k_radix_scatter<unsigned long>"],
-    "build_sort_csr": ["k_radix_hist<unsigned int>", "k_radix_scatter<unsigned int>"],
+    "build_sort_pairs": ["k_onesweep_hist<unsigned long>", "k_radix_scatter<unsigned long, 12>"],
     "build_pair_keys": ["k_pair_keys"], "build_pair_segments": ["k_pair_segments"],
     "build_emit_edges": ["k_emit_edges"], "build_gather_csr": ["k_gather_csr"],
     "build_twins": ["k_twins"], "repeat_edges": ["k_repeat_edges"],
     "filter_pairs": ["k_filter_pairs"], "filter_ovf_init": ["k_filter_ovf_init"],
     "filter_final": ["k_filter_final"], "filter_tpoly": ["k_filter_tpoly"],
     "filter_lasthit": ["k_filter_lasthit"], "comp_live_union": ["k_live_union"],
-    "comp_compact_fill": ["k_compact_fill"],
+    "comp_compact_fill": ["k_compact_fill"], "build_twins": ["k_twins"],
 }
 
 
@@ -144,7 +143,7 @@ def recorded_traffic(name):
         return None
     d = json.load(open(path))
     if name in ("k_components_lds", "k_walk_tasks", "k_components"):
-        ks = [k for k in d if k.split("(")[0].split("<")[0] == name]
+        ks = [k for k in d if k.split("(")[0].split("<")[0].split("[")[0] == name]
         tot = sum((d[k]["fetch_bytes_per_launch_raw"] + d[k]["write_bytes_per_launch"]) * d[k]["launches"] for k in ks)
         n = sum(d[k]["launches"] for k in ks)
         return tot / n if n else None      # average over the launches of the recorded step
