@@ -88,7 +88,7 @@ def algorithmic_bytes(name, n, m, nrec, eng):
     # the launch handles, read once; states and marks written once
     if name == "k_components":
         return max(eng.stat("bytes_components_global_mem"), 0)
-    if name == "k_components_lds":        # all size classes: bytes of ONE step's launches
+    if name in ("k_components_lds", "k_components_pool"):   # all size classes: bytes of ONE step's launches
         return sum(max(eng.stat("bytes_components_lds_class%d" % i), 0) for i in range(MAX_LDS_CLASSES))
     if name == "k_walk_tasks":            # every task stages its component once; one step's launches
         return max(eng.stat("bytes_walk_tasks"), 0)
@@ -105,7 +105,9 @@ def kernel_groups(kt):
         if name.startswith("span_"):
             spans[name] = (calls, ms)
             continue
-        if name.startswith("components_makescaffold_lds") or name.startswith("components_removecycles_lds"):
+        if name in ("components_makescaffold_pool", "components_removecycles_pool"):
+            key = "k_components_pool"
+        elif name.startswith("components_makescaffold_lds") or name.startswith("components_removecycles_lds"):
             key = "k_components_lds"
         elif name == "components_walk_tasks":
             key = "k_walk_tasks"
@@ -142,7 +144,7 @@ def recorded_traffic(name):
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
-    if name in ("k_components_lds", "k_walk_tasks", "k_components"):
+    if name in ("k_components_lds", "k_components_pool", "k_walk_tasks", "k_components"):
         ks = [k for k in d if k.split("(")[0].split("<")[0].split("[")[0] == name]
         tot = sum((d[k]["fetch_bytes_per_launch_raw"] + d[k]["write_bytes_per_launch"]) * d[k]["launches"] for k in ks)
         n = sum(d[k]["launches"] for k in ks)
@@ -344,7 +346,7 @@ def main():
         # the dominant kernel: largest sum of launch durations, as rocprofv3 --stats ranks them
         dname = max(groups.items(), key=lambda kv: kv[1][1])[0]
         roof = roofline_of(dname)
-        if dname == "k_components_lds":
+        if dname in ("k_components_lds", "k_components_pool"):
             sp = spans.get("span_components_makescaffold")
             if sp and roof["algorithmic_bytes"]:
                 span_ms = sp[1] / max(sp[0], 1)
@@ -353,8 +355,8 @@ def main():
                             frac_over_span=step_bytes / (span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
             roof["note"] = ("one wavefront per connected component, graph staged in LDS: bound by "
                             "instruction issue and LDS latency of the resident waves (DESIGN.md, SQ "
-                            "counters in profiles/), not by HBM; launches of the size classes overlap, "
-                            "span_ms = fork to last join")
+                            "counters in profiles/), not by HBM; span_ms = fork to join of the component "
+                            "launches")
         sq = os.path.join(ROOT, "profiles", "sq_counters_latest.json")
         if os.path.exists(sq):
             roof["sq_counters_recorded"] = json.load(open(sq)).get(dname)
@@ -392,6 +394,11 @@ def main():
                                                  for i in range(MAX_LDS_CLASSES)
                                                  if eng.stat("lds_class%d_kb" % i) > 0},
                        components_global_mem=eng.stat("components_global_mem"),
+                       wave_us_per_lds_class={"%dk" % eng.stat("lds_class%d_kb" % i):
+                                              dict(wave_us=eng.stat("lds_class%d_wave_us" % i),
+                                                   walk_us=eng.stat("lds_class%d_walk_us" % i))
+                                              for i in range(MAX_LDS_CLASSES)
+                                              if eng.stat("lds_class%d_kb" % i) > 0},
                        **{k: eng.stat(k) for k in
                           ("us_sum_removecycles", "us_max_removecycles", "us_sum_makescaffold_other",
                            "us_max_makescaffold_other", "us_sum_walks_fast", "us_max_walks_fast",
@@ -405,7 +412,8 @@ def main():
                        walk_task_runs=eng.stat("walk_task_runs"),
                        deferred_components=eng.stat("deferred_components"),
                        by_size={"<=%s" % b: dict(components=eng.stat("size_band%d_components" % i),
-                                                 wave_us=eng.stat("size_band%d_us" % i))
+                                                 wave_us=eng.stat("size_band%d_us" % i),
+                                                 walk_us=eng.stat("size_band%d_walk_us" % i))
                                 for i, b in enumerate(("2", "3", "4", "8", "16", "32", "64", "inf"))},
                        slowest_components=[
                            {k: eng.stat("top%d_%s" % (r, k)) for k in

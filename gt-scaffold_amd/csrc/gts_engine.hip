@@ -34,7 +34,7 @@
    completely, which the small classes' workgroups prevent for milliseconds;
    seven classes 60.8 ms.) */
 static const uint32_t gts_klass_bytes[GTS_NKLASS] = {4096, 6144, 8192, 12288, 16384, 24576, 32768,
-                                                    49152, 65536, 98304, 163840};
+                                                    49152, 65536, 98304, 159744};
 /* profile-event names of the class launches: string literals, so the pointers
    kept in the pending-event table are valid in every thread for the life of
    the library ([0] removecycles, [1] makescaffold) */
@@ -57,6 +57,7 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_S_TQBASE 336
 #define GTS_S_TQCNT 352    /* u64 */
 #define GTS_S_NDEF 384     /* u64 */
+#define GTS_S_POOLCUR 392  /* u64: claim counter of k_components_pool */
 
 static const char *klass_event(int makescaffold, uint32_t bytes)
 {
@@ -123,6 +124,9 @@ struct GtsgEngine {
      deferral at all is fastest: 55.8 ms per step against 60.0 with every
      component of 256 contigs deferred (gpurun_out/r02m) */
   int64_t defer_min_work = 1ll << 17;
+  int64_t pool_components = 1;        /* all LDS components in one launch (k_components_pool) */
+  int n_cus = 256;
+  int64_t pair_walks_min_bytes = 0;   /* LDS classes of at least this size: two wavefronts per component (0 = none) */
   int64_t fast_walks = 1, lds_components = 1;
   /* walks of global-memory components fan out only on request: the components
      that end up there on the 50 M workload are scaffolds tied together by an
@@ -933,6 +937,7 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
 struct GtsWave64 {
   static const uint32_t WIDTH = 64;
   static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
+  static __device__ __forceinline__ void block_sync() { __syncthreads(); }
   static __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
   static __device__ __forceinline__ uint32_t popc(uint64_t m) { return (uint32_t)__popcll(m); }
   /* set bits of m below the calling lane (l is always lane()): v_mbcnt_lo/hi */
@@ -1032,11 +1037,12 @@ __device__ __forceinline__ T __attribute__((address_space(3))) *lds_carve(gts_ld
 }
 /* stages component c into the workgroup's LDS (packed layout) and points M at
    it; with_analysis also loads the strands / sweep order a deferred walk needs */
+template <bool FILL = true>
 __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c, char *smem,
                                                 GtsCompMemT<true> &M, bool with_analysis)
 {
   const GtsCompMem G0 = GtsComponent<GtsWave64>::global_mem(C, c);
-  const uint32_t nv = G0.nv, ne = G0.ne, lane = threadIdx.x;
+  const uint32_t nv = G0.nv, ne = G0.ne, lane = threadIdx.x & (GTS_WAVE - 1u);
   gts_lds_cursor p = (gts_lds_cursor)smem;
   typedef GtsCompMemT<true>::idx_t idx_t;
   M.nv = nv; M.ne = ne; M.e0 = 0;
@@ -1061,6 +1067,9 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   auto cdist = lds_carve<int32_t>(p, ne);
   auto cfs = lds_carve<uint8_t>(p, ne);   /* flags | state << 4 */
   M.cflags.b = cfs; M.cstate.b = cfs;
+  M.coff = coff; M.cseq = cseq; M.cend = cend; M.cdist = cdist;
+  M.cstart.coff = coff; M.cstart.nv = nv;
+  if (!FILL) return;
   for (uint32_t i = lane; i <= nv; i += GTS_WAVE) coff[i] = (idx_t)(G0.coff[i] - G0.e0);
   for (uint32_t i = lane; i < nv; i += GTS_WAVE) {
     cseq[i] = (int32_t)G0.cseq[i]; M.vst[i] = G0.vst[i];
@@ -1073,9 +1082,13 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
     cend[i] = (idx_t)G0.cend[i]; cdist[i] = (int32_t)G0.cdist[i];
     cfs[i] = (uint8_t)((G0.cflags[i] & 15u) | (G0.cstate[i] << 4));
   }
-  M.coff = coff; M.cseq = cseq; M.cend = cend; M.cdist = cdist;
-  M.cstart.coff = coff; M.cstart.nv = nv;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+/* the pointers only: for a second wavefront on a component staged by the first */
+__device__ __forceinline__ void stage_component_view(const GtsCompView &C, uint32_t c, char *smem,
+                                                     GtsCompMemT<true> &M)
+{
+  stage_component<false>(C, c, smem, M, false);
 }
 
 __global__ void __launch_bounds__(GTS_WAVE)
@@ -1088,6 +1101,181 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
   stage_component(C, c, smem, M, false);
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.run(mode);
+}
+
+/* The same on two wavefronts (gts_component.hpp, run_pair): the classes whose
+   wave time is long enough for the second wavefront to pay are launched with
+   this kernel.  A component whose pair layout does not fit the launch's LDS
+   (the largest class holds some) runs on wavefront 0 alone. */
+__global__ void __launch_bounds__(2 * GTS_WAVE)
+k_components_lds_pair(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
+                      uint32_t lds_bytes)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x >= count) return;
+  const uint32_t c = order[first + blockIdx.x];
+  const uint32_t w = threadIdx.x / GTS_WAVE;
+  const uint32_t s0 = C.comp_off[c], s1 = C.comp_off[c + 1];
+  const uint32_t nv = s1 - s0, ne = C.coff[s1] - C.coff[s0];
+  const bool pair = gts_comp_lds_bytes_pair(nv, ne) <= lds_bytes;
+  GtsCompMemT<true> M;
+  if (!pair) {
+    if (w) return;
+    stage_component(C, c, smem, M, false);
+    GtsComponent<GtsWave64, true> prog(C, M, c);
+    prog.run(mode);
+    return;
+  }
+  typedef GtsCompMemT<true>::idx_t idx_t;
+  volatile GtsPairCtl *ctl = (volatile GtsPairCtl *)smem;
+  gts_lds_cursor p = (gts_lds_cursor)(smem + GTS_PAIR_CTL_BYTES + gts_comp_lds_bytes(nv, ne));
+  auto queue1 = lds_carve<idx_t>(p, nv); auto st_par1 = lds_carve<idx_t>(p, nv);
+  auto edgemap1 = lds_carve<idx_t>(p, nv); auto par1 = lds_carve<idx_t>(p, nv);
+  auto best1 = lds_carve<idx_t>(p, nv);
+  auto distmap1 = lds_carve<float>(p, nv);
+  auto nd1 = lds_carve<int32_t>(p, nv); auto plen1 = lds_carve<uint32_t>(p, nv);
+  if (w == 0) stage_component(C, c, smem + GTS_PAIR_CTL_BYTES, M, false);
+  else for (uint32_t i = threadIdx.x - GTS_WAVE; i < nv; i += GTS_WAVE) distmap1[i] = GTS_DIST_UNSET;
+  __syncthreads();
+  if (w == 1) {
+    /* the same view (pointer arithmetic only), then the private walk scratch */
+    stage_component_view(C, c, smem + GTS_PAIR_CTL_BYTES, M);
+    M.queue = queue1; M.st_par = st_par1; M.edgemap = edgemap1; M.par = par1; M.cc_best = best1;
+    M.distmap = distmap1; M.nd = nd1; M.plen = plen1;
+    M.st_cur = best1; M.lastpop = (uint32_t __attribute__((address_space(3))) *)nd1;
+  }
+  GtsComponent<GtsWave64, true> prog(C, M, c);
+  prog.run_pair(mode, w, ctl, best1);
+}
+
+/* ---- all LDS components in ONE launch: a pool of wavefronts per CU -----------
+   One workgroup of GTS_POOL_WAVES wavefronts per CU owns (almost) all of the
+   CU's LDS as a pool of GTS_POOL_PAGE-byte pages.  Every wavefront works on its
+   own: it claims the next component from the list sorted by decreasing
+   footprint -- from the FRONT (largest first) or, while another wavefront of
+   the workgroup is waiting for room for a front component, from the BACK
+   (smallest first) --, allocates the component's pages, stages it, runs the
+   component program, frees the pages and claims again.  Large components
+   start first (their wave time is the critical path), the LDS they leave and
+   the wave slots they do not use are filled with small ones: the CU is bound
+   by LDS at the start and by wave slots at the end, not by one of them after
+   the other as a launch per size class is.
+
+   Claims: one 64-bit counter, front claims add 1, back claims add 2^32; the
+   value before the add (h, t) gives index h resp. count-1-t, valid while
+   h + t < count -- every index is handed out once, an invalid claim ends the
+   wavefront (every wavefront gets there: the exit condition).
+   A waiting wavefront holds no pages, and what it waits for is released by
+   wavefronts that run to completion, so it gets its turn; while it waits, back
+   components may only take pages above the ones it needs. */
+#define GTS_POOL_WAVES 16u
+#define GTS_POOL_PAGE 2048u
+#define GTS_POOL_PAGES 78u                      /* 156 KB */
+#define GTS_POOL_BYTES (GTS_POOL_PAGES * GTS_POOL_PAGE)
+struct GtsPoolCtl {
+  uint32_t lock;
+  uint32_t front_busy;     /* a wavefront holds a front claim it has no pages for yet */
+  uint32_t wait_pages;     /* pages that wavefront needs (0: it is not waiting) */
+  uint32_t used[3];        /* page bitmap */
+};
+__device__ __forceinline__ bool pool_run_free(const volatile uint32_t *used, uint32_t pos, uint32_t n)
+{
+  for (uint32_t q = pos; q < pos + n; ++q)
+    if (used[q >> 5] >> (q & 31u) & 1u) return false;
+  return true;
+}
+/* first fit from below (front) or from above (back, not below `floor`); lane 0, lock held */
+__device__ __forceinline__ uint32_t pool_find(const volatile uint32_t *used, uint32_t n, bool from_below,
+                                              uint32_t floor)
+{
+  if (n > GTS_POOL_PAGES - floor) return GTS_NONE;
+  if (from_below) {
+    for (uint32_t pos = floor; pos + n <= GTS_POOL_PAGES; ++pos)
+      if (pool_run_free(used, pos, n)) return pos;
+  } else {
+    for (uint32_t pos = GTS_POOL_PAGES - n + 1; pos-- > floor;)
+      if (pool_run_free(used, pos, n)) return pos;
+  }
+  return GTS_NONE;
+}
+__device__ __forceinline__ void pool_lock(GtsPoolCtl *ctl)
+{
+  while (atomicCAS(&ctl->lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void pool_unlock(GtsPoolCtl *ctl)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  atomicExch(&ctl->lock, 0u);
+}
+__global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
+k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
+                  unsigned long long *cursor)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ GtsPoolCtl ctl_s;
+  GtsPoolCtl *ctl = &ctl_s;
+  if (threadIdx.x == 0) {
+    ctl->lock = 0; ctl->front_busy = 0; ctl->wait_pages = 0;
+    ctl->used[0] = ctl->used[1] = ctl->used[2] = 0;
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & (GTS_WAVE - 1u);
+  for (;;) {
+    /* role, claim, pages: lane 0; the rest of the wavefront waits at the broadcast */
+    uint32_t idx = GTS_NONE, pos = 0, npages = 0;
+    if (lane == 0) {
+      pool_lock(ctl);
+      const bool front = ((volatile GtsPoolCtl *)ctl)->front_busy == 0;
+      if (front) ((volatile GtsPoolCtl *)ctl)->front_busy = 1;
+      pool_unlock(ctl);
+      const unsigned long long old = atomicAdd(cursor, front ? 1ull : 1ull << 32);
+      const uint64_t h = old & 0xFFFFFFFFull, t = old >> 32;
+      if (h + t < (uint64_t)count) idx = front ? (uint32_t)h : count - 1u - (uint32_t)t;
+      if (idx != GTS_NONE) {
+        const uint32_t c = order[first + idx];
+        const uint32_t s0 = C.comp_off[c], s1 = C.comp_off[c + 1];
+        npages = (gts_comp_lds_bytes(s1 - s0, C.coff[s1] - C.coff[s0]) + GTS_POOL_PAGE - 1u) / GTS_POOL_PAGE;
+        bool waiting = false;
+        for (;;) {
+          pool_lock(ctl);
+          volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
+          const uint32_t floor = front ? 0u : v->wait_pages;
+          pos = pool_find(v->used, npages, front, floor);
+          if (pos != GTS_NONE) {
+            for (uint32_t q = pos; q < pos + npages; ++q) v->used[q >> 5] |= 1u << (q & 31u);
+            if (front) { v->front_busy = 0; v->wait_pages = 0; }
+          } else if (front && !waiting) {
+            v->wait_pages = npages; waiting = true;
+          }
+          pool_unlock(ctl);
+          if (pos != GTS_NONE) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+      } else if (front) {
+        pool_lock(ctl);
+        ((volatile GtsPoolCtl *)ctl)->front_busy = 0;
+        pool_unlock(ctl);
+      }
+    }
+    idx = GtsWave64::uni(idx);
+    if (idx == GTS_NONE) break;
+    pos = GtsWave64::uni(pos); npages = GtsWave64::uni(npages);
+    {
+      const uint32_t c = order[first + idx];
+      GtsCompMemT<true> M;
+      stage_component(C, c, smem + pos * GTS_POOL_PAGE, M, false);
+      GtsComponent<GtsWave64, true> prog(C, M, c);
+      prog.run(mode);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) {
+      pool_lock(ctl);
+      volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
+      for (uint32_t q = pos; q < pos + npages; ++q) v->used[q >> 5] &= ~(1u << (q & 31u));
+      pool_unlock(ctl);
+    }
+  }
 }
 
 /* one deferred walk per workgroup (gts_component.hpp, try_defer / walk_task);
@@ -1173,7 +1361,7 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 const uint8_t *comp_wide, const unsigned long long *comp_len,
                                 uint8_t *comp_klass, const uint32_t *klass, uint32_t nklass,
                                 uint32_t *klass_count, unsigned long long *klass_bytes,
-                                uint32_t *klass_slots)
+                                uint32_t *klass_slots, uint32_t pair_min_bytes)
 {
   /* counters are summed per workgroup in LDS first: seven global counters hit by
      every component serialise */
@@ -1186,6 +1374,13 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
     const uint32_t s0 = comp_off[c], s1 = comp_off[c + 1];
     const uint32_t cnv = s1 - s0, cne = coff[s1] - coff[s0];
     uint32_t need = gts_comp_lds_bytes(cnv, cne);
+    /* the classes above pair_min_bytes run two wavefronts per component: the
+       second one's walk scratch counts (unless that pushes the component out of
+       LDS altogether -- it then runs on one wavefront in the largest class) */
+    if (need > pair_min_bytes) {
+      const uint32_t need2 = gts_comp_lds_bytes_pair(cnv, cne);
+      if (need2 <= klass[nklass ? nklass - 1 : 0]) need = need2;
+    }
     /* not representable in the packed LDS layout: run from global memory */
     if (comp_wide[c] || cnv >= 4096u || cne > GTS_LDS_MAX_INDEX || comp_len[c] >= (1ull << 32))
       need = 0x7FFFFFFFu;
@@ -1366,9 +1561,15 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
     if (hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
   if (!rc && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
   const void *big_lds[] = {(const void *)k_walk_tasks_mixed, (const void *)k_walk_tasks,
-                           (const void *)k_components_lds};
+                           (const void *)k_components_lds, (const void *)k_components_lds_pair,
+                           (const void *)k_components_pool};
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+      e->n_cus = cus;
+  }
   for (const void *f : big_lds)
-    if (!rc && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess) {
+    if (!rc && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159744) != hipSuccess) {
       fprintf(stderr, "gtsg_create: cannot raise the dynamic LDS limit to 160 KiB\n");
       rc = GTSG_EHIP;
     }
@@ -1420,6 +1621,8 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
   else if (!strcmp(name, "defer_min_work") && value >= 0) e->defer_min_work = value;
+  else if (!strcmp(name, "pair_walks_min_bytes") && value >= 0) e->pair_walks_min_bytes = value;
+  else if (!strcmp(name, "pool_components")) e->pool_components = value != 0;
   else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NSTREAMS) e->class_streams = value;
   else if (!strcmp(name, "mixed_task_limit") && value >= 0) e->mixed_task_limit = value;
 
@@ -2069,9 +2272,18 @@ static int run_components(GtsgEngine *e, int mode)
     uint32_t *klass_d = e->d_scalars + GTS_S_KSIZE, *klass_count = e->d_scalars + GTS_S_KCOUNT;
     HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_KSIZE, 0, (GTS_S_NDEF + 4 - GTS_S_KSIZE) * 4, e->st));
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, nklass * sizeof(uint32_t), hipMemcpyHostToDevice, e->st));
+    /* two wavefronts per component in the classes of at least
+       pair_walks_min_bytes: pair_min = the size of the class below them (a
+       component is assigned by the footprint of the kernel that runs its class) */
+    uint32_t pair_min = 0xFFFFFFFFu;
+    if (mode == GTS_MODE_MAKESCAFFOLD && e->lds_components && e->pair_walks_min_bytes > 0) {
+      for (uint32_t k = 0; k < nklass; ++k)
+        if ((int64_t)klass_h[k] >= e->pair_walks_min_bytes) { pair_min = k ? klass_h[k - 1] : 0u; break; }
+    }
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
            ncomp, comp_wide, comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? nklass : 0), klass_count,
-           (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS);
+           (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS,
+           pair_min);
     LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + GTS_S_KSLOTS, e->d_scalars + GTS_S_TQBASE);
     const uint32_t *order;
     {
@@ -2148,13 +2360,42 @@ static int run_components(GtsgEngine *e, int mode)
          before the statistics.  The runtime multiplexes a process' streams
          onto GPU_MAX_HW_QUEUES hardware queues (default 4, the main stream
          included): that many launches are in flight at a time. */
-      for (int k = (int)nk - 1; k >= 0; --k) {
+      uint32_t pooled = 0;
+      if (e->pool_components)
+        for (uint32_t k = 0; k < nk; ++k) {
+          pooled += kcount[k];
+          e->stats["components_lds_class" + std::to_string(k)] = kcount[k];
+        }
+      if (pooled) {
+        /* one launch for all of them: a workgroup per CU, its wavefronts claim
+           components until none is left (k_components_pool) */
+        hipStream_t ss = e->side[0];
+        unsigned long long *cursor = (unsigned long long *)(e->d_scalars + GTS_S_POOLCUR);
+        HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
+        HIPCHK(hipMemsetAsync(cursor, 0, 8, ss));
+        hipEvent_t _a = nullptr, _b = nullptr;
+        if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
+        k_components_pool<<<e->n_cus, GTS_POOL_WAVES * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, order, first, pooled,
+                                                                                     mode, cursor);
+        if (e->profile) { hipEventRecord(_b, ss);
+                          e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_pool"
+                                                                              : "components_removecycles_pool",
+                                                _a, _b}); }
+        HIPCHK(hipEventRecord(e->ev_join[0], ss));
+        HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[0], 0));
+        first += pooled;
+      }
+      for (int k = (int)nk - 1; k >= 0 && !pooled; --k) {
         if (!kcount[k]) continue;
         hipStream_t ss = e->side[((int)nk - 1 - k) % (int)e->class_streams];
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
-        k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode);
+        if (klass_h[k] > pair_min)
+          k_components_lds_pair<<<kcount[k], 2 * GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode,
+                                                                           klass_h[k]);
+        else
+          k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode);
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({klass_event(mode == GTS_MODE_MAKESCAFFOLD, klass_h[k]), _a, _b}); }
         HIPCHK(hipEventRecord(e->ev_join[k], ss));
@@ -2164,7 +2405,7 @@ static int run_components(GtsgEngine *e, int mode)
       }
       /* joins after the last launch: a wait queued earlier would hold back a
          side stream that shares its hardware queue with this stream */
-      for (uint32_t k = 0; k < nk; ++k)
+      for (uint32_t k = 0; k < nk && !pooled; ++k)
         if (kcount[k]) HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[k], 0));
       if (e->profile) {
         hipEventRecord(span_b, e->st);
@@ -2299,9 +2540,20 @@ static int run_components(GtsgEngine *e, int mode)
       HIPCHK(hipMemcpy(hc.data(), stat_clean, (size_t)ncomp * 4, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(ho.data(), comp_off, ((size_t)ncomp + 1) * 4, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(hco.data(), coff, ((size_t)nslots + 1) * 4, hipMemcpyDeviceToHost));
+      if (const char *dump = getenv("GTS_DUMP_COMPONENTS")) {   /* input of tools/sim/pack_sim.py: contigs, edges, clocks per component */
+        FILE *f = fopen(dump, "wb");
+        if (f) {
+          for (uint32_t c2 = 0; c2 < ncomp; ++c2) {
+            uint64_t rec[6] = {ho[c2 + 1] - ho[c2], hco[ho[c2 + 1]] - hco[ho[c2]], ht[5 * (size_t)c2],
+                               ht[5 * (size_t)c2 + 1], ht[5 * (size_t)c2 + 2], ht[5 * (size_t)c2 + 3]};
+            fwrite(rec, 8, 6, f);
+          }
+          fclose(f);
+        }
+      }
       {   /* component sizes and the time spent per size band */
         static const uint32_t band[8] = {2, 3, 4, 8, 16, 32, 64, 0xFFFFFFFFu};
-        uint64_t bc[8] = {0}, bt[8] = {0};
+        uint64_t bc[8] = {0}, bt[8] = {0}, bw[8] = {0};
         for (uint32_t c2 = 0; c2 < ncomp; ++c2) {
           const uint32_t sz = ho[c2 + 1] - ho[c2];
           int b = 0;
@@ -2309,10 +2561,27 @@ static int run_components(GtsgEngine *e, int mode)
           ++bc[b];
           const uint64_t *t = &ht[5 * (size_t)c2];
           bt[b] += t[0] + t[1] + t[2] + t[3];
+          bw[b] += t[2] + t[3];
+        }
+        {   /* the same per LDS size class ([GTS_NKLASS] = global memory) */
+          std::vector<uint8_t> hk((size_t)ncomp);
+          HIPCHK(hipMemcpy(hk.data(), comp_klass, (size_t)ncomp, hipMemcpyDeviceToHost));
+          uint64_t kt[GTS_NKLASS + 1] = {0}, kw[GTS_NKLASS + 1] = {0};
+          for (uint32_t c2 = 0; c2 < ncomp; ++c2) {
+            const uint64_t *t = &ht[5 * (size_t)c2];
+            const int k = hk[c2] <= GTS_NKLASS ? hk[c2] : GTS_NKLASS;
+            kt[k] += t[0] + t[1] + t[2] + t[3];
+            kw[k] += t[2] + t[3];
+          }
+          for (int k = 0; k <= GTS_NKLASS; ++k) {
+            e->stats["lds_class" + std::to_string(k) + "_wave_us"] = (int64_t)(kt[k] / 100);
+            e->stats["lds_class" + std::to_string(k) + "_walk_us"] = (int64_t)(kw[k] / 100);
+          }
         }
         for (int b = 0; b < 8; ++b) {
           e->stats["size_band" + std::to_string(b) + "_components"] = (int64_t)bc[b];
           e->stats["size_band" + std::to_string(b) + "_us"] = (int64_t)(bt[b] / 100);
+          e->stats["size_band" + std::to_string(b) + "_walk_us"] = (int64_t)(bw[b] / 100);
         }
       }
       auto total = [&](uint32_t c2) { const uint64_t *t = &ht[5 * (size_t)c2]; return t[0] + t[1] + t[2] + t[3]; };
