@@ -394,6 +394,9 @@ def main():
                                                  for i in range(MAX_LDS_CLASSES)
                                                  if eng.stat("lds_class%d_kb" % i) > 0},
                        components_global_mem=eng.stat("components_global_mem"),
+                       pool={k[5:]: eng.stat(k) for k in
+                             ("pool_us_sum_run", "pool_us_sum_wait_pages", "pool_us_sum_wave_life",
+                              "pool_us_first_exit", "pool_us_last_exit")},
                        wave_us_per_lds_class={"%dk" % eng.stat("lds_class%d_kb" % i):
                                               dict(wave_us=eng.stat("lds_class%d_wave_us" % i),
                                                    walk_us=eng.stat("lds_class%d_walk_us" % i))

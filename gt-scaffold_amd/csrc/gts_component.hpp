@@ -265,28 +265,6 @@ GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
   b += ((ne + a - 1) / a) * a;                        /* flags + state */
   return b;
 }
-/* Two wavefronts on one staged component (k_components_lds_pair): the second
-   one walks every other terminal of a cc with walk scratch of its own --
-   queue, st_par, edgemap, par, cc_best (16 bit), distmap, nd, plen (32 bit) --
-   behind a small control block. */
-struct GtsPairCtl {
-  uint64_t len[2];        /* best walk of each wavefront for the cc in hand */
-  uint32_t n[2], j[2];    /* its number of edges, the terminal it starts at */
-  uint32_t ncc;           /* ccs to walk (0: nothing for the second wavefront to do) */
-  uint32_t clean;         /* the component's analysis holds: the second wavefront takes part */
-  uint32_t redo;          /* a walk of the second wavefront needs the reference search */
-  uint32_t abort;         /* written by wavefront 0 between a cc's two barriers only */
-  uint32_t nfast1;        /* statistics of the second wavefront */
-  uint32_t err1;          /* error of the second wavefront */
-  uint64_t tfast1;
-};
-#define GTS_PAIR_CTL_BYTES 64u
-GTS_HD uint32_t gts_comp_lds_bytes_pair(uint32_t nv, uint32_t ne)
-{
-  const uint32_t a = 16;
-  return GTS_PAIR_CTL_BYTES + gts_comp_lds_bytes(nv, ne) + ((nv * 2 + a - 1) / a) * a * 5 +
-         ((nv * 4 + a - 1) / a) * a * 3;
-}
 /* the packed layout addresses at most this many slots / edges */
 #define GTS_LDS_MAX_INDEX 65000u
 
@@ -1722,126 +1700,6 @@ struct GtsComponent {
     W::fence();
   }
 
-  /* ---- a component on TWO wavefronts ---------------------------------------
-     The walks of the terminals of one cc are independent of each other: the
-     best one is marked after all of them (algorithms.c:817-848).  Wavefront 0
-     runs the program; for a cc with several terminals of a clean component
-     wavefront 1 (same staged graph, walk scratch of its own: `this` is then
-     the object built on that view) takes every other terminal.  The reference
-     keeps the first strictly longest walk in terminal order, i.e. the longest
-     and among equals the one of the earliest terminal: each wavefront keeps
-     that of its share, wavefront 0 takes the better of the two.  A wavefront
-     stops early after a walk that holds every contig (nothing can be strictly
-     longer); walks the sequential order would have skipped cannot win.  If a
-     walk of wavefront 1 needs the reference search the whole cc is redone by
-     wavefront 0 alone.  `best1` is wavefront 1's cc_best array. */
-  template <class BestPtr>
-  GTS_HD void run_pair(int mode, uint32_t w, volatile GtsPairCtl *ctl, BestPtr best1)
-  {
-    const uint32_t lane = W::lane();
-    const uint64_t t0 = W::clock();
-    uint64_t t1 = t0;
-    bool was_clean = false, deferred = false;
-    if (w == 0) {
-      removecycles(mode == GTS_MODE_MAKESCAFFOLD);
-      reuse_cc = clean;
-      t1 = W::clock();
-      was_clean = clean;
-      bool walks = false;
-      if (mode == GTS_MODE_MAKESCAFFOLD) {
-        if (C.defer_min_nv && nv >= C.defer_min_nv) {
-          if (!reuse_cc) { calc_cc(); reuse_cc = true; }
-          deferred = try_defer();
-        }
-        if (!deferred) {
-          if (!reuse_cc) calc_cc();
-          for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }
-          walks = true;
-        }
-      }
-      if (lane == 0) {
-        ctl->ncc = walks ? ncc : 0; ctl->clean = clean ? 1u : 0u; ctl->redo = 0; ctl->abort = 0;
-        ctl->nfast1 = 0; ctl->tfast1 = 0; ctl->err1 = 0;
-      }
-      W::fence();
-    }
-    W::block_sync();
-    const uint32_t n_cc = W::uni(ctl->ncc);
-    if (w == 1) { clean = W::uni(ctl->clean) != 0; no_reference = true; }
-    const bool both = clean;
-    auto ccoff = M.ccoff;
-    for (uint32_t i = 0; i < n_cc; ++i) {
-      const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
-      if (te - tb == 1 && w == 0) lonesome(W::uni(M.term[tb]));
-      if (te - tb < 2) continue;
-      uint64_t my_len = 0;
-      uint32_t my_n = 0, my_j = GTS_NONE;
-      bool redo = false;
-      if (w == 0 || both) {
-        for (uint32_t j = tb + (both ? w : 0); j < te; j += both ? 2 : 1) {
-          if (my_len == all_bases()) break;
-          const uint64_t prev = my_len;
-          needs_reference = false;
-          if (!create_walk(W::uni(M.term[j]), my_len, my_n)) break;
-          if (needs_reference) { redo = true; break; }
-          if (my_len > prev) my_j = j;
-        }
-      }
-      if (lane == 0) {
-        ctl->len[w] = my_len; ctl->n[w] = my_n; ctl->j[w] = my_j;
-        if (w == 1 && redo) ctl->redo = 1;
-        if (w == 1 && err) ctl->err1 = err;
-      }
-      W::fence();
-      W::block_sync();
-      if (w == 0) {
-        if (!err) err = W::uni(ctl->err1);
-        if (!err && both && W::uni(ctl->redo)) {
-          /* as makescaffold(): every terminal in order, on this wavefront */
-          my_len = 0; my_n = 0;
-          for (uint32_t j = tb; j < te; ++j) {
-            if (my_len == all_bases()) break;
-            if (!create_walk(W::uni(M.term[j]), my_len, my_n)) break;
-          }
-          if (!err) mark_best(M.cc_best, my_n);
-          if (lane == 0) ctl->redo = 0;
-        } else if (!err) {
-          const uint64_t len1 = both ? (uint64_t)W::uni64((int64_t)ctl->len[1]) : 0;
-          const uint32_t j1 = W::uni(ctl->j[1]);
-          if (len1 > my_len || (len1 == my_len && len1 > 0 && j1 < my_j))
-            mark_best(best1, W::uni(ctl->n[1]));
-          else
-            mark_best(M.cc_best, my_n);
-        }
-        if (err && lane == 0) ctl->abort = 1;   /* read by both after the barrier below */
-        W::fence();
-      }
-      W::block_sync();
-      if (W::uni(ctl->abort)) break;
-    }
-    if (w == 1) {
-      if (lane == 0) { ctl->nfast1 = nfast; ctl->tfast1 = tfast; }
-      W::fence();
-    }
-    W::block_sync();
-    if (w != 0) return;
-    nfast += W::uni(ctl->nfast1);
-    tfast += (uint64_t)W::uni64((int64_t)ctl->tfast1);
-    const uint64_t t2 = W::clock();
-    for (uint32_t s = lane; s < nv; s += W::WIDTH) C.G.vstate[C.slot_v[s0 + s]] = M.vst[s];
-    if (lane == 0) {
-      C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow;
-      C.stat_clean[c] = (was_clean ? 1u : 0u) | (deferred ? 2u : 0u) | (nodefer << 2) | (nterm << 8);
-      C.tstat[5 * (uint64_t)c] = t1 - t0;
-      C.tstat[5 * (uint64_t)c + 1] = t2 - t1 - tfast - tslow;
-      C.tstat[5 * (uint64_t)c + 2] = tfast;
-      C.tstat[5 * (uint64_t)c + 3] = tslow;
-      C.tstat[5 * (uint64_t)c + 4] = npops;
-    }
-    W::fence();
-  }
-
-
   /* ---- fan-out of the walks of a large component -------------------------
      The terminals of every cc are found before the first walk
      (algorithms.c:784) and SCAFFOLD is an unmarked state, so marking the
@@ -2146,7 +2004,6 @@ struct GtsWave1 {
   static GTS_HD uint32_t uni(uint32_t v) { return v; }
   static GTS_HD int64_t uni64(int64_t v) { return v; }
   static GTS_HD void fence() {}
-  static GTS_HD void block_sync() {}
   static GTS_HD uint64_t clock() { return 0; }
   static GTS_HD void count(unsigned long long *p) { ++*p; }
   static GTS_HD void count_n(uint32_t *p, uint32_t n) { *p += n; }

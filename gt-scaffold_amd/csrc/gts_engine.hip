@@ -57,7 +57,9 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_S_TQBASE 336
 #define GTS_S_TQCNT 352    /* u64 */
 #define GTS_S_NDEF 384     /* u64 */
+#define GTS_POOL_WAVES 16u /* wavefronts of a k_components_pool workgroup (one per CU) */
 #define GTS_S_POOLCUR 392  /* u64: claim counter of k_components_pool */
+#define GTS_S_POOLSTAT 400 /* 9 x u64: clocks and give-up counts of k_components_pool */
 
 static const char *klass_event(int makescaffold, uint32_t bytes)
 {
@@ -125,8 +127,8 @@ struct GtsgEngine {
      component of 256 contigs deferred (gpurun_out/r02m) */
   int64_t defer_min_work = 1ll << 17;
   int64_t pool_components = 1;        /* all LDS components in one launch (k_components_pool) */
+  int64_t pool_waves = GTS_POOL_WAVES; /* wavefronts per workgroup of that launch */
   int n_cus = 256;
-  int64_t pair_walks_min_bytes = 0;   /* LDS classes of at least this size: two wavefronts per component (0 = none) */
   int64_t fast_walks = 1, lds_components = 1;
   /* walks of global-memory components fan out only on request: the components
      that end up there on the 50 M workload are scaffolds tied together by an
@@ -937,7 +939,6 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
 struct GtsWave64 {
   static const uint32_t WIDTH = 64;
   static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
-  static __device__ __forceinline__ void block_sync() { __syncthreads(); }
   static __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
   static __device__ __forceinline__ uint32_t popc(uint64_t m) { return (uint32_t)__popcll(m); }
   /* set bits of m below the calling lane (l is always lane()): v_mbcnt_lo/hi */
@@ -1037,7 +1038,6 @@ __device__ __forceinline__ T __attribute__((address_space(3))) *lds_carve(gts_ld
 }
 /* stages component c into the workgroup's LDS (packed layout) and points M at
    it; with_analysis also loads the strands / sweep order a deferred walk needs */
-template <bool FILL = true>
 __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c, char *smem,
                                                 GtsCompMemT<true> &M, bool with_analysis)
 {
@@ -1069,7 +1069,6 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   M.cflags.b = cfs; M.cstate.b = cfs;
   M.coff = coff; M.cseq = cseq; M.cend = cend; M.cdist = cdist;
   M.cstart.coff = coff; M.cstart.nv = nv;
-  if (!FILL) return;
   for (uint32_t i = lane; i <= nv; i += GTS_WAVE) coff[i] = (idx_t)(G0.coff[i] - G0.e0);
   for (uint32_t i = lane; i < nv; i += GTS_WAVE) {
     cseq[i] = (int32_t)G0.cseq[i]; M.vst[i] = G0.vst[i];
@@ -1084,13 +1083,6 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
-/* the pointers only: for a second wavefront on a component staged by the first */
-__device__ __forceinline__ void stage_component_view(const GtsCompView &C, uint32_t c, char *smem,
-                                                     GtsCompMemT<true> &M)
-{
-  stage_component<false>(C, c, smem, M, false);
-}
-
 __global__ void __launch_bounds__(GTS_WAVE)
 k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode)
 {
@@ -1101,51 +1093,6 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
   stage_component(C, c, smem, M, false);
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.run(mode);
-}
-
-/* The same on two wavefronts (gts_component.hpp, run_pair): the classes whose
-   wave time is long enough for the second wavefront to pay are launched with
-   this kernel.  A component whose pair layout does not fit the launch's LDS
-   (the largest class holds some) runs on wavefront 0 alone. */
-__global__ void __launch_bounds__(2 * GTS_WAVE)
-k_components_lds_pair(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
-                      uint32_t lds_bytes)
-{
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (blockIdx.x >= count) return;
-  const uint32_t c = order[first + blockIdx.x];
-  const uint32_t w = threadIdx.x / GTS_WAVE;
-  const uint32_t s0 = C.comp_off[c], s1 = C.comp_off[c + 1];
-  const uint32_t nv = s1 - s0, ne = C.coff[s1] - C.coff[s0];
-  const bool pair = gts_comp_lds_bytes_pair(nv, ne) <= lds_bytes;
-  GtsCompMemT<true> M;
-  if (!pair) {
-    if (w) return;
-    stage_component(C, c, smem, M, false);
-    GtsComponent<GtsWave64, true> prog(C, M, c);
-    prog.run(mode);
-    return;
-  }
-  typedef GtsCompMemT<true>::idx_t idx_t;
-  volatile GtsPairCtl *ctl = (volatile GtsPairCtl *)smem;
-  gts_lds_cursor p = (gts_lds_cursor)(smem + GTS_PAIR_CTL_BYTES + gts_comp_lds_bytes(nv, ne));
-  auto queue1 = lds_carve<idx_t>(p, nv); auto st_par1 = lds_carve<idx_t>(p, nv);
-  auto edgemap1 = lds_carve<idx_t>(p, nv); auto par1 = lds_carve<idx_t>(p, nv);
-  auto best1 = lds_carve<idx_t>(p, nv);
-  auto distmap1 = lds_carve<float>(p, nv);
-  auto nd1 = lds_carve<int32_t>(p, nv); auto plen1 = lds_carve<uint32_t>(p, nv);
-  if (w == 0) stage_component(C, c, smem + GTS_PAIR_CTL_BYTES, M, false);
-  else for (uint32_t i = threadIdx.x - GTS_WAVE; i < nv; i += GTS_WAVE) distmap1[i] = GTS_DIST_UNSET;
-  __syncthreads();
-  if (w == 1) {
-    /* the same view (pointer arithmetic only), then the private walk scratch */
-    stage_component_view(C, c, smem + GTS_PAIR_CTL_BYTES, M);
-    M.queue = queue1; M.st_par = st_par1; M.edgemap = edgemap1; M.par = par1; M.cc_best = best1;
-    M.distmap = distmap1; M.nd = nd1; M.plen = plen1;
-    M.st_cur = best1; M.lastpop = (uint32_t __attribute__((address_space(3))) *)nd1;
-  }
-  GtsComponent<GtsWave64, true> prog(C, M, c);
-  prog.run_pair(mode, w, ctl, best1);
 }
 
 /* ---- all LDS components in ONE launch: a pool of wavefronts per CU -----------
@@ -1161,46 +1108,72 @@ k_components_lds_pair(GtsCompView C, const uint32_t *order, uint32_t first, uint
    by LDS at the start and by wave slots at the end, not by one of them after
    the other as a launch per size class is.
 
-   Claims: one 64-bit counter, front claims add 1, back claims add 2^32; the
-   value before the add (h, t) gives index h resp. count-1-t, valid while
-   h + t < count -- every index is handed out once, an invalid claim ends the
-   wavefront (every wavefront gets there: the exit condition).
+   Claims: one 64-bit counter, a front claim of B adds B, a back claim B * 2^32;
+   the value before the add (h, t) gives the indices h .. h+B-1 resp.
+   count-1-t downwards, those of them valid that the other end has not reached
+   (h' + t' < count) -- every index is handed out once.  The workgroup claims
+   for its wavefronts and keeps the indices in stock (a single counter hit
+   once per component by 4096 wavefronts is what the launch would wait for:
+   same-address atomics across the XCDs run at a few tens per microsecond):
+   one at a time among the `nbig` largest, GTS_POOL_BATCH at a time after that
+   and from the back.  A wavefront that finds stock and both ends empty leaves
+   (every wavefront gets there: the exit condition).
    A waiting wavefront holds no pages, and what it waits for is released by
    wavefronts that run to completion, so it gets its turn; while it waits, back
    components may only take pages above the ones it needs. */
-#define GTS_POOL_WAVES 16u
 #define GTS_POOL_PAGE 2048u
-#define GTS_POOL_PAGES 78u                      /* 156 KB */
+#define GTS_POOL_PAGES 78u                      /* 156 KB: one workgroup per CU */
 #define GTS_POOL_BYTES (GTS_POOL_PAGES * GTS_POOL_PAGE)
+#define GTS_POOL_BATCH 8u
 struct GtsPoolCtl {
   uint32_t lock;
   uint32_t front_busy;     /* a wavefront holds a front claim it has no pages for yet */
   uint32_t wait_pages;     /* pages that wavefront needs (0: it is not waiting) */
   uint32_t used[3];        /* page bitmap */
+  uint32_t f_next, f_end;  /* stock of front indices [f_next, f_end) */
+  uint32_t b_next, b_cnt;  /* stock of back indices b_next, b_next-1, ... (b_cnt of them) */
+  uint32_t f_done, b_done; /* the end has nothing more to give */
 };
-__device__ __forceinline__ bool pool_run_free(const volatile uint32_t *used, uint32_t pos, uint32_t n)
+/* the page bitmap as one integer (bit q = page q in use) */
+typedef unsigned __int128 gts_pool_bits;
+__device__ __forceinline__ gts_pool_bits pool_bits_load(const volatile uint32_t *used)
 {
-  for (uint32_t q = pos; q < pos + n; ++q)
-    if (used[q >> 5] >> (q & 31u) & 1u) return false;
-  return true;
+  return (gts_pool_bits)used[0] | (gts_pool_bits)used[1] << 32 | (gts_pool_bits)used[2] << 64;
 }
-/* first fit from below (front) or from above (back, not below `floor`); lane 0, lock held */
-__device__ __forceinline__ uint32_t pool_find(const volatile uint32_t *used, uint32_t n, bool from_below,
-                                              uint32_t floor)
+__device__ __forceinline__ void pool_bits_store(volatile uint32_t *used, gts_pool_bits b)
 {
-  if (n > GTS_POOL_PAGES - floor) return GTS_NONE;
+  used[0] = (uint32_t)b; used[1] = (uint32_t)(b >> 32); used[2] = (uint32_t)(b >> 64);
+}
+__device__ __forceinline__ gts_pool_bits pool_run_mask(uint32_t pos, uint32_t n)
+{
+  return (((gts_pool_bits)1 << n) - 1) << pos;    /* n <= 78 */
+}
+/* first fit from below (front) or from above (back, not below `floor`); the
+   search runs on registers: lane 0, lock held */
+__device__ __forceinline__ uint32_t pool_find(gts_pool_bits used, uint32_t n, bool from_below, uint32_t floor,
+                                              uint32_t pages)
+{
+  if (floor > pages || n > pages - floor) return GTS_NONE;
   if (from_below) {
-    for (uint32_t pos = floor; pos + n <= GTS_POOL_PAGES; ++pos)
-      if (pool_run_free(used, pos, n)) return pos;
+    for (uint32_t pos = floor; pos + n <= pages; ++pos)
+      if (!(used & pool_run_mask(pos, n))) return pos;
   } else {
-    for (uint32_t pos = GTS_POOL_PAGES - n + 1; pos-- > floor;)
-      if (pool_run_free(used, pos, n)) return pos;
+    for (uint32_t pos = pages - n + 1; pos-- > floor;)
+      if (!(used & pool_run_mask(pos, n))) return pos;
   }
   return GTS_NONE;
 }
-__device__ __forceinline__ void pool_lock(GtsPoolCtl *ctl)
+/* Every wait of the pool is bounded: after GTS_POOL_SPINS rounds (seconds) the
+   wavefront gives up, counts the place in pstat[6 + where] and carries on as
+   if it had been served -- the launch ends, the host reports GTSG_EINTERNAL. */
+#define GTS_POOL_SPINS (1u << 22)
+__device__ __forceinline__ void pool_lock(GtsPoolCtl *ctl, unsigned long long *pstat)
 {
-  while (atomicCAS(&ctl->lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);
+  uint32_t spins = 0;
+  while (atomicCAS(&ctl->lock, 0u, 1u) != 0u) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins == GTS_POOL_SPINS) { atomicAdd(pstat + 6, 1ull); break; }
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void pool_unlock(GtsPoolCtl *ctl)
@@ -1210,14 +1183,20 @@ __device__ __forceinline__ void pool_unlock(GtsPoolCtl *ctl)
 }
 __global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
 k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
-                  unsigned long long *cursor)
+                  unsigned long long *cursor, unsigned long long *pstat, uint32_t nbig)
 {
+  /* pstat (100 MHz ticks, summed over the wavefronts): [0] staging + program,
+     [1] waiting for pages, [2] whole life of the wavefront; [3] first exit,
+     [4] last exit (since the first wavefront's start, [5]) */
+  const uint64_t t_begin = GtsWave64::clock();
+  uint64_t t_run = 0, t_wait = 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ GtsPoolCtl ctl_s;
   GtsPoolCtl *ctl = &ctl_s;
   if (threadIdx.x == 0) {
     ctl->lock = 0; ctl->front_busy = 0; ctl->wait_pages = 0;
     ctl->used[0] = ctl->used[1] = ctl->used[2] = 0;
+    ctl->f_next = ctl->f_end = ctl->b_next = ctl->b_cnt = ctl->f_done = ctl->b_done = 0;
   }
   __syncthreads();
   const uint32_t lane = threadIdx.x & (GTS_WAVE - 1u);
@@ -1225,56 +1204,100 @@ k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
     /* role, claim, pages: lane 0; the rest of the wavefront waits at the broadcast */
     uint32_t idx = GTS_NONE, pos = 0, npages = 0;
     if (lane == 0) {
-      pool_lock(ctl);
-      const bool front = ((volatile GtsPoolCtl *)ctl)->front_busy == 0;
-      if (front) ((volatile GtsPoolCtl *)ctl)->front_busy = 1;
-      pool_unlock(ctl);
-      const unsigned long long old = atomicAdd(cursor, front ? 1ull : 1ull << 32);
-      const uint64_t h = old & 0xFFFFFFFFull, t = old >> 32;
-      if (h + t < (uint64_t)count) idx = front ? (uint32_t)h : count - 1u - (uint32_t)t;
+      bool front;
+      for (uint32_t spins = 0;;) {
+        bool more;
+        pool_lock(ctl, pstat);
+        volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
+        front = v->front_busy == 0;
+        if (front) {
+          if (v->f_next == v->f_end && !v->f_done) {
+            const uint32_t want = v->f_end < nbig ? 1u : GTS_POOL_BATCH;
+            const unsigned long long old = atomicAdd(cursor, (unsigned long long)want);
+            const uint64_t h = old & 0xFFFFFFFFull, t = old >> 32;
+            const uint64_t lim = (uint64_t)count > t ? (uint64_t)count - t : 0;   /* the back holds [lim, count) */
+            if (h < lim) { v->f_next = (uint32_t)h; v->f_end = (uint32_t)(h + want < lim ? h + want : lim); }
+            else v->f_done = 1;
+          }
+          if (v->f_next < v->f_end) { idx = v->f_next; v->f_next = idx + 1; v->front_busy = 1; }
+          else front = false;
+        }
+        if (!front) {
+          if (v->b_cnt == 0 && !v->b_done) {
+            const unsigned long long old = atomicAdd(cursor, (unsigned long long)GTS_POOL_BATCH << 32);
+            const uint64_t h = old & 0xFFFFFFFFull, t = old >> 32;
+            const uint64_t avail = h + t < (uint64_t)count ? (uint64_t)count - h - t : 0;
+            if (avail) { v->b_next = count - 1u - (uint32_t)t; v->b_cnt = (uint32_t)(avail < GTS_POOL_BATCH ? avail : GTS_POOL_BATCH); }
+            else v->b_done = 1;
+          }
+          if (v->b_cnt) { idx = v->b_next; v->b_next = idx - 1u; v->b_cnt = v->b_cnt - 1u; }
+        }
+        /* nothing for this wavefront now, but the front (held by the one that
+           waits for pages) has: look again later */
+        more = idx == GTS_NONE && !(v->f_done && v->f_next == v->f_end);
+        pool_unlock(ctl);
+        if (!more) break;
+        if (++spins == GTS_POOL_SPINS) { atomicAdd(pstat + 7, 1ull); break; }
+        __builtin_amdgcn_s_sleep(16);
+      }
       if (idx != GTS_NONE) {
         const uint32_t c = order[first + idx];
         const uint32_t s0 = C.comp_off[c], s1 = C.comp_off[c + 1];
         npages = (gts_comp_lds_bytes(s1 - s0, C.coff[s1] - C.coff[s0]) + GTS_POOL_PAGE - 1u) / GTS_POOL_PAGE;
         bool waiting = false;
-        for (;;) {
-          pool_lock(ctl);
+        const uint64_t tw0 = GtsWave64::clock();
+        for (uint32_t spins = 0;;) {
+          pool_lock(ctl, pstat);
           volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
           const uint32_t floor = front ? 0u : v->wait_pages;
-          pos = pool_find(v->used, npages, front, floor);
+          const gts_pool_bits bits = pool_bits_load(v->used);
+          pos = pool_find(bits, npages, front, floor, GTS_POOL_PAGES);
           if (pos != GTS_NONE) {
-            for (uint32_t q = pos; q < pos + npages; ++q) v->used[q >> 5] |= 1u << (q & 31u);
+            pool_bits_store(v->used, bits | pool_run_mask(pos, npages));
             if (front) { v->front_busy = 0; v->wait_pages = 0; }
           } else if (front && !waiting) {
             v->wait_pages = npages; waiting = true;
+          }
+          if (pos == GTS_NONE && ++spins == GTS_POOL_SPINS) {
+            /* give up: the component is not run (its state stays as it is), the host sees the count */
+            atomicAdd(pstat + 8, 1ull);
+            if (front) { v->front_busy = 0; v->wait_pages = 0; }
+            pool_unlock(ctl);
+            idx = GTS_NONE;
+            break;
           }
           pool_unlock(ctl);
           if (pos != GTS_NONE) break;
           __builtin_amdgcn_s_sleep(8);
         }
-      } else if (front) {
-        pool_lock(ctl);
-        ((volatile GtsPoolCtl *)ctl)->front_busy = 0;
-        pool_unlock(ctl);
+        t_wait += GtsWave64::clock() - tw0;
       }
     }
     idx = GtsWave64::uni(idx);
     if (idx == GTS_NONE) break;
     pos = GtsWave64::uni(pos); npages = GtsWave64::uni(npages);
     {
+      const uint64_t tr0 = GtsWave64::clock();
       const uint32_t c = order[first + idx];
       GtsCompMemT<true> M;
       stage_component(C, c, smem + pos * GTS_POOL_PAGE, M, false);
       GtsComponent<GtsWave64, true> prog(C, M, c);
       prog.run(mode);
+      t_run += GtsWave64::clock() - tr0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane == 0) {
-      pool_lock(ctl);
+      pool_lock(ctl, pstat);
       volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
-      for (uint32_t q = pos; q < pos + npages; ++q) v->used[q >> 5] &= ~(1u << (q & 31u));
+      pool_bits_store(v->used, pool_bits_load(v->used) & ~pool_run_mask(pos, npages));
       pool_unlock(ctl);
     }
+  }
+  if (lane == 0) {
+    const uint64_t t_end = GtsWave64::clock();
+    atomicAdd(pstat + 0, t_run); atomicAdd(pstat + 1, t_wait); atomicAdd(pstat + 2, t_end - t_begin);
+    atomicMin(pstat + 5, t_begin);
+    atomicMin(pstat + 3, t_end); atomicMax(pstat + 4, t_end);
   }
 }
 
@@ -1361,7 +1384,7 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 const uint8_t *comp_wide, const unsigned long long *comp_len,
                                 uint8_t *comp_klass, const uint32_t *klass, uint32_t nklass,
                                 uint32_t *klass_count, unsigned long long *klass_bytes,
-                                uint32_t *klass_slots, uint32_t pair_min_bytes)
+                                uint32_t *klass_slots)
 {
   /* counters are summed per workgroup in LDS first: seven global counters hit by
      every component serialise */
@@ -1374,13 +1397,6 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
     const uint32_t s0 = comp_off[c], s1 = comp_off[c + 1];
     const uint32_t cnv = s1 - s0, cne = coff[s1] - coff[s0];
     uint32_t need = gts_comp_lds_bytes(cnv, cne);
-    /* the classes above pair_min_bytes run two wavefronts per component: the
-       second one's walk scratch counts (unless that pushes the component out of
-       LDS altogether -- it then runs on one wavefront in the largest class) */
-    if (need > pair_min_bytes) {
-      const uint32_t need2 = gts_comp_lds_bytes_pair(cnv, cne);
-      if (need2 <= klass[nklass ? nklass - 1 : 0]) need = need2;
-    }
     /* not representable in the packed LDS layout: run from global memory */
     if (comp_wide[c] || cnv >= 4096u || cne > GTS_LDS_MAX_INDEX || comp_len[c] >= (1ull << 32))
       need = 0x7FFFFFFFu;
@@ -1561,7 +1577,7 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
     if (hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
   if (!rc && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
   const void *big_lds[] = {(const void *)k_walk_tasks_mixed, (const void *)k_walk_tasks,
-                           (const void *)k_components_lds, (const void *)k_components_lds_pair,
+                           (const void *)k_components_lds,
                            (const void *)k_components_pool};
   {
     int cus = 0;
@@ -1621,8 +1637,8 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
   else if (!strcmp(name, "defer_min_work") && value >= 0) e->defer_min_work = value;
-  else if (!strcmp(name, "pair_walks_min_bytes") && value >= 0) e->pair_walks_min_bytes = value;
   else if (!strcmp(name, "pool_components")) e->pool_components = value != 0;
+  else if (!strcmp(name, "pool_waves") && value >= 1 && value <= GTS_POOL_WAVES) e->pool_waves = value;
   else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NSTREAMS) e->class_streams = value;
   else if (!strcmp(name, "mixed_task_limit") && value >= 0) e->mixed_task_limit = value;
 
@@ -2272,18 +2288,9 @@ static int run_components(GtsgEngine *e, int mode)
     uint32_t *klass_d = e->d_scalars + GTS_S_KSIZE, *klass_count = e->d_scalars + GTS_S_KCOUNT;
     HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_KSIZE, 0, (GTS_S_NDEF + 4 - GTS_S_KSIZE) * 4, e->st));
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, nklass * sizeof(uint32_t), hipMemcpyHostToDevice, e->st));
-    /* two wavefronts per component in the classes of at least
-       pair_walks_min_bytes: pair_min = the size of the class below them (a
-       component is assigned by the footprint of the kernel that runs its class) */
-    uint32_t pair_min = 0xFFFFFFFFu;
-    if (mode == GTS_MODE_MAKESCAFFOLD && e->lds_components && e->pair_walks_min_bytes > 0) {
-      for (uint32_t k = 0; k < nklass; ++k)
-        if ((int64_t)klass_h[k] >= e->pair_walks_min_bytes) { pair_min = k ? klass_h[k - 1] : 0u; break; }
-    }
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
            ncomp, comp_wide, comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? nklass : 0), klass_count,
-           (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS,
-           pair_min);
+           (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS);
     LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + GTS_S_KSLOTS, e->d_scalars + GTS_S_TQBASE);
     const uint32_t *order;
     {
@@ -2304,6 +2311,7 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemsetAsync(e->d_scalars + 12, 0, 16, e->st));
     LAUNCH("comp_max_size", k_max_u32_diff, nblk(ncomp), GTS_BLOCK, comp_off, ncomp,
            e->d_scalars + 14);
+    bool pool_ran = false;
     GtsCompView C;
     C.G = G; C.cmap = cmap; C.ncomp = ncomp; C.comp_off = comp_off; C.slot_v = slot_v;
     C.cseq = cseq; C.coff = coff; C.cstart = cstart; C.cend = cend; C.cdist = cdist;
@@ -2354,29 +2362,31 @@ static int run_components(GtsgEngine *e, int mode)
                (int)e->defer_global_components);
         first += kcount[nk];
       }
-      /* the size classes are independent: fork them onto side streams so the
-         launches overlap (each has its own tail and, being bound by its LDS
-         footprint, leaves room for workgroups of the other classes); join
-         before the statistics.  The runtime multiplexes a process' streams
-         onto GPU_MAX_HW_QUEUES hardware queues (default 4, the main stream
-         included): that many launches are in flight at a time. */
       uint32_t pooled = 0;
       if (e->pool_components)
         for (uint32_t k = 0; k < nk; ++k) {
           pooled += kcount[k];
           e->stats["components_lds_class" + std::to_string(k)] = kcount[k];
         }
+      pool_ran = pooled != 0;
       if (pooled) {
         /* one launch for all of them: a workgroup per CU, its wavefronts claim
            components until none is left (k_components_pool) */
         hipStream_t ss = e->side[0];
+        uint32_t nbig = 0;   /* components above 8 KB: claimed one at a time */
+        for (uint32_t k = 0; k < nk; ++k) if (klass_h[k] > 8192u) nbig += kcount[k];
         unsigned long long *cursor = (unsigned long long *)(e->d_scalars + GTS_S_POOLCUR);
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         HIPCHK(hipMemsetAsync(cursor, 0, 8, ss));
+        unsigned long long *pstat = (unsigned long long *)(e->d_scalars + GTS_S_POOLSTAT);
+        HIPCHK(hipMemsetAsync(pstat, 0, 72, ss));
+        HIPCHK(hipMemsetAsync(pstat + 3, 0xFF, 8, ss));
+        HIPCHK(hipMemsetAsync(pstat + 5, 0xFF, 8, ss));
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
-        k_components_pool<<<e->n_cus, GTS_POOL_WAVES * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, order, first, pooled,
-                                                                                     mode, cursor);
+        const uint32_t pw = (uint32_t)e->pool_waves;
+        k_components_pool<<<e->n_cus, pw * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, order, first, pooled, mode, cursor,
+                                                                          pstat, nbig);
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_pool"
                                                                               : "components_removecycles_pool",
@@ -2385,17 +2395,21 @@ static int run_components(GtsgEngine *e, int mode)
         HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[0], 0));
         first += pooled;
       }
+      /* pool_components = 0: a launch per size class.  The classes are
+         independent: fork them onto side streams so the launches overlap (each
+         has its own tail and, being bound by its LDS footprint, leaves room for
+         workgroups of the other classes); join before the statistics.  The
+         runtime multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware
+         queues (default 4, the main stream included): that many launches are
+         in flight at a time -- the small classes, most of the wave time, start
+         when the large ones are done (17.4 ms against the pool's 14). */
       for (int k = (int)nk - 1; k >= 0 && !pooled; --k) {
         if (!kcount[k]) continue;
         hipStream_t ss = e->side[((int)nk - 1 - k) % (int)e->class_streams];
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
-        if (klass_h[k] > pair_min)
-          k_components_lds_pair<<<kcount[k], 2 * GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode,
-                                                                           klass_h[k]);
-        else
-          k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode);
+        k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode);
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({klass_event(mode == GTS_MODE_MAKESCAFFOLD, klass_h[k]), _a, _b}); }
         HIPCHK(hipEventRecord(e->ev_join[k], ss));
@@ -2519,11 +2533,28 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(ts, e->d_scalars + 32, 64, hipMemcpyDeviceToHost, e->st));
     uint64_t why[8];
     HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 64, hipMemcpyDeviceToHost, e->st));
+    uint64_t pst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 72, hipMemcpyDeviceToHost, e->st));
     uint32_t res[3] = {0, 0, 0};
     uint64_t wstat[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 12, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 32, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
+    if (pst[6] | pst[7] | pst[8]) {
+      e->stats["pool_gave_up_lock"] = (int64_t)pst[6];
+      e->stats["pool_gave_up_claim"] = (int64_t)pst[7];
+      e->stats["pool_gave_up_pages"] = (int64_t)pst[8];
+      fprintf(stderr, "gts: k_components_pool gave up waiting (lock %llu, claim %llu, pages %llu)\n",
+              (unsigned long long)pst[6], (unsigned long long)pst[7], (unsigned long long)pst[8]);
+      return fail(e, GTSG_EINTERNAL, "component pool: a wavefront gave up waiting");
+    }
+    if (pool_ran) {   /* 100 MHz ticks -> microseconds */
+      e->stats["pool_us_sum_run"] = (int64_t)(pst[0] / 100);
+      e->stats["pool_us_sum_wait_pages"] = (int64_t)(pst[1] / 100);
+      e->stats["pool_us_sum_wave_life"] = (int64_t)(pst[2] / 100);
+      e->stats["pool_us_first_exit"] = (int64_t)((pst[3] - pst[5]) / 100);
+      e->stats["pool_us_last_exit"] = (int64_t)((pst[4] - pst[5]) / 100);
+    }
     {
       static const char *nm[4] = {"removecycles", "makescaffold_other", "walks_fast", "walks_reference"};
       for (int k = 0; k < 4; ++k) {   /* 100 MHz ticks -> microseconds */

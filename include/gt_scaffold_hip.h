@@ -45,7 +45,8 @@ enum {
   GTSG_EHIP = -2,      /* HIP runtime error */
   GTSG_ENOMEM = -3,
   GTSG_EWALK = -4,     /* a walk exceeded its pop bound (cyclic distance maps) */
-  GTSG_ELIMIT = -5     /* 2^31 contigs, 2^29 records or 2^30 edges, or more */
+  GTSG_ELIMIT = -5,    /* 2^31 contigs, 2^29 records or 2^30 edges, or more */
+  GTSG_EINTERNAL = -6  /* a device-side wait ran into its bound (a bug: please report) */
 };
 
 /* Engine bound to HIP device `device`.  `stream` is a hipStream_t (NULL: the
@@ -182,8 +183,11 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      from global memory), "defer_min_contigs" (default 256; components with at
      least that many contigs hand their walks to one workgroup per terminal,
      0 = never) and "defer_min_work" (default 2^17: ... and with at least that
-     many terminals x contigs), "class_streams" (default 6: side streams the LDS size classes
-     are launched on), "mixed_task_limit" (default 256: a round with at most
+     many terminals x contigs), "pool_components" (default 1: the LDS-resident
+     components run in ONE launch of a workgroup per CU whose "pool_waves"
+     (default and maximum 16) wavefronts claim components and share the CU's
+     LDS in 2 KB pages; 0: one launch per LDS size class on "class_streams"
+     (default 6) side streams), "mixed_task_limit" (default 256: a round with at most
      that many pending walks is one launch for all classes), "walk_path_entries" (default 2^24, pool for the tasks' walks;
      grows by itself like the walk queues), "defer_global_components" (default 0; 1: components
      that run from global memory hand their walks out, too),

@@ -190,21 +190,22 @@ def test_deferred_walk_tasks(seed):
     assert eng1.digest() == eng0.digest()
 
 
-@pytest.mark.parametrize("min_bytes", [1, 16384])
-def test_two_wavefronts_per_component(min_bytes):
-    """the classes of at least `pair_walks_min_bytes` walk the terminals of a
-    cc on two wavefronts: same scaffolds, ties between the two included"""
-    cases = [dict(n=3000, seed=21, dist_range_small=True, contig_median=300),
-             dict(n=8000, seed=1201, p_chimeric=0.08, p_inversion=0.0, p_bubble=0.05, links_per_side=4,
-                  unique_pairs=True),
-             dict(n=8000, seed=1200, p_chimeric=0.03),
-             dict(n=4000, seed=11, p_repeat=0.02, repeat_degree=300, p_chimeric=0.05)]
-    for kw in cases:
+def test_component_pool_matches_the_class_launches():
+    """the LDS components in one launch of wavefront pools (default) or in a
+    launch per size class: same states; the pool's waits never ran into their
+    bound"""
+    for kw in (dict(n=30000, seed=8, p_chimeric=0.02),
+               dict(n=8000, seed=1201, p_chimeric=0.08, p_inversion=0.0, p_bubble=0.05, links_per_side=4,
+                    unique_pairs=True)):
         kw = dict(kw)
         g = make_inputs(kw.pop("n"), kw.pop("seed"), **kw)
-        eng, _ = run_pipeline(g, pair_walks_min_bytes=min_bytes, defer_min_contigs=0)
-        eng0, _ = run_pipeline(g, defer_min_contigs=0)
-        assert eng.digest() == eng0.digest()
+        eng, _ = run_pipeline(g)
+        assert eng.stat("pool_gave_up_lock") <= 0 and eng.stat("pool_gave_up_pages") <= 0
+        eng0, _ = run_pipeline(g, pool_components=0)
+        eng1, _ = run_pipeline(g, pool_waves=3)
+        assert eng.digest() == eng0.digest() == eng1.digest()
+        assert sum(eng.stat("components_lds_class%d" % k) for k in range(11)) == \
+            sum(eng0.stat("components_lds_class%d" % k) for k in range(11)) > 0
 
 
 def test_fast_walks_resolve_ties():

@@ -63,7 +63,7 @@ def test_engine_on_handmade_fixture(tmp_path, hm_dir, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("opts", [dict(fast_walks=0), dict(lds_components=0), dict(defer_min_contigs=2, defer_min_work=0),
-                                  dict(pair_walks_min_bytes=1)])
+                                  dict(pool_components=0)])
 def test_engine_variants_on_handmade_fixtures(tmp_path, hm_dir, opts):
     """the same final states from the reference-search walks, the global-memory
     component programs and the deferred walk tasks"""
