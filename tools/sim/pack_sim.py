@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Event-driven model of how the component programs pack onto the GPU.
 
-Input: gpurun_out/comps.npy -- per component (contigs, compact edges, ticks of
-removecycles+other, ticks of walks; 100 MHz), dumped from a profile-2 run.
+Input: the file GTS_DUMP_COMPONENTS names (six uint64 per component: contigs,
+compact edges, ticks of removecycles, other, linear walks, reference walks;
+100 MHz), written by the engine in a profile-2 step, e.g.
+    GTS_DUMP_COMPONENTS=/tmp/comps.bin python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    python tools/sim/pack_sim.py /tmp/comps.bin [extra]
 Each CU has 160 KB of LDS and S wave slots; a component needs its packed LDS
 footprint (rounded to pages) and one slot for its measured wave time.
 
@@ -116,8 +119,16 @@ def classes(need, t, slots, streams=6, queues=4):
     return now
 
 
-def main():
-    a = np.load(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/comps.npy").astype(np.int64)
+def load(path):
+    """-> (contigs, edges, ticks without walks, ticks of walks) per component"""
+    if path.endswith(".npy"):
+        return np.load(path).astype(np.int64)
+    a = np.fromfile(path, dtype=np.uint64).reshape(-1, 6).astype(np.int64)
+    return np.stack([a[:, 0], a[:, 1], a[:, 2] + a[:, 3], a[:, 4] + a[:, 5]], 1)
+
+
+def main(path):
+    a = load(path)
     nv, ne = a[:, 0], a[:, 1]
     t = (a[:, 2] + a[:, 3]) / 100.0
     need = np.array([lds_bytes(int(x), int(y)) for x, y in zip(nv, ne)], dtype=np.int64)
@@ -141,8 +152,8 @@ def main():
 
 
 
-def extra():
-    a = np.load("gpurun_out/comps.npy").astype(np.int64)
+def extra(path):
+    a = load(path)
     nv, ne = a[:, 0], a[:, 1]
     t = (a[:, 2] + a[:, 3]) / 100.0
     need = np.array([lds_bytes(int(x), int(y)) for x, y in zip(nv, ne)], dtype=np.int64)
@@ -164,7 +175,6 @@ def extra():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "extra":
-        extra()
-    else:
-        main()
+    if len(sys.argv) < 2:
+        sys.exit(__doc__)
+    (extra if sys.argv[2:3] == ["extra"] else main)(sys.argv[1])
