@@ -59,7 +59,7 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_S_NDEF 384     /* u64 */
 #define GTS_POOL_WAVES 16u /* wavefronts of a k_components_pool workgroup (one per CU) */
 #define GTS_S_POOLCUR 392  /* u64: claim counter of k_components_pool */
-#define GTS_S_POOLSTAT 400 /* 9 x u64: clocks and give-up counts of k_components_pool */
+#define GTS_S_POOLSTAT 400 /* 10 x u64: clocks, give-up and overrun counts of k_components_pool */
 
 static const char *klass_event(int makescaffold, uint32_t bytes)
 {
@@ -1187,7 +1187,9 @@ k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
 {
   /* pstat (100 MHz ticks, summed over the wavefronts): [0] staging + program,
      [1] waiting for pages, [2] whole life of the wavefront; [3] first exit,
-     [4] last exit (since the first wavefront's start, [5]) */
+     [4] last exit (since the first wavefront's start, [5]); [6..8] waits that
+     ran into their bound (lock, claim, pages); [9] programs that wrote past
+     their footprint */
   const uint64_t t_begin = GtsWave64::clock();
   uint64_t t_run = 0, t_wait = 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1202,7 +1204,7 @@ k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
   const uint32_t lane = threadIdx.x & (GTS_WAVE - 1u);
   for (;;) {
     /* role, claim, pages: lane 0; the rest of the wavefront waits at the broadcast */
-    uint32_t idx = GTS_NONE, pos = 0, npages = 0;
+    uint32_t idx = GTS_NONE, pos = 0, npages = 0, need = 0;
     if (lane == 0) {
       bool front;
       for (uint32_t spins = 0;;) {
@@ -1243,7 +1245,8 @@ k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
       if (idx != GTS_NONE) {
         const uint32_t c = order[first + idx];
         const uint32_t s0 = C.comp_off[c], s1 = C.comp_off[c + 1];
-        npages = (gts_comp_lds_bytes(s1 - s0, C.coff[s1] - C.coff[s0]) + GTS_POOL_PAGE - 1u) / GTS_POOL_PAGE;
+        need = gts_comp_lds_bytes(s1 - s0, C.coff[s1] - C.coff[s0]);
+        npages = (need + GTS_POOL_PAGE - 1u) / GTS_POOL_PAGE;
         bool waiting = false;
         const uint64_t tw0 = GtsWave64::clock();
         for (uint32_t spins = 0;;) {
@@ -1275,7 +1278,13 @@ k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
     }
     idx = GtsWave64::uni(idx);
     if (idx == GTS_NONE) break;
-    pos = GtsWave64::uni(pos); npages = GtsWave64::uni(npages);
+    pos = GtsWave64::uni(pos); npages = GtsWave64::uni(npages); need = GtsWave64::uni(need);
+    /* the components of a workgroup are neighbours in LDS: a word behind the
+       footprint (where the last page has room for one) shows a program that
+       wrote past its arrays */
+    volatile uint32_t *canary = need + 4u <= npages * GTS_POOL_PAGE
+                                    ? (volatile uint32_t *)(smem + pos * GTS_POOL_PAGE + need) : nullptr;
+    if (lane == 0 && canary) *canary = 0x5CAFF01Du;
     {
       const uint64_t tr0 = GtsWave64::clock();
       const uint32_t c = order[first + idx];
@@ -1287,6 +1296,7 @@ k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane == 0) {
+      if (canary && *canary != 0x5CAFF01Du) atomicAdd(pstat + 9, 1ull);
       pool_lock(ctl, pstat);
       volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
       pool_bits_store(v->used, pool_bits_load(v->used) & ~pool_run_mask(pos, npages));
@@ -2379,7 +2389,7 @@ static int run_components(GtsgEngine *e, int mode)
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         HIPCHK(hipMemsetAsync(cursor, 0, 8, ss));
         unsigned long long *pstat = (unsigned long long *)(e->d_scalars + GTS_S_POOLSTAT);
-        HIPCHK(hipMemsetAsync(pstat, 0, 72, ss));
+        HIPCHK(hipMemsetAsync(pstat, 0, 80, ss));
         HIPCHK(hipMemsetAsync(pstat + 3, 0xFF, 8, ss));
         HIPCHK(hipMemsetAsync(pstat + 5, 0xFF, 8, ss));
         hipEvent_t _a = nullptr, _b = nullptr;
@@ -2533,13 +2543,18 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(ts, e->d_scalars + 32, 64, hipMemcpyDeviceToHost, e->st));
     uint64_t why[8];
     HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 64, hipMemcpyDeviceToHost, e->st));
-    uint64_t pst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 72, hipMemcpyDeviceToHost, e->st));
+    uint64_t pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 80, hipMemcpyDeviceToHost, e->st));
     uint32_t res[3] = {0, 0, 0};
     uint64_t wstat[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 12, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 32, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
+    if (pst[9]) {
+      e->stats["pool_lds_overruns"] = (int64_t)pst[9];
+      return fail(e, GTSG_EINTERNAL, "component pool: %llu program(s) wrote past their LDS arrays",
+                  (unsigned long long)pst[9]);
+    }
     if (pst[6] | pst[7] | pst[8]) {
       e->stats["pool_gave_up_lock"] = (int64_t)pst[6];
       e->stats["pool_gave_up_claim"] = (int64_t)pst[7];
