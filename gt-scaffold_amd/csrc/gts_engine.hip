@@ -128,6 +128,7 @@ struct GtsgEngine {
   int64_t defer_min_work = 1ll << 17;
   int64_t pool_components = 1;        /* all LDS components in one launch (k_components_pool) */
   int64_t pool_waves = GTS_POOL_WAVES; /* wavefronts per workgroup of that launch */
+  int64_t lds_poison = -1;             /* test aid: fill a component's pages with this byte before staging */
   int n_cus = 256;
   int64_t fast_walks = 1, lds_components = 1;
   /* walks of global-memory components fan out only on request: the components
@@ -1183,7 +1184,7 @@ __device__ __forceinline__ void pool_unlock(GtsPoolCtl *ctl)
 }
 __global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
 k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
-                  unsigned long long *cursor, unsigned long long *pstat, uint32_t nbig)
+                  unsigned long long *cursor, unsigned long long *pstat, uint32_t nbig, int poison)
 {
   /* pstat (100 MHz ticks, summed over the wavefronts): [0] staging + program,
      [1] waiting for pages, [2] whole life of the wavefront; [3] first exit,
@@ -1284,6 +1285,14 @@ k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
        wrote past its arrays */
     volatile uint32_t *canary = need + 4u <= npages * GTS_POOL_PAGE
                                     ? (volatile uint32_t *)(smem + pos * GTS_POOL_PAGE + need) : nullptr;
+    if (poison >= 0) {
+      /* test aid: the pages hold this byte instead of what the last component
+         left there -- a program that reads scratch it has not written shows */
+      uint32_t *pw = (uint32_t *)(smem + pos * GTS_POOL_PAGE);
+      const uint32_t word = (uint32_t)(poison & 0xFF) * 0x01010101u;
+      for (uint32_t i = lane; i < npages * (GTS_POOL_PAGE / 4u); i += GTS_WAVE) pw[i] = word;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     if (lane == 0 && canary) *canary = 0x5CAFF01Du;
     {
       const uint64_t tr0 = GtsWave64::clock();
@@ -1649,6 +1658,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "defer_min_work") && value >= 0) e->defer_min_work = value;
   else if (!strcmp(name, "pool_components")) e->pool_components = value != 0;
   else if (!strcmp(name, "pool_waves") && value >= 1 && value <= GTS_POOL_WAVES) e->pool_waves = value;
+  else if (!strcmp(name, "lds_poison") && value >= -1 && value <= 255) e->lds_poison = value;
   else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NSTREAMS) e->class_streams = value;
   else if (!strcmp(name, "mixed_task_limit") && value >= 0) e->mixed_task_limit = value;
 
@@ -2396,7 +2406,7 @@ static int run_components(GtsgEngine *e, int mode)
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
         const uint32_t pw = (uint32_t)e->pool_waves;
         k_components_pool<<<e->n_cus, pw * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, order, first, pooled, mode, cursor,
-                                                                          pstat, nbig);
+                                                                          pstat, nbig, (int)e->lds_poison);
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_pool"
                                                                               : "components_removecycles_pool",

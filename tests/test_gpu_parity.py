@@ -208,6 +208,26 @@ def test_component_pool_matches_the_class_launches():
             sum(eng0.stat("components_lds_class%d" % k) for k in range(11)) > 0
 
 
+@pytest.mark.parametrize("poison", [0x00, 0xFF, 0xA5])
+def test_programs_do_not_depend_on_stale_lds(poison):
+    """a wavefront of the pool runs one component after the other in recycled
+    LDS pages; with the pages overwritten by a byte pattern before staging the
+    states are still the oracle's, whatever the pattern (linear walks, cyclic
+    state graphs, reference searches, cycle removal, hubs)"""
+    cases = [dict(n=3000, seed=21, dist_range_small=True, contig_median=300),
+             dict(n=5000, seed=60, p_chimeric=0.05),
+             dict(n=2000, seed=7, p_chimeric=0.1, p_bubble=0.1),
+             dict(n=4000, seed=11, p_repeat=0.02, repeat_degree=300, p_chimeric=0.05),
+             dict(n=6000, seed=900, p_chimeric=0.15, p_inversion=0.0, p_bubble=0.05, links_per_side=4,
+                  p_relist=0.05)]
+    for kw in cases:
+        kw = dict(kw)
+        g = make_inputs(kw.pop("n"), kw.pop("seed"), **kw)
+        run_pipeline(g, lds_poison=poison)
+    g = make_inputs(5000, 61, p_chimeric=0.05)
+    run_pipeline(g, lds_poison=poison, fast_walks=0)
+
+
 def test_fast_walks_resolve_ties():
     g = make_inputs(3000, 21, dist_range_small=True, contig_median=300)
     eng, _ = run_pipeline(g)
@@ -424,15 +444,20 @@ def test_ragged_inputs():
 def test_full_size_properties():
     """BASELINE configs[1] (10 M contigs / 100 M edges, the workload bench.py
     times) through properties that need no oracle: structural invariants of the
-    built graph, the same digest whatever the parallel decomposition (deferred
-    walks or not, one or six streams), and the oracle's digest on a sample drawn by the same generator."""
+    built graph, the same digest whatever the parallel decomposition (wavefront
+    pool or a launch per LDS class, deferred walks or not), and the oracle's
+    digest on a sample drawn by the same generator."""
     import torch
     import bench
     n = 10_000_000
     g = bench.make_inputs(pkg, n, 1234, "cuda:0", bench.WORKLOAD["gen"])
     g["num_pairs"] = g["num_pairs"].to(torch.int64)
     digests = []
-    for opts in (dict(), dict(defer_min_contigs=0, class_streams=1), dict(defer_min_contigs=96, defer_min_work=0, mixed_task_limit=0)):
+    # pool launch; launch per LDS class on one stream; walks fanned out; the pool
+    # with 5 wavefronts per CU and its pages overwritten before every component
+    for opts in (dict(), dict(defer_min_contigs=0, pool_components=0, class_streams=1),
+                 dict(defer_min_contigs=96, defer_min_work=0, mixed_task_limit=0),
+                 dict(pool_waves=5, lds_poison=0xA5)):
         eng = pkg.engine.Engine(0)
         for k, v in opts.items():
             eng.set_option(k, v)
@@ -464,7 +489,7 @@ def test_full_size_properties():
             assert np.array_equal(es[0:m:2] == 6, es[1:m:2] == 6)   # twins are marked together
             del vs, es, ee
         del eng
-    assert digests[0] == digests[1] == digests[2]
+    assert digests[0] == digests[1] == digests[2] == digests[3]
     # the slow path at full size: 10 % of the false links are inversions and
     # repeated pairs are kept, so components holding them leave the linear walks
     # for the reference's label-correcting search (create_walk_reference) -- in
@@ -476,7 +501,7 @@ def test_full_size_properties():
     g = bench.make_inputs(pkg, n, 1234, "cuda:0", gen)
     g["num_pairs"] = g["num_pairs"].to(torch.int64)
     slow = []
-    for opts in (dict(), dict(defer_min_contigs=0, class_streams=1)):
+    for opts in (dict(), dict(defer_min_contigs=0, pool_components=0, class_streams=1)):
         eng = pkg.engine.Engine(0)
         for k, v in opts.items():
             eng.set_option(k, v)
@@ -580,8 +605,10 @@ def test_50M_contig_repeat_rich_graph():
     assert np.array_equal(es[0:m:2] == 6, es[1:m:2] == 6)
     assert (es == 1).any() and (es == 2).any() and (es == 3).any()
     del e, vs, es, sc
-    # another decomposition of the same work: walks in place, one stream
+    # another decomposition of the same work: walks in place, a launch per LDS
+    # class on one stream instead of the wavefront pool
     eng.set_option("defer_min_contigs", 0)
+    eng.set_option("pool_components", 0)
     eng.set_option("class_streams", 1)
     bench.run_step(eng, g)
     assert eng.digest() == d0
