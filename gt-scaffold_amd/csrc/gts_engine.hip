@@ -1183,7 +1183,8 @@ __device__ __forceinline__ void pool_unlock(GtsPoolCtl *ctl)
   atomicExch(&ctl->lock, 0u);
 }
 __global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
-k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
+k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_key, uint32_t first,
+                  uint32_t count, int mode,
                   unsigned long long *cursor, unsigned long long *pstat, uint32_t nbig, int poison)
 {
   /* pstat (100 MHz ticks, summed over the wavefronts): [0] staging + program,
@@ -1244,9 +1245,7 @@ k_components_pool(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
         __builtin_amdgcn_s_sleep(16);
       }
       if (idx != GTS_NONE) {
-        const uint32_t c = order[first + idx];
-        const uint32_t s0 = C.comp_off[c], s1 = C.comp_off[c + 1];
-        need = gts_comp_lds_bytes(s1 - s0, C.coff[s1] - C.coff[s0]);
+        need = ~order_key[first + idx];   /* the sort key: one load instead of three dependent ones */
         npages = (need + GTS_POOL_PAGE - 1u) / GTS_POOL_PAGE;
         bool waiting = false;
         const uint64_t tw0 = GtsWave64::clock();
@@ -2312,11 +2311,12 @@ static int run_components(GtsgEngine *e, int mode)
            ncomp, comp_wide, comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? nklass : 0), klass_count,
            (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS);
     LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + GTS_S_KSLOTS, e->d_scalars + GTS_S_TQBASE);
-    const uint32_t *order;
+    const uint32_t *order, *order_key;   /* order_key[i] = ~footprint of component order[i] */
     {
       int shifts[4] = {0, 8, 16, 24};
       const int where = gts_radix_sort<uint32_t>(ok0, ov0, ok1, ov1, ncomp, shifts, 4, otmp, e->st);
       order = where ? ov1 : ov0;
+      order_key = where ? ok1 : ok0;
     }
     uint32_t kcount[GTS_NKLASS + 1];
     uint64_t kbytes[GTS_NKLASS + 1];
@@ -2405,8 +2405,8 @@ static int run_components(GtsgEngine *e, int mode)
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
         const uint32_t pw = (uint32_t)e->pool_waves;
-        k_components_pool<<<e->n_cus, pw * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, order, first, pooled, mode, cursor,
-                                                                          pstat, nbig, (int)e->lds_poison);
+        k_components_pool<<<e->n_cus, pw * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, order, order_key, first, pooled, mode,
+                                                                          cursor, pstat, nbig, (int)e->lds_poison);
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_pool"
                                                                               : "components_removecycles_pool",
