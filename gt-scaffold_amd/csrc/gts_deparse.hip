@@ -1,0 +1,680 @@
+/*
+  gts_deparse.hip -- DistEst (.de) text -> records on the GPU (gfx950).
+
+  Replaces the two passes of gt_scaffolder_parser.c over the distance file for
+  files in the regular form ABySS' DistanceEst writes:
+
+      <root> <ctg>{+,-},<dist>,<pairs>,<std> ... ; <ctg>{+,-},... \n
+
+    pass 0  gt_scaffolder_parser_count_distances  (ref parser.c:150-291):
+            integrity check, first error in file order, number of records
+            between known contigs;
+    pass 1  gt_scaffolder_parser_read_distances   (ref parser.c:295-394):
+            the records in file order, sense flipped at ';'.
+
+  The reference tokenises with strtok(" "), scans a record with
+  sscanf("%[^>,],%ld,%ld,%f") and finds contigs with bsearch over the sorted
+  headers.  Here: the text is cut into strides of 16 KB, a workgroup takes the
+  lines that START in its stride (a line is at most 1023 bytes, so a stride
+  plus one line fits LDS), stages them with coalesced loads, finds the line
+  starts with a ballot-free scan in LDS and parses one line per thread from
+  LDS.  Contig names are looked up in an open-addressing hash table built from
+  the sorted header list (entry = upper half of a 64-bit FNV-1a + id, the name
+  itself is compared on a hit).  Records go to candidate slots numbered by a
+  scan over the strides (every record token of the file has one), a compaction
+  follows only if a token did not become a record.
+
+  Exactness: the parser accepts exactly the inputs for which it provably
+  computes what sscanf / strtol / strtof compute (plain decimal integers of at
+  most 18 digits; decimal fractions of at most 19 significant digits, computed
+  in double and refused if the double is within its error of a float midpoint,
+  so rounding it to float cannot differ from strtof's single rounding of the
+  decimal).  Anything else -- control characters, exponents, hex floats,
+  inf/nan, '>' in a header, a blank before the line end, a last line without
+  newline, lines above 1023 bytes -- sets `irregular`, and the caller parses
+  the file with the host code instead (gt_scaffolder_host.c, which restates
+  the reference line by line).  irregular never changes a result, only who
+  computes it.
+*/
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gt_scaffold_hip.h"
+#include "gts_prims.hpp"
+
+#define DP_STRIDE 16384u
+#define DP_MAXLINE 1023u            /* fgets(line, 1024): longest line with its newline */
+#define DP_THREADS 256u
+#define DP_MAXLINES 4096u           /* lines starting in one stride (more: irregular) */
+#define DP_BUF (DP_STRIDE + 1024u + 32u)
+
+#define DP_ERR_RECORD 1u            /* "Invalid record in dist file"                 parser.c:205,236 */
+#define DP_ERR_PAIRS 2u             /* "Invalid value for number of pairs ..."       parser.c:218 */
+#define DP_ERR_SIGN 3u              /* "Invalid composition sign ..."                parser.c:226 */
+
+struct GtsgDeParser {
+  int device;
+  hipStream_t st;
+  bool own_stream;
+  /* contig names: blob + n+1 offsets, hash table */
+  char *names;
+  uint32_t *name_off;
+  uint64_t *table;
+  uint64_t table_mask;
+  uint64_t n_names;
+  /* text staged on the device when the caller hands a host buffer */
+  char *text;
+  uint64_t text_cap;
+  /* candidates / records of the last parse */
+  uint32_t *root, *ctg;
+  int64_t *dist, *np;
+  float *sd;
+  uint8_t *flags, *valid;
+  uint32_t *cand_cnt;               /* per stride, then its exclusive scan */
+  uint32_t *scan_tmp;
+  uint32_t *pos;                    /* compaction */
+  uint64_t cap_cand, cap_blocks;
+  /* compacted copies (only when a candidate is not a record) */
+  uint32_t *root2, *ctg2;
+  int64_t *dist2, *np2;
+  float *sd2;
+  uint8_t *flags2;
+  uint64_t cap2;
+  bool compacted;
+  uint64_t n_records;
+  unsigned long long *d_res;        /* [0] first error, [1] irregular, [2] valid, [3] candidates */
+  char err[256];
+};
+
+static int dp_fail(GtsgDeParser *p, int code, const char *msg)
+{
+  snprintf(p->err, sizeof p->err, "%s", msg);
+  return code;
+}
+#define DPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
+  snprintf(p->err, sizeof p->err, "%s: %s", #x, hipGetErrorString(_e)); \
+  return _e == hipErrorOutOfMemory ? GTSG_ENOMEM : GTSG_EHIP; } } while (0)
+
+/* ---- names ---------------------------------------------------------------- */
+__device__ __forceinline__ uint64_t dp_hash_step(uint64_t h, uint8_t c)
+{
+  return (h ^ c) * 1099511628211ull;    /* FNV-1a */
+}
+#define DP_HASH_INIT 14695981039346656037ull
+
+__global__ void k_dp_insert(const char *names, const uint32_t *off, uint64_t n, uint64_t *table,
+                            uint64_t mask)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t h = DP_HASH_INIT;
+  for (uint32_t k = off[i]; k < off[i + 1]; ++k) h = dp_hash_step(h, (uint8_t)names[k]);
+  const unsigned long long entry = (h & 0xFFFFFFFF00000000ull) | (unsigned long long)(i + 1);
+  uint64_t slot = h & mask;
+  while (atomicCAS((unsigned long long *)&table[slot], 0ull, entry) != 0ull) slot = (slot + 1) & mask;
+}
+
+/* id of the name buf[a, b) (LDS), or GTS_NONE */
+#define DP_NONE 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t dp_lookup(const uint8_t *buf, uint32_t a, uint32_t b, const char *names,
+                                              const uint32_t *off, const uint64_t *table, uint64_t mask)
+{
+  if (a >= b) return DP_NONE;
+  uint64_t h = DP_HASH_INIT;
+  for (uint32_t k = a; k < b; ++k) h = dp_hash_step(h, buf[k]);
+  for (uint64_t slot = h & mask;; slot = (slot + 1) & mask) {
+    const uint64_t e = table[slot];
+    if (e == 0) return DP_NONE;
+    if ((e ^ h) >> 32) continue;
+    const uint32_t id = (uint32_t)e - 1u;
+    const uint32_t o = off[id], len = off[id + 1] - o;
+    if (len != b - a) continue;
+    bool same = true;
+    for (uint32_t k = 0; k < len && same; ++k) same = (uint8_t)names[o + k] == buf[a + k];
+    if (same) return id;
+  }
+}
+
+/* ---- tokens --------------------------------------------------------------- */
+enum { DP_TOK_REC = 0, DP_TOK_FAIL = 1, DP_TOK_SEMI = 2, DP_TOK_IRREGULAR = 3 };
+
+struct DpRecord {
+  uint32_t h0, h1;    /* header without its last character: buf[h0, h1) */
+  uint8_t last;       /* the last character of the header (the sign) */
+  int64_t dist, np;
+  float sd;
+};
+
+__device__ __forceinline__ bool dp_digit(uint8_t c) { return c >= '0' && c <= '9'; }
+
+/* [+-]?digits, at most 18 digits.  0 ok, 1 sscanf would fail, 2 out of the regular form */
+__device__ __forceinline__ int dp_int(const uint8_t *buf, uint32_t &i, uint32_t e, int64_t &out)
+{
+  bool neg = false;
+  if (i < e && (buf[i] == '-' || buf[i] == '+')) { neg = buf[i] == '-'; ++i; }
+  if (i >= e || !dp_digit(buf[i])) return 1;
+  uint64_t v = 0;
+  uint32_t nd = 0;
+  while (i < e && dp_digit(buf[i])) { v = v * 10u + (uint64_t)(buf[i] - '0'); ++i; ++nd; }
+  if (nd > 18) return 2;
+  out = neg ? -(int64_t)v : (int64_t)v;
+  return 0;
+}
+
+/* the token buf[s, e) as sscanf("%1023[^>,],%ld,%ld,%f") sees it */
+__device__ __forceinline__ int dp_token(const uint8_t *buf, uint32_t s, uint32_t e, DpRecord &r)
+{
+  if (e - s == 1 && buf[s] == ';') return DP_TOK_SEMI;
+  const bool semi = buf[s] == ';';
+  /* a token that starts with ';' and is longer: a record named ";..." if it
+     scans, a separator if not -- left to the host */
+  if (semi) return DP_TOK_IRREGULAR;
+  uint32_t i = s;
+  while (i < e && buf[i] != ',' && buf[i] != '>') ++i;
+  if (i == s) return DP_TOK_FAIL;                 /* %[ matched nothing */
+  if (i < e && buf[i] == '>') return DP_TOK_IRREGULAR;
+  if (i >= e) return DP_TOK_FAIL;                 /* no ',' after the header */
+  r.h0 = s; r.h1 = i - 1; r.last = buf[i - 1];
+  ++i;
+  int rc = dp_int(buf, i, e, r.dist);
+  if (rc) return rc == 1 ? DP_TOK_FAIL : DP_TOK_IRREGULAR;
+  if (i >= e || buf[i] != ',') return DP_TOK_FAIL;
+  ++i;
+  rc = dp_int(buf, i, e, r.np);
+  if (rc) return rc == 1 ? DP_TOK_FAIL : DP_TOK_IRREGULAR;
+  if (i >= e || buf[i] != ',') return DP_TOK_FAIL;
+  ++i;
+  /* %f: sign, digits [. digits] | . digits, then the end of the token */
+  bool neg = false;
+  if (i < e && (buf[i] == '-' || buf[i] == '+')) { neg = buf[i] == '-'; ++i; }
+  if (i >= e) return DP_TOK_FAIL;
+  if (!dp_digit(buf[i]) && buf[i] != '.') return DP_TOK_IRREGULAR;   /* inf, nan, ... or a failure */
+  uint64_t m = 0;
+  uint32_t sig = 0, frac = 0, nd = 0;
+  while (i < e && dp_digit(buf[i])) {
+    if (m || buf[i] != '0') ++sig;
+    m = m * 10u + (uint64_t)(buf[i] - '0'); ++i; ++nd;
+    if (sig > 19) return DP_TOK_IRREGULAR;
+  }
+  if (i < e && buf[i] == '.') {
+    ++i;
+    while (i < e && dp_digit(buf[i])) {
+      if (m || buf[i] != '0') ++sig;
+      m = m * 10u + (uint64_t)(buf[i] - '0'); ++i; ++nd; ++frac;
+      if (sig > 19 || frac > 22) return DP_TOK_IRREGULAR;
+    }
+  }
+  if (nd == 0) return DP_TOK_IRREGULAR;            /* "." alone: a failure; rare enough for the host */
+  if (i != e) return DP_TOK_IRREGULAR;             /* exponent, hex, trailing text */
+  /* m < 10^19 < 2^64; 10^frac (frac <= 22) is a double.  (double)m and the
+     quotient round once each: d is within 2^-52 of the decimal, relatively
+     (about one unit of its last place).  strtof rounds the decimal to 24 bits;
+     (float)d rounds d.  The two agree unless a float midpoint lies between the
+     decimal and d, i.e. unless d is within that distance of a midpoint: the low
+     29 bits of d's fraction are then within a few units of 2^28.  Four units
+     of margin; such a value goes to the host. */
+  double p10 = 1.0;
+  for (uint32_t k = 0; k < frac; ++k) p10 *= 10.0;
+  const double d = (double)m / p10;
+  const uint64_t bits = (uint64_t)__double_as_longlong(d);
+  const int64_t low = (int64_t)(bits & 0x1FFFFFFFull) - 0x10000000ll;
+  /* (an exact d -- 99936252, 8388608.5 -- may be a midpoint: both roundings
+     then break the tie to even) */
+  const bool exact = m < (1ull << 53) && __fma_rn(d, p10, -(double)m) == 0.0;
+  if (!exact && low >= -4 && low <= 4) return DP_TOK_IRREGULAR;
+  if (d != 0.0 && d < 1.2e-38) return DP_TOK_IRREGULAR;   /* float subnormals round on another grid */
+  r.sd = neg ? -(float)d : (float)d;
+  return DP_TOK_REC;
+}
+
+/* ---- the stride kernel ------------------------------------------------------
+   EMIT = false: candidate slots per stride (cand_cnt[b]), irregular flags.
+   EMIT = true : parses, looks the names up, writes the candidates of stride b
+                 from cand_base[b] on, first error, number of valid records. */
+template <bool EMIT>
+__global__ void __launch_bounds__(DP_THREADS)
+k_dp_stride(const char *text, uint64_t len, uint32_t *cand_cnt, const uint32_t *cand_base,
+            const char *names, const uint32_t *name_off, const uint64_t *table, uint64_t mask,
+            uint32_t *o_root, uint32_t *o_ctg, int64_t *o_dist, int64_t *o_np, float *o_sd,
+            uint8_t *o_flags, uint8_t *o_valid, unsigned long long *res)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t sbuf[DP_BUF];
+  __shared__ uint16_t line_start[DP_MAXLINES + 1];
+  __shared__ uint16_t line_cand[DP_MAXLINES];
+  __shared__ uint32_t s_scan[DP_THREADS];
+  __shared__ uint32_t s_first[2], s_total, s_irregular;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * DP_STRIDE;
+  const uint64_t hi = lo + DP_STRIDE < len ? lo + DP_STRIDE : len;
+  if (tid < 2) s_first[tid] = 0xFFFFFFFFu;
+  if (tid == 0) { s_total = 0; s_irregular = 0; }
+  __syncthreads();
+  /* first line start at or after lo / hi: one past the first newline from
+     position x - 1 on, within a line's length */
+  for (int w = 0; w < 2; ++w) {
+    const uint64_t x = w ? hi : lo;
+    if (x == 0 || x >= len) continue;
+    for (uint32_t k = tid; k < DP_MAXLINE + 1; k += DP_THREADS) {
+      const uint64_t q = x - 1 + k;
+      if (q < len && text[q] == '\n') atomicMin(&s_first[w], k);
+    }
+  }
+  __syncthreads();
+  uint64_t start = lo, end = hi;
+  bool bad = false;
+  if (lo != 0) { if (s_first[0] == 0xFFFFFFFFu) bad = true; else start = lo + s_first[0]; }
+  if (hi < len) { if (s_first[1] == 0xFFFFFFFFu) bad = true; else end = hi + s_first[1]; }
+  if (bad) {
+    /* a line above the reference's buffer (or no newline up to the end of the
+       file): the host reports it */
+    if (tid == 0) atomicOr(res + 1, 1ull);
+    if (!EMIT && tid == 0) cand_cnt[blockIdx.x] = 0;
+    return;
+  }
+  if (start >= end) {
+    if (!EMIT && tid == 0) cand_cnt[blockIdx.x] = 0;
+    return;
+  }
+  const uint32_t n = (uint32_t)(end - start);     /* <= DP_STRIDE + DP_MAXLINE */
+  /* stage: 16-byte chunks of the aligned range, bytes at the ends */
+  {
+    const uint64_t g0 = start & ~15ull;
+    const uint32_t shift = (uint32_t)(start - g0);
+    const uint32_t chunks = (shift + n + 15u) / 16u;
+    for (uint32_t c = tid; c < chunks; c += DP_THREADS) {
+      const uint64_t g = g0 + (uint64_t)c * 16u;
+      if (g >= start && g + 16u <= end && ((uintptr_t)(text + g) & 15u) == 0) {
+        *(uint4 *)(sbuf + (size_t)c * 16u) = *(const uint4 *)(text + g);
+      } else {
+        for (uint32_t k = 0; k < 16u; ++k) {
+          const uint64_t q = g + k;
+          sbuf[(size_t)c * 16u + k] = (q >= start && q < end) ? (uint8_t)text[q] : (uint8_t)'\n';
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const uint8_t *buf = sbuf + (uint32_t)(start - (start & ~15ull));
+  /* line starts: every thread a slice of the bytes, counts, scan, write */
+  const uint32_t q = (n + DP_THREADS - 1) / DP_THREADS;
+  const uint32_t b0 = tid * q < n ? tid * q : n, b1 = b0 + q < n ? b0 + q : n;
+  uint32_t cnt = 0;
+  bool irregular = false;
+  for (uint32_t i = b0; i < b1; ++i) {
+    const uint8_t c = buf[i];
+    if (i == 0 || buf[i - 1] == '\n') ++cnt;
+    if ((c < 0x20 && c != '\n') || c == 0x7F) irregular = true;     /* tabs, CR, NUL, ... */
+    if (c == '\n' && i > 0 && buf[i - 1] == ' ') irregular = true;  /* pass 0 and pass 1 see different tokens */
+  }
+  if (start + n == len && tid == DP_THREADS - 1 && buf[n - 1] != '\n') irregular = true;
+  s_scan[tid] = cnt;
+  __syncthreads();
+  for (uint32_t off = 1; off < DP_THREADS; off <<= 1) {
+    const uint32_t v = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t nlines = s_scan[DP_THREADS - 1];
+  if (nlines > DP_MAXLINES) irregular = true;
+  if (irregular) atomicOr(&s_irregular, 1u);
+  {
+    uint32_t w = s_scan[tid] - cnt;
+    if (nlines <= DP_MAXLINES)
+      for (uint32_t i = b0; i < b1; ++i)
+        if (i == 0 || buf[i - 1] == '\n') line_start[w++] = (uint16_t)i;
+  }
+  __syncthreads();
+  if (s_irregular) {
+    if (tid == 0) atomicOr(res + 1, 1ull);
+    if (!EMIT && tid == 0) cand_cnt[blockIdx.x] = 0;
+    return;
+  }
+  /* the last line of the range ends at n (with its newline at n - 1) */
+  /* pass A: candidate slots per line = tokens - root - separators */
+  uint32_t mine = 0;
+  for (uint32_t j = tid; j < nlines; j += DP_THREADS) {
+    const uint32_t ls = line_start[j], le = (j + 1 < nlines ? line_start[j + 1] : n) - 1u;
+    uint32_t ntok = 0, nsemi = 0;
+    if (le + 1u - ls > DP_MAXLINE) atomicOr(res + 1, 1ull);   /* the reference's fgets would split it */
+    for (uint32_t i = ls; i < le;) {
+      while (i < le && buf[i] == ' ') ++i;
+      if (i >= le) break;
+      const uint32_t s = i;
+      while (i < le && buf[i] != ' ') ++i;
+      ++ntok;
+      if (i - s == 1 && buf[s] == ';') ++nsemi;
+    }
+    const uint32_t c = ntok > 1 ? ntok - 1 - nsemi : 0;
+    line_cand[j] = (uint16_t)c;
+    mine += c;
+  }
+  if (!EMIT) {
+    atomicAdd(&s_total, mine);
+    __syncthreads();
+    if (tid == 0) cand_cnt[blockIdx.x] = s_total;
+    return;
+  }
+  __syncthreads();
+  /* exclusive scan of line_cand (thread t scans the lines t*per .. ) */
+  {
+    const uint32_t per = (nlines + DP_THREADS - 1) / DP_THREADS;
+    const uint32_t l0 = tid * per < nlines ? tid * per : nlines, l1 = l0 + per < nlines ? l0 + per : nlines;
+    uint32_t sum = 0;
+    for (uint32_t j = l0; j < l1; ++j) sum += line_cand[j];
+    s_scan[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < DP_THREADS; off <<= 1) {
+      const uint32_t v = tid >= off ? s_scan[tid - off] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    /* line_cand becomes the line's first slot inside the stride: below 2^16,
+       a stride has at most (DP_STRIDE + DP_MAXLINE) / 2 = 8703 tokens */
+    uint32_t run = s_scan[tid] - sum;
+    for (uint32_t j = l0; j < l1; ++j) { const uint32_t c = line_cand[j]; line_cand[j] = (uint16_t)run; run += c; }
+    __syncthreads();
+  }
+  /* pass B: one line per thread */
+  const uint64_t base = cand_base[blockIdx.x];
+  unsigned long long first_err = ~0ull;
+  uint32_t nvalid = 0;
+  for (uint32_t j = tid; j < nlines; j += DP_THREADS) {
+    const uint32_t ls = line_start[j], le = (j + 1 < nlines ? line_start[j + 1] : n) - 1u;
+    uint64_t slot = base + line_cand[j];
+    uint32_t ntok = 0, root = DP_NONE;
+    bool sense = true, irr = false;
+    for (uint32_t i = ls; i < le;) {
+      while (i < le && buf[i] == ' ') ++i;
+      if (i >= le) break;
+      const uint32_t s = i;
+      while (i < le && buf[i] != ' ') ++i;
+      if (ntok++ == 0) {
+        root = dp_lookup(buf, s, i, names, name_off, table, mask);
+        continue;
+      }
+      DpRecord r;
+      const int kind = dp_token(buf, s, i, r);
+      if (kind == DP_TOK_SEMI) { sense = !sense; continue; }
+      bool ok = false;
+      if (kind == DP_TOK_IRREGULAR) irr = true;
+      else if (root != DP_NONE) {
+        const unsigned long long at = (unsigned long long)(start + s) << 4;
+        if (kind == DP_TOK_FAIL) { if ((at | DP_ERR_RECORD) < first_err) first_err = at | DP_ERR_RECORD; }
+        else if (r.np < 0) { if ((at | DP_ERR_PAIRS) < first_err) first_err = at | DP_ERR_PAIRS; }
+        else if (r.last != '+' && r.last != '-') { if ((at | DP_ERR_SIGN) < first_err) first_err = at | DP_ERR_SIGN; }
+        else {
+          const uint32_t ctg = dp_lookup(buf, r.h0, r.h1, names, name_off, table, mask);
+          if (ctg != DP_NONE) {
+            ok = true;
+            o_root[slot] = root; o_ctg[slot] = ctg; o_dist[slot] = r.dist; o_np[slot] = r.np;
+            o_sd[slot] = r.sd;
+            o_flags[slot] = (uint8_t)((sense ? 1u : 0u) | (r.last == '+' ? 2u : 0u));
+          }
+        }
+      }
+      o_valid[slot] = ok ? 1 : 0;
+      nvalid += ok ? 1u : 0u;
+      ++slot;
+    }
+    /* a line without a second token, whatever its first one (parser.c:203-208) */
+    if (ntok < 2) {
+      const unsigned long long at = ((unsigned long long)(start + ls) << 4) | DP_ERR_RECORD;
+      if (at < first_err) first_err = at;
+    }
+    if (irr) atomicOr(res + 1, 1ull);
+  }
+  if (first_err != ~0ull) atomicMin(res + 0, first_err);
+  if (nvalid) atomicAdd(res + 2, (unsigned long long)nvalid);
+}
+
+__global__ void k_dp_compact(const uint8_t *valid, const uint32_t *pos, uint64_t n, const uint32_t *root,
+                             const uint32_t *ctg, const int64_t *dist, const int64_t *np, const float *sd,
+                             const uint8_t *flags, uint32_t *root2, uint32_t *ctg2, int64_t *dist2,
+                             int64_t *np2, float *sd2, uint8_t *flags2)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !valid[i]) return;
+  const uint32_t o = pos[i];
+  root2[o] = root[i]; ctg2[o] = ctg[i]; dist2[o] = dist[i]; np2[o] = np[i]; sd2[o] = sd[i];
+  flags2[o] = flags[i];
+}
+
+/* ---- C ABI -------------------------------------------------------------------- */
+extern "C" {
+
+int gtsg_deparser_create(GtsgDeParser **out, int device, void *stream)
+{
+  if (!out) return GTSG_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return GTSG_EHIP;
+  GtsgDeParser *p = new GtsgDeParser();
+  memset(p, 0, sizeof *p);
+  p->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete p; return GTSG_EHIP; }
+  if (stream) p->st = (hipStream_t)stream;
+  else {
+    if (hipStreamCreate(&p->st) != hipSuccess) { delete p; return GTSG_EHIP; }
+    p->own_stream = true;
+  }
+  if (hipMalloc((void **)&p->d_res, 64) != hipSuccess) {
+    if (p->own_stream) hipStreamDestroy(p->st);
+    delete p;
+    return GTSG_ENOMEM;
+  }
+  *out = p;
+  return 0;
+}
+
+static void dp_free_parse(GtsgDeParser *p)
+{
+  void *ptrs[] = {p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->valid, p->cand_cnt, p->scan_tmp, p->pos,
+                  p->root2, p->ctg2, p->dist2, p->np2, p->sd2, p->flags2};
+  for (void *q : ptrs) if (q) hipFree(q);
+  p->root = p->ctg = p->root2 = p->ctg2 = p->cand_cnt = p->scan_tmp = p->pos = nullptr;
+  p->dist = p->np = p->dist2 = p->np2 = nullptr;
+  p->sd = p->sd2 = nullptr;
+  p->flags = p->valid = p->flags2 = nullptr;
+  p->cap_cand = p->cap_blocks = p->cap2 = 0;
+}
+
+void gtsg_deparser_destroy(GtsgDeParser *p)
+{
+  if (!p) return;
+  hipSetDevice(p->device);
+  dp_free_parse(p);
+  if (p->names) hipFree(p->names);
+  if (p->name_off) hipFree(p->name_off);
+  if (p->table) hipFree(p->table);
+  if (p->text) hipFree(p->text);
+  if (p->d_res) hipFree(p->d_res);
+  if (p->own_stream) hipStreamDestroy(p->st);
+  delete p;
+}
+
+const char *gtsg_deparser_last_error(const GtsgDeParser *p) { return p ? p->err : "no parser"; }
+
+int gtsg_deparser_set_names(GtsgDeParser *p, const char *blob, const uint64_t *offsets, uint64_t n)
+{
+  if (!p || (n && (!blob || !offsets))) return GTSG_EINVAL;
+  DPCHK(hipSetDevice(p->device));
+  if (p->names) { hipFree(p->names); p->names = nullptr; }
+  if (p->name_off) { hipFree(p->name_off); p->name_off = nullptr; }
+  if (p->table) { hipFree(p->table); p->table = nullptr; }
+  p->n_names = 0;
+  const uint64_t bytes = n ? offsets[n] : 0;
+  if (n >= 0x7FFFFFFFull || bytes >= 0xFFFFFFFFull) return dp_fail(p, GTSG_ELIMIT, "too many contig names");
+  uint64_t size = 16;
+  while (size < 2 * n + 2) size <<= 1;
+  DPCHK(hipMalloc((void **)&p->names, bytes + 16));
+  DPCHK(hipMalloc((void **)&p->name_off, (n + 1) * sizeof(uint32_t)));
+  DPCHK(hipMalloc((void **)&p->table, size * sizeof(uint64_t)));
+  uint32_t *off32 = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));
+  if (!off32) return dp_fail(p, GTSG_ENOMEM, "out of host memory");
+  for (uint64_t i = 0; i <= n; ++i) off32[i] = (uint32_t)(n ? offsets[i] : 0);
+  hipError_t e1 = hipMemcpyAsync(p->name_off, off32, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, p->st);
+  hipError_t e2 = bytes ? hipMemcpyAsync(p->names, blob, bytes, hipMemcpyHostToDevice, p->st) : hipSuccess;
+  hipError_t e3 = hipMemsetAsync(p->table, 0, size * sizeof(uint64_t), p->st);
+  if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && n)
+    k_dp_insert<<<(uint32_t)((n + 255) / 256), 256, 0, p->st>>>(p->names, p->name_off, n, p->table, size - 1);
+  hipError_t e4 = hipStreamSynchronize(p->st);
+  free(off32);
+  DPCHK(e1); DPCHK(e2); DPCHK(e3); DPCHK(e4);
+  DPCHK(hipGetLastError());
+  p->table_mask = size - 1;
+  p->n_names = n;
+  return 0;
+}
+
+int gtsg_deparser_parse(GtsgDeParser *p, const char *text, uint64_t len, int on_device, GtsgDeParseResult *res)
+{
+  if (!p || !res || (len && !text)) return GTSG_EINVAL;
+  memset(res, 0, sizeof *res);
+  DPCHK(hipSetDevice(p->device));
+  if (!p->table) return dp_fail(p, GTSG_EINVAL, "gtsg_deparser_set_names has not been called");
+  p->n_records = 0;
+  p->compacted = false;
+  if (len == 0) return 0;
+  /* candidate slots are numbered in 32 bits, a stride has fewer than 2^14 */
+  if (len >= (1ull << 32)) return dp_fail(p, GTSG_ELIMIT, "distance file of 4 GB or more");
+  const char *d_text = text;
+  if (!on_device) {
+    if (p->text_cap < len + 16) {
+      if (p->text) hipFree(p->text);
+      p->text = nullptr; p->text_cap = 0;
+      DPCHK(hipMalloc((void **)&p->text, len + 16));
+      p->text_cap = len + 16;
+    }
+    DPCHK(hipMemcpyAsync(p->text, text, len, hipMemcpyHostToDevice, p->st));
+    d_text = p->text;
+  }
+  const uint64_t nblocks = (len + DP_STRIDE - 1) / DP_STRIDE;
+  if (nblocks >= 0x7FFFFFFFull) return dp_fail(p, GTSG_ELIMIT, "distance file too large");
+  if (p->cap_blocks < nblocks + 1) {
+    if (p->cand_cnt) hipFree(p->cand_cnt);
+    if (p->scan_tmp) hipFree(p->scan_tmp);
+    p->cand_cnt = p->scan_tmp = nullptr; p->cap_blocks = 0;
+    DPCHK(hipMalloc((void **)&p->cand_cnt, (nblocks + 1) * sizeof(uint32_t)));
+    p->cap_blocks = nblocks + 1;
+  }
+  unsigned long long init[4] = {~0ull, 0ull, 0ull, 0ull};
+  DPCHK(hipMemcpyAsync(p->d_res, init, sizeof init, hipMemcpyHostToDevice, p->st));
+  k_dp_stride<false><<<(uint32_t)nblocks, DP_THREADS, 0, p->st>>>(
+      d_text, len, p->cand_cnt, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+      nullptr, nullptr, nullptr, p->d_res);
+  /* candidates per stride -> bases; a text of n bytes holds fewer than n / 2 tokens */
+  {
+    const uint64_t need = gts_scan_tmp_elems(nblocks + 1) + 2;
+    uint32_t *tmp = nullptr;
+    DPCHK(hipMalloc((void **)&tmp, need * sizeof(uint32_t)));
+    if (p->scan_tmp) hipFree(p->scan_tmp);
+    p->scan_tmp = tmp;
+    gts_exscan<uint32_t, uint32_t>(p->cand_cnt, p->cand_cnt, nblocks, p->scan_tmp, (uint32_t *)(p->d_res + 3), p->st);
+  }
+  unsigned long long h[4];
+  DPCHK(hipMemcpyAsync(h, p->d_res, sizeof h, hipMemcpyDeviceToHost, p->st));
+  DPCHK(hipStreamSynchronize(p->st));
+  DPCHK(hipGetLastError());
+  const uint64_t ncand = (uint32_t)h[3];
+  res->n_candidates = ncand;
+  if (h[1]) { res->irregular = 1; return 0; }
+  if (ncand >= (1ull << 31)) return dp_fail(p, GTSG_ELIMIT, "2^31 records or more in the distance file");
+  if (p->cap_cand < ncand + 1) {
+    void *ptrs[] = {p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->valid, p->pos};
+    for (void *q : ptrs) if (q) hipFree(q);
+    p->root = p->ctg = p->pos = nullptr; p->dist = p->np = nullptr; p->sd = nullptr; p->flags = p->valid = nullptr;
+    p->cap_cand = 0;
+    const uint64_t c = ncand + 1;
+    DPCHK(hipMalloc((void **)&p->root, c * 4)); DPCHK(hipMalloc((void **)&p->ctg, c * 4));
+    DPCHK(hipMalloc((void **)&p->dist, c * 8)); DPCHK(hipMalloc((void **)&p->np, c * 8));
+    DPCHK(hipMalloc((void **)&p->sd, c * 4)); DPCHK(hipMalloc((void **)&p->flags, c));
+    DPCHK(hipMalloc((void **)&p->valid, c));
+    p->cap_cand = c;
+  }
+  DPCHK(hipMemsetAsync(p->d_res + 3, 0, 8, p->st));
+  k_dp_stride<true><<<(uint32_t)nblocks, DP_THREADS, 0, p->st>>>(
+      d_text, len, nullptr, p->cand_cnt, p->names, p->name_off, p->table, p->table_mask, p->root, p->ctg,
+      p->dist, p->np, p->sd, p->flags, p->valid, p->d_res);
+  DPCHK(hipMemcpyAsync(h, p->d_res, sizeof h, hipMemcpyDeviceToHost, p->st));
+  DPCHK(hipStreamSynchronize(p->st));
+  DPCHK(hipGetLastError());
+  if (h[1]) { res->irregular = 1; return 0; }
+  if (h[0] != ~0ull) {
+    res->error = (int)(h[0] & 15u);
+    res->error_pos = h[0] >> 4;
+    return 0;
+  }
+  const uint64_t nvalid = h[2];
+  res->n_records = nvalid;
+  p->n_records = nvalid;
+  if (nvalid != ncand) {
+    /* some token is not a record (unknown contig): close the gaps, order kept */
+    if (p->cap2 < nvalid + 1) {
+      void *ptrs[] = {p->root2, p->ctg2, p->dist2, p->np2, p->sd2, p->flags2};
+      for (void *q : ptrs) if (q) hipFree(q);
+      p->root2 = p->ctg2 = nullptr; p->dist2 = p->np2 = nullptr; p->sd2 = nullptr; p->flags2 = nullptr;
+      p->cap2 = 0;
+      const uint64_t c = nvalid + 1;
+      DPCHK(hipMalloc((void **)&p->root2, c * 4)); DPCHK(hipMalloc((void **)&p->ctg2, c * 4));
+      DPCHK(hipMalloc((void **)&p->dist2, c * 8)); DPCHK(hipMalloc((void **)&p->np2, c * 8));
+      DPCHK(hipMalloc((void **)&p->sd2, c * 4)); DPCHK(hipMalloc((void **)&p->flags2, c));
+      p->cap2 = c;
+    }
+    uint32_t *pos = nullptr, *tmp = nullptr;
+    DPCHK(hipMalloc((void **)&pos, (ncand + 1) * 4));
+    if (hipMalloc((void **)&tmp, (gts_scan_tmp_elems(ncand) + 2) * 4) != hipSuccess) {
+      hipFree(pos);
+      return dp_fail(p, GTSG_ENOMEM, "out of device memory");
+    }
+    gts_exscan<uint8_t, uint32_t>(p->valid, pos, ncand, tmp, (uint32_t *)nullptr, p->st);
+    k_dp_compact<<<(uint32_t)((ncand + 255) / 256), 256, 0, p->st>>>(
+        p->valid, pos, ncand, p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->root2, p->ctg2, p->dist2,
+        p->np2, p->sd2, p->flags2);
+    hipError_t es = hipStreamSynchronize(p->st);
+    hipFree(pos); hipFree(tmp);
+    DPCHK(es);
+    DPCHK(hipGetLastError());
+    p->compacted = true;
+  }
+  return 0;
+}
+
+int gtsg_deparser_records(const GtsgDeParser *p, uint64_t *n, const uint32_t **root, const uint32_t **ctg,
+                          const int64_t **dist, const float **std_dev, const int64_t **num_pairs,
+                          const uint8_t **flags)
+{
+  if (!p || !n) return GTSG_EINVAL;
+  *n = p->n_records;
+  const bool c = p->compacted;
+  if (root) *root = c ? p->root2 : p->root;
+  if (ctg) *ctg = c ? p->ctg2 : p->ctg;
+  if (dist) *dist = c ? p->dist2 : p->dist;
+  if (std_dev) *std_dev = c ? p->sd2 : p->sd;
+  if (num_pairs) *num_pairs = c ? p->np2 : p->np;
+  if (flags) *flags = c ? p->flags2 : p->flags;
+  return 0;
+}
+
+/* the records of the last parse copied to host arrays (tests, bindings) */
+int gtsg_deparser_download(GtsgDeParser *p, uint32_t *root, uint32_t *ctg, int64_t *dist, float *std_dev,
+                           int64_t *num_pairs, uint8_t *flags)
+{
+  if (!p) return GTSG_EINVAL;
+  const uint64_t n = p->n_records;
+  if (!n) return 0;
+  DPCHK(hipSetDevice(p->device));
+  const bool c = p->compacted;
+  if (root) DPCHK(hipMemcpy(root, c ? p->root2 : p->root, n * 4, hipMemcpyDeviceToHost));
+  if (ctg) DPCHK(hipMemcpy(ctg, c ? p->ctg2 : p->ctg, n * 4, hipMemcpyDeviceToHost));
+  if (dist) DPCHK(hipMemcpy(dist, c ? p->dist2 : p->dist, n * 8, hipMemcpyDeviceToHost));
+  if (std_dev) DPCHK(hipMemcpy(std_dev, c ? p->sd2 : p->sd, n * 4, hipMemcpyDeviceToHost));
+  if (num_pairs) DPCHK(hipMemcpy(num_pairs, c ? p->np2 : p->np, n * 8, hipMemcpyDeviceToHost));
+  if (flags) DPCHK(hipMemcpy(flags, c ? p->flags2 : p->flags, n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  /* extern "C" */

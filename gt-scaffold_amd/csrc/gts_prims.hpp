@@ -211,7 +211,7 @@ k_onesweep_hist(const K *keys, uint64_t n, uint32_t *ghist, int npasses, int s0,
     if (h[p][threadIdx.x]) atomicAdd(&ghist[p * 256 + threadIdx.x], h[p][threadIdx.x]);
 }
 /* ghist[pass][*] -> exclusive prefix, one workgroup per pass */
-__global__ void __launch_bounds__(GTS_BLOCK)
+static __global__ void __launch_bounds__(GTS_BLOCK)
 k_onesweep_bases(uint32_t *ghist)
 {
   uint32_t total;

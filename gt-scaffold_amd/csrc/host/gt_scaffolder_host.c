@@ -46,6 +46,8 @@ struct GtScaffolderGraph {
   bool edges_cached;
   uint8_t *vstate, *estate;  /* host copies, refreshed from the engine */
   GtsgEngine *eng;           /* NULL for hand-built graphs */
+  GtsgDeParser *dp;          /* GPU parser of the distance file (holds the name table) */
+  bool dp_names;             /* its name table is the sorted headers */
   bool sorted;               /* contigs in header order (ids are final) */
   char err[512];
 };
@@ -119,6 +121,7 @@ void gt_scaffolder_graph_delete(GtScaffolderGraph *g)
   for (i = 0; i < g->nof_vertices; i++) free(g->ctg[i].name);
   free(g->ctg); free(g->edges); free(g->vstate); free(g->estate);
   if (g->eng) gtsg_destroy(g->eng);
+  if (g->dp) gtsg_deparser_destroy(g->dp);
   free(g);
 }
 
@@ -131,6 +134,8 @@ int gt_scaffolder_graph_add_vertex(GtScaffolderGraph *g, const char *header,
   c->name = strdup(header ? header : "");
   c->seq_len = seq_len; c->astat = astat; c->copy_num = copy_num;
   g->vstate[g->nof_vertices++] = 0;
+  g->sorted = false;       /* ids are final only after the next sort (parser.c:172) */
+  g->dp_names = false;
   return 0;
 }
 
@@ -404,6 +409,61 @@ static int read_distance_records(const GtScaffolderGraph *g, const char *path,
   return 0;
 }
 
+/* Which parser reads distance files: 0 the GPU parser with the host code as
+   the fallback for files outside its regular form (default), 1 the host code
+   only, 2 the GPU parser or an error (tests). */
+static int g_host_parser = 0;
+void gt_scaffolder_set_distance_parser(int mode) { g_host_parser = mode; }
+
+/* The distance file through the GPU parser (gts_deparse.hip).  *used = 0: not
+   parsed there (no GPU, file outside the regular form or above its limits) --
+   the caller runs the host passes instead.  Otherwise res holds the outcome
+   and, without an error, the records are on the device. */
+static int gpu_parse_distances(GtScaffolderGraph *g, const char *path, GtsgDeParseResult *res,
+                               int *used, char *err, size_t errlen)
+{
+  size_t len = 0;
+  char *buf;
+  int rc;
+  *used = 0;
+  if (g_host_parser == 1) return 0;
+  sort_contigs(g);
+  if (!g->dp) {
+    if (gtsg_deparser_create(&g->dp, g_device, NULL) != 0) {
+      g->dp = NULL;
+      if (g_host_parser == 2) return seterr(err, errlen, "no MI355X available for the distance parser");
+      return 0;
+    }
+    g->dp_names = false;
+  }
+  if (!g->dp_names) {
+    uint64_t i, total = 0, *off = xcalloc(g->nof_vertices + 1, sizeof *off);
+    char *blob;
+    for (i = 0; i < g->nof_vertices; i++) { off[i] = total; total += strlen(g->ctg[i].name); }
+    off[g->nof_vertices] = total;
+    blob = xcalloc(total + 1, 1);
+    for (i = 0; i < g->nof_vertices; i++) memcpy(blob + off[i], g->ctg[i].name, off[i + 1] - off[i]);
+    rc = gtsg_deparser_set_names(g->dp, blob, off, g->nof_vertices);
+    free(blob); free(off);
+    if (rc == GTSG_ELIMIT && g_host_parser != 2) return 0;
+    if (rc) return seterr(err, errlen, "distance parser: %s", gtsg_deparser_last_error(g->dp));
+    g->dp_names = true;
+  }
+  buf = slurp(path, &len);
+  if (!buf) return seterr(err, errlen, "can not read distance file %s", path);
+  rc = gtsg_deparser_parse(g->dp, buf, len, 0, res);
+  free(buf);
+  if (rc == GTSG_ELIMIT && g_host_parser != 2) return 0;
+  if (rc) return seterr(err, errlen, "distance parser: %s", gtsg_deparser_last_error(g->dp));
+  if (res->irregular) {
+    if (g_host_parser == 2)
+      return seterr(err, errlen, "distance file %s is outside the GPU parser's regular form", path);
+    return 0;
+  }
+  *used = 1;
+  return 0;
+}
+
 static int engine_err(GtScaffolderGraph *g, int rc, char *err, size_t errlen)
 {
   if (rc == 0) return 0;
@@ -420,9 +480,21 @@ int gt_scaffolder_parser_count_distances(const GtScaffolderGraph *graph, const c
                                          uint64_t *nof_distances, char *err, size_t errlen)
 {
   uint64_t valid = 0;
-  int rc;
+  int rc, used = 0;
+  GtsgDeParseResult res;
   if (!graph || !file_name || !nof_distances) return seterr(err, errlen, "invalid argument");
   sort_contigs((GtScaffolderGraph *)graph);   /* the reference sorts through the const, too */
+  if (gpu_parse_distances((GtScaffolderGraph *)graph, file_name, &res, &used, err, errlen)) return -1;
+  if (used) {
+    /* the reference's messages, parser.c:205-236, :286 */
+    if (res.error == 1) return seterr(err, errlen, "Invalid record in dist file %s", file_name);
+    if (res.error == 2)
+      return seterr(err, errlen, "Invalid value for number of pairs in dist file %s", file_name);
+    if (res.error == 3) return seterr(err, errlen, "Invalid composition sign in dist file %s", file_name);
+    if (res.n_records == 0) return seterr(err, errlen, "distance file %s is empty", file_name);
+    *nof_distances = 2 * res.n_records;
+    return 0;
+  }
   rc = read_distance_records(graph, file_name, 0, &valid, NULL, err, errlen);
   if (!rc) *nof_distances = 2 * valid;
   return rc;
@@ -440,14 +512,22 @@ int gt_scaffolder_parser_read_distances(const char *filename, GtScaffolderGraph 
   int64_t *seq;
   float *as, *cn;
   uint64_t i;
-  int rc;
+  int rc, used = 0;
+  GtsgDeParseResult res;
   if (!g || !filename) return seterr(err, errlen, "invalid argument");
   if (g->eng) return seterr(err, errlen, "distances have been read into this graph already");
   if (g->nof_edges) return seterr(err, errlen, "the graph holds hand-built edges");
   memset(&r, 0, sizeof r);
   sort_contigs(g);
-  rc = read_distance_records(g, filename, 1, NULL, &r, err, errlen);
-  if (rc) { rec_free(&r); return -1; }
+  if (gpu_parse_distances(g, filename, &res, &used, err, errlen)) return -1;
+  /* a file the integrity check would refuse: the reference's second pass
+     skips what it cannot scan and takes the rest as it is (parser.c:340-378);
+     that is the host code's business */
+  if (used && res.error) used = 0;
+  if (!used) {
+    rc = read_distance_records(g, filename, 1, NULL, &r, err, errlen);
+    if (rc) { rec_free(&r); return -1; }
+  }
   if (gtsg_create(&g->eng, g_device, NULL) != 0) {
     rec_free(&r);
     g->eng = NULL;
@@ -460,10 +540,21 @@ int gt_scaffolder_parser_read_distances(const char *filename, GtScaffolderGraph 
     seq[i] = (int64_t)g->ctg[i].seq_len; as[i] = g->ctg[i].astat; cn[i] = g->ctg[i].copy_num;
   }
   rc = gtsg_set_contigs(g->eng, g->nof_vertices, seq, as, cn, 0);
-  if (!rc)
+  if (!rc && used) {
+    /* the records never leave the device */
+    uint64_t n = 0;
+    const uint32_t *d_root, *d_ctg;
+    const int64_t *d_dist, *d_np;
+    const float *d_sd;
+    const uint8_t *d_flags;
+    gtsg_deparser_records(g->dp, &n, &d_root, &d_ctg, &d_dist, &d_sd, &d_np, &d_flags);
+    rc = gtsg_build_from_records_ex(g->eng, n, d_root, d_ctg, d_dist, d_sd, d_np, d_flags, 1,
+                                    ismatepair ? 1 : 0);
+  } else if (!rc)
     rc = gtsg_build_from_records_ex(g->eng, r.n, r.root, r.ctg, r.dist, r.sd, r.np, r.flags, 0,
                                     ismatepair ? 1 : 0);
   free(seq); free(as); free(cn); rec_free(&r);
+  if (g->dp) { gtsg_deparser_destroy(g->dp); g->dp = NULL; g->dp_names = false; }
   if (rc) {
     engine_err(g, rc, err, errlen);
     gtsg_destroy(g->eng);
@@ -594,6 +685,25 @@ static int refresh(GtScaffolderGraph *g)
   rc = gtsg_get_vertex_states(g->eng, g->vstate);
   if (!rc && g->nof_edges) rc = gtsg_get_edge_states(g->eng, g->estate);
   return engine_err(g, rc, NULL, 0);
+}
+
+/* the edges in id order (accessor for bindings and tests; arrays of
+   gt_scaffolder_graph_nof_edges elements, any may be NULL) */
+int gt_scaffolder_graph_get_edges(GtScaffolderGraph *g, uint32_t *start, uint32_t *end, int64_t *dist,
+                                  float *std_dev, int64_t *num_pairs, uint8_t *flags)
+{
+  uint64_t i;
+  if (!g) return -1;
+  if (refresh(g)) return -1;
+  for (i = 0; i < g->nof_edges; i++) {
+    if (start) start[i] = g->edges[i].start;
+    if (end) end[i] = g->edges[i].end;
+    if (dist) dist[i] = g->edges[i].dist;
+    if (std_dev) std_dev[i] = g->edges[i].std_dev;
+    if (num_pairs) num_pairs[i] = g->edges[i].num_pairs;
+    if (flags) flags[i] = g->edges[i].flags;
+  }
+  return 0;
 }
 
 /* ref gt_scaffolder_graph.c:269-307 */

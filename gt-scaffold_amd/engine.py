@@ -21,6 +21,8 @@ SYMBOLS = [
     "gtsg_set_option", "gtsg_selftest_ambiguous", "gtsg_filter_begin", "gtsg_filter_end",
     "gtsg_filter_get_lasthit", "gtsg_filter_set_lasthit", "gtsg_label_components",
     "gtsg_route_pack", "gtsg_route_unpack", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
+    "gtsg_deparser_create", "gtsg_deparser_destroy", "gtsg_deparser_last_error", "gtsg_deparser_set_names",
+    "gtsg_deparser_parse", "gtsg_deparser_records", "gtsg_deparser_download",
 ]
 
 
@@ -36,7 +38,13 @@ HOST_SYMBOLS = [
     "gt_scaffolder_graph_last_error", "gt_scaffolder_set_device",
     "gt_scaffolder_parser_count_contigs", "gt_scaffolder_parser_read_contigs",
     "gt_scaffolder_parser_count_distances", "gt_scaffolder_parser_read_distances",
+    "gt_scaffolder_set_distance_parser", "gt_scaffolder_graph_get_edges",
 ]
+
+
+class DeParseResult(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_candidates", C.c_uint64), ("error_pos", C.c_uint64),
+                ("error", C.c_int), ("irregular", C.c_int)]
 
 
 class KernelTime(C.Structure):
@@ -120,12 +128,79 @@ def lib():
         L.gt_scaffolder_parser_read_contigs.argtypes = [vp, cp, u64, b, cp, sz]
         L.gt_scaffolder_parser_count_distances.argtypes = [vp, cp, C.POINTER(u64), cp, sz]
         L.gt_scaffolder_parser_read_distances.argtypes = [cp, vp, b, cp, sz]
+        L.gt_scaffolder_set_distance_parser.argtypes = [ci]
+        L.gt_scaffolder_graph_get_edges.argtypes = [vp] * 7
+        L.gtsg_deparser_create.argtypes = [C.POINTER(vp), ci, vp]
+        L.gtsg_deparser_destroy.argtypes = [vp]
+        L.gtsg_deparser_last_error.argtypes = [vp]
+        L.gtsg_deparser_last_error.restype = cp
+        L.gtsg_deparser_set_names.argtypes = [vp, vp, vp, u64]
+        L.gtsg_deparser_parse.argtypes = [vp, vp, u64, ci, C.POINTER(DeParseResult)]
+        L.gtsg_deparser_records.argtypes = [vp, C.POINTER(u64)] + [C.POINTER(vp)] * 6
+        L.gtsg_deparser_download.argtypes = [vp] + [vp] * 6
         _LIB = L
     return _LIB
 
 
 class EngineError(RuntimeError):
     pass
+
+
+class DeParser:
+    """DistEst text -> records on the GPU (include/gt_scaffold_hip.h, gtsg_deparser_*).
+    names: the contig headers in id order (sorted)."""
+
+    ERRORS = {1: "Invalid record", 2: "Invalid value for number of pairs", 3: "Invalid composition sign"}
+
+    def __init__(self, names, device=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        if self._L.gtsg_deparser_create(C.byref(self._h), device, None) != 0:
+            self._h = None
+            raise EngineError("no MI355X available: the distance parser has no CPU path")
+        enc = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
+        off = np.zeros(len(enc) + 1, dtype=np.uint64)
+        np.cumsum([len(x) for x in enc], out=off[1:])
+        blob = b"".join(enc)
+        self._chk(self._L.gtsg_deparser_set_names(self._h, blob, off.ctypes.data, len(enc)))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(self._L.gtsg_deparser_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gtsg_deparser_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def parse(self, text):
+        """text: bytes (host) or a uint8 device tensor.  Returns the result
+        structure (n_records, n_candidates, error, error_pos, irregular)."""
+        res = DeParseResult()
+        if isinstance(text, (bytes, bytearray)):
+            self._chk(self._L.gtsg_deparser_parse(self._h, bytes(text), len(text), 0, C.byref(res)))
+        else:
+            import torch
+            torch.cuda.current_stream().synchronize()   # the text must be complete before the call
+            self._chk(self._L.gtsg_deparser_parse(self._h, text.data_ptr(), text.numel(), 1, C.byref(res)))
+        return res
+
+    def records(self):
+        """the records of the last parse as numpy arrays"""
+        n = C.c_uint64()
+        self._chk(self._L.gtsg_deparser_records(self._h, C.byref(n), None, None, None, None, None, None))
+        n = n.value
+        out = dict(root=np.zeros(n, np.uint32), ctg=np.zeros(n, np.uint32), dist=np.zeros(n, np.int64),
+                   std_dev=np.zeros(n, np.float32), num_pairs=np.zeros(n, np.int64), flags=np.zeros(n, np.uint8))
+        self._chk(self._L.gtsg_deparser_download(self._h, *[out[k].ctypes.data for k in
+                                                            ("root", "ctg", "dist", "std_dev", "num_pairs", "flags")]))
+        return out
 
 
 HIP_STREAM_LEGACY = 1   # hip_runtime_api.h: #define hipStreamLegacy ((hipStream_t)1)
@@ -424,6 +499,17 @@ class ScaffolderGraph:
     @property
     def ne(self):
         return int(self._L.gt_scaffolder_graph_nof_edges(self._h))
+
+    def edges(self):
+        m = self.ne
+        n = max(m, 1)
+        o = dict(start=np.zeros(n, np.uint32), end=np.zeros(n, np.uint32),
+                 dist=np.zeros(n, np.int64), std_dev=np.zeros(n, np.float32),
+                 num_pairs=np.zeros(n, np.int64), flags=np.zeros(n, np.uint8))
+        self._chk(self._L.gt_scaffolder_graph_get_edges(self._h, *[o[k].ctypes.data for k in
+                                                                    ("start", "end", "dist", "std_dev",
+                                                                     "num_pairs", "flags")]))
+        return {k: v[:m] for k, v in o.items()}
 
     def mark_repeats(self, astat_file, copy_num_cutoff=0.3, astat_cutoff=20.0):
         err = C.create_string_buffer(512)

@@ -194,6 +194,43 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
      "global_task_pool_mb" (default 2048: scratch slabs of those walks; fewer
      slabs than pending walks = several launches per round) */
 
+/* ---- DistEst text on the GPU (gts_deparse.hip) --------------------------------
+   Replaces the two passes of gt_scaffolder_parser.c over the .de file
+   (count_distances: integrity check, ref parser.c:150-291; read_distances:
+   records in file order, parser.c:295-394) for files in the regular form
+   DistanceEst writes.  The records stay on the device and go to
+   gtsg_build_from_records_ex with on_device = 1.
+     set_names   the contig headers in id order (sorted, ref parser.c:172):
+                 `offsets` has n + 1 entries into `blob`
+     parse       text: the file's bytes (host or device pointer).  On return
+                 irregular != 0: the file is outside the form this parser
+                                 reproduces exactly -- parse it on the host;
+                 error != 0    : the reference's first error in file order
+                                 (1 "Invalid record", 2 "Invalid value for
+                                 number of pairs", 3 "Invalid composition
+                                 sign") at byte error_pos;
+                 otherwise     : n_records records between known contigs
+                                 (count_distances' *nof_distances is twice that)
+     records     device pointers to the records of the last parse, valid until
+                 the next parse or destroy */
+typedef struct GtsgDeParser GtsgDeParser;
+typedef struct {
+  uint64_t n_records, n_candidates, error_pos;
+  int error, irregular;
+} GtsgDeParseResult;
+int gtsg_deparser_create(GtsgDeParser **out, int device, void *hip_stream);
+void gtsg_deparser_destroy(GtsgDeParser *p);
+const char *gtsg_deparser_last_error(const GtsgDeParser *p);
+int gtsg_deparser_set_names(GtsgDeParser *p, const char *blob, const uint64_t *offsets, uint64_t n);
+int gtsg_deparser_parse(GtsgDeParser *p, const char *text, uint64_t len, int on_device,
+                        GtsgDeParseResult *res);
+int gtsg_deparser_records(const GtsgDeParser *p, uint64_t *n, const uint32_t **root,
+                          const uint32_t **ctg, const int64_t **dist, const float **std_dev,
+                          const int64_t **num_pairs, const uint8_t **flags);
+/* the same copied to host arrays of n_records elements (any may be NULL) */
+int gtsg_deparser_download(GtsgDeParser *p, uint32_t *root, uint32_t *ctg, int64_t *dist,
+                           float *std_dev, int64_t *num_pairs, uint8_t *flags);
+
 /* per-kernel timing collected with hipEvents on the engine's stream while
    option "profile" is 1.  Fills up to cap entries, returns the number of
    distinct kernels. */

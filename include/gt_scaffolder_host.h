@@ -113,8 +113,17 @@ int gt_scaffolder_graph_write_scaffold(const GtScaffolderGraphRecords *records,
 uint64_t gt_scaffolder_graph_nof_vertices(const GtScaffolderGraph *g);
 uint64_t gt_scaffolder_graph_nof_edges(const GtScaffolderGraph *g);
 const char *gt_scaffolder_graph_last_error(const GtScaffolderGraph *g);
+/* the edges in id order, arrays of gt_scaffolder_graph_nof_edges elements (any
+   may be NULL); flags: bit 0 sense, bit 1 same */
+int gt_scaffolder_graph_get_edges(GtScaffolderGraph *g, uint32_t *start, uint32_t *end,
+                                  int64_t *dist, float *std_dev, int64_t *num_pairs,
+                                  uint8_t *flags);
 /* which GPU new_from_file / the algorithms use (default 0) */
 void gt_scaffolder_set_device(int device);
+/* who reads distance files: 0 (default) the GPU parser (gts_deparse.hip), the
+   host restatement of parser.c for a file outside its regular form; 1 the host
+   code only; 2 the GPU parser or an error */
+void gt_scaffolder_set_distance_parser(int mode);
 
 #ifdef __cplusplus
 }

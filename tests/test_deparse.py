@@ -1,0 +1,250 @@
+"""The GPU DistEst parser (gts_deparse.hip) against the host restatement of
+gt_scaffolder_parser.c (gt_scaffolder_host.c: sscanf / strtok / bsearch, line by
+line as the reference) and against records written by the test itself."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+
+from helpers import DEFAULTS, pkg
+
+pytestmark = pytest.mark.gpu
+engine = pkg.engine
+
+
+def host_mode(mode):
+    engine.lib().gt_scaffolder_set_distance_parser(mode)
+
+
+@pytest.fixture(autouse=True)
+def default_parser_afterwards():
+    yield
+    host_mode(0)
+
+
+def graph_arrays(fa, de, mode):
+    host_mode(mode)
+    G = engine.ScaffolderGraph.from_files(fa, de, DEFAULTS["min_ctg_len"])
+    e = G.edges()
+    G.close()
+    return e
+
+
+def same_edges(a, b):
+    assert len(a["start"]) == len(b["start"])
+    for k in a:
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        if x.dtype.kind == "f":
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), k
+        else:
+            assert np.array_equal(x, y), k
+
+
+def write_fasta(path, names, length=300):
+    with open(path, "w") as f:
+        for n in names:
+            f.write(">%s\n%s\n" % (n, "A" * length))
+
+
+def test_reference_files_parse_on_the_gpu(golden_dir):
+    fa, de = golden_dir + "/primary-contigs.fa", golden_dir + "/libPE.de"
+    same_edges(graph_arrays(fa, de, 2), graph_arrays(fa, de, 1))
+
+
+@pytest.mark.parametrize("name", ["wrong_libPE_1.de", "wrong_libPE_2.de"])
+def test_reference_error_files(golden_dir, name):
+    """the reference's two broken distance files: same message from both parsers"""
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.skip("fixture not present")
+    msgs = []
+    for mode in (1, 2):
+        host_mode(mode)
+        with pytest.raises(engine.EngineError) as ei:
+            engine.ScaffolderGraph.from_files(golden_dir + "/primary-contigs.fa", path, DEFAULTS["min_ctg_len"])
+        msgs.append(str(ei.value))
+    assert msgs[0] == msgs[1]
+
+
+def random_de(rng, names, known_frac=0.97, lines=400):
+    """a DistEst file in the regular form + what it says, as the test reads it"""
+    out, recs = [], []
+    ids = {n: i for i, n in enumerate(sorted(names))}
+    pool = list(names) + ["ghost%d" % i for i in range(max(1, int(len(names) * (1 - known_frac))))]
+    for _ in range(lines):
+        root = rng.choice(pool)
+        toks, sense = [root], True
+        parts = []
+        for side in range(2):
+            for _ in range(rng.randrange(0, 6)):
+                ctg = rng.choice(pool)
+                sign = rng.choice("+-")
+                dist = rng.randrange(-5000, 50000)
+                npairs = rng.randrange(0, 2000)
+                digits = rng.randrange(1, 8)
+                sd = "%.*f" % (rng.randrange(0, 7), rng.uniform(0, 10 ** rng.randrange(0, digits)))
+                parts.append((side == 0, ctg, sign, dist, npairs, sd))
+                toks.append("%s%s,%d,%d,%s" % (ctg, sign, dist, npairs, sd))
+            if side == 0:
+                toks.append(";")
+        if len(toks) == 2 and toks[1] == ";":
+            pass   # "root ;" is a legal line without records
+        out.append((" " * rng.randrange(0, 2)) + (" " * rng.randrange(1, 3)).join(toks) + "\n")
+        if root in ids:
+            for sense, ctg, sign, dist, npairs, sd in parts:
+                if ctg in ids:
+                    recs.append((ids[root], ids[ctg], dist, npairs, np.float32(float(sd)),
+                                 (1 if sense else 0) | (2 if sign == "+" else 0)))
+    return "".join(out).encode(), recs
+
+
+def test_records_of_a_regular_file():
+    """record by record: ids, distances, pairs, deviations, sense flipped at
+    ';', records of unknown contigs and of lines with an unknown root dropped
+    (the compaction), repeated blanks"""
+    rng = random.Random(5)
+    names = ["ctg%d" % i for i in range(300)] + ["k%d_x" % i for i in range(50)]
+    text, recs = random_de(rng, names, lines=3000)
+    p = engine.DeParser(sorted(names))
+    res = p.parse(text)
+    assert not res.irregular and res.error == 0
+    assert res.n_records == len(recs) and res.n_candidates > res.n_records
+    got = p.records()
+    exp = np.array([(r[0], r[1], r[2], r[3], r[5]) for r in recs], dtype=np.int64)
+    assert np.array_equal(got["root"], exp[:, 0]) and np.array_equal(got["ctg"], exp[:, 1])
+    assert np.array_equal(got["dist"], exp[:, 2]) and np.array_equal(got["num_pairs"], exp[:, 3])
+    assert np.array_equal(got["flags"], exp[:, 4])
+    assert np.array_equal(got["std_dev"].view(np.uint32),
+                          np.array([r[4] for r in recs], dtype=np.float32).view(np.uint32))
+    # all contigs known: no compaction, same records from a device-resident text
+    text, recs = random_de(rng, names, known_frac=1.0, lines=2000)
+    import torch
+    dev = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+    res = p.parse(dev)
+    # (ghost pool is never empty: one unknown name stays; just compare the counts)
+    assert not res.irregular and res.error == 0 and res.n_records == len(recs)
+    p.close()
+
+
+@pytest.mark.parametrize("n_contigs", [3000, 100000])
+def test_synthetic_files_both_parsers(tmp_path, n_contigs):
+    """the file API on generated .fa / .de files: the GPU parser's graph is the
+    host parser's graph, bit for bit (std_dev as sscanf reads it)"""
+    from helpers import make_inputs
+    g = make_inputs(n_contigs, 77)
+    pkg.synth.write_files(g, str(tmp_path / "syn"))
+    fa, de = str(tmp_path / "syn.fa"), str(tmp_path / "syn.de")
+    same_edges(graph_arrays(fa, de, 2), graph_arrays(fa, de, 1))
+
+
+IRREGULAR = {
+    "exponent": "c0 c1+,10,5,1.5e1 ;\n",
+    "tab": "c0 c1+,10,5,1.5\t;\n",
+    "crlf": "c0 c1+,10,5,1.5 ;\r\n",
+    "no_final_newline": "c0 c1+,10,5,1.5 ;",
+    "gt_in_header": "c0 c>1+,10,5,1.5 ;\n",
+    "nineteen_digits": "c0 c1+,1234567890123456789,5,1.5 ;\n",
+    "blank_before_newline": "c0 c1+,10,5,1.5 \n",
+    "inf": "c0 c1+,10,5,inf ;\n",
+    "twenty_significant_digits": "c0 c1+,10,5,1.2345678901234567891 ;\n",
+    "semicolon_token": "c0 ;c1+,10,5,1.5\n",
+    "long_line": "c0 " + " ".join("c1+,10,5,1.5" for _ in range(90)) + " ;\n",
+}
+
+
+@pytest.mark.parametrize("what", sorted(IRREGULAR))
+def test_irregular_files_go_to_the_host_parser(tmp_path, what):
+    names = ["c0", "c1", "c2"]
+    fa, de = str(tmp_path / "x.fa"), str(tmp_path / "x.de")
+    write_fasta(fa, names)
+    with open(de, "w", newline="") as f:
+        f.write("c2 c0-,7,3,2.25 ;\n" + IRREGULAR[what])
+    p = engine.DeParser(sorted(names))
+    assert p.parse(open(de, "rb").read()).irregular == 1
+    p.close()
+    outcomes = []
+    for mode in (1, 0):
+        host_mode(mode)
+        try:
+            G = engine.ScaffolderGraph.from_files(fa, de, 200)
+            outcomes.append(("ok", G.edges()))
+            G.close()
+        except engine.EngineError as e:
+            outcomes.append(("error", str(e)))
+    assert outcomes[0][0] == outcomes[1][0]
+    if outcomes[0][0] == "ok":
+        same_edges(outcomes[0][1], outcomes[1][1])
+    else:
+        assert outcomes[0][1] == outcomes[1][1]
+    host_mode(2)
+    with pytest.raises(engine.EngineError, match="regular form"):
+        engine.ScaffolderGraph.from_files(fa, de, 200)
+
+
+ERRONEOUS = {
+    "one_token_line": "c0\n",
+    "empty_line": "\n",
+    "bad_record": "c0 c1+,10,x,1.5 ;\n",
+    "missing_field": "c0 c1+,10,5 ;\n",
+    "negative_pairs": "c0 c1+,10,-5,1.5 ;\n",
+    "no_sign": "c0 c1,10,5,1.5 ;\n",
+    "unknown_root_one_token": "zz\n",
+    "error_on_unknown_root_line_is_none": "zz c1+,10,x,1.5 ;\n",
+}
+
+
+@pytest.mark.parametrize("what", sorted(ERRONEOUS))
+def test_integrity_errors_are_the_reference_messages(tmp_path, what):
+    """first error in file order, the reference's message (parser.c:205-236);
+    errors on a line whose root is unknown do not count"""
+    names = ["c0", "c1", "c2"]
+    fa, de = str(tmp_path / "x.fa"), str(tmp_path / "x.de")
+    write_fasta(fa, names)
+    with open(de, "w") as f:
+        f.write("c2 c0-,7,3,2.25 ;\n" + ERRONEOUS[what] + "c1 c2+,5,5,5 ; c0+,1,1,1\n")
+    out = []
+    for mode in (1, 2):
+        host_mode(mode)
+        try:
+            G = engine.ScaffolderGraph.from_files(fa, de, 200)
+            out.append(("ok", G.ne))
+            G.close()
+        except engine.EngineError as e:
+            out.append(("error", str(e)))
+    assert out[0] == out[1], out
+
+
+def test_decimal_fractions_round_like_strtof(tmp_path):
+    """std_dev strings with up to 19 significant digits, tiny and huge, the
+    shortest round-trip forms of floats and values at float midpoints: the GPU
+    parser's float is sscanf's (or the file is handed to the host)"""
+    rng = random.Random(11)
+    names = ["c%d" % i for i in range(4)]
+    fa, de = str(tmp_path / "x.fa"), str(tmp_path / "x.de")
+    write_fasta(fa, names)
+    vals = ["0", "0.0", "-0", "1", "16777217", "16777216.5", "0.1", "0.5", "123456789012345", "0.000000000000001",
+            "33554433", "8388608.5", "8388609.5", "1.0000000596046448", "340282346638528", ".5", "5.", "+2.5"]
+    for _ in range(1000):   # repr of a float32 (up to 17 digits), as synth.write_files writes them
+        vals.append(repr(float(np.float32(rng.uniform(0.001, 10 ** rng.randrange(-2, 6))))))   # no exponent form
+    for _ in range(3000):
+        nd = rng.randrange(1, 20)
+        digits = "".join(rng.choice("0123456789") for _ in range(nd))
+        k = rng.randrange(0, nd + 1)
+        v = (digits[:k] or "0") + ("." + digits[k:] if k < nd else "")
+        vals.append(v)
+    with open(de, "w") as f:
+        for i, v in enumerate(vals):
+            f.write("c%d c%d+,%d,1,%s ;\n" % (i % 4, (i + 1) % 4, i, v))
+    same_edges(graph_arrays(fa, de, 0), graph_arrays(fa, de, 1))
+    p = engine.DeParser(sorted(names))
+    res = p.parse(open(de, "rb").read())
+    p.close()
+    # "1.0000000596046448" is 2e-17 above the midpoint of two floats, closer than
+    # the double in between can tell: such a value is the host's, the whole file irregular
+    assert res.irregular == 1
+    with open(de, "w") as f:
+        for i, v in enumerate(vals[18:]):
+            f.write("c%d c%d+,%d,1,%s ;\n" % (i % 4, (i + 1) % 4, i, v))
+    same_edges(graph_arrays(fa, de, 2), graph_arrays(fa, de, 1))
