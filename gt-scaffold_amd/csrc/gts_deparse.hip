@@ -47,7 +47,8 @@
 #define DP_STRIDE 16384u
 #define DP_MAXLINE 1023u            /* fgets(line, 1024): longest line with its newline */
 #define DP_THREADS 256u
-#define DP_MAXLINES 4096u           /* lines starting in one stride (more: irregular) */
+#define DP_MAXLINES 1024u           /* lines starting in one stride (more: irregular) */
+#define DP_MAXTOK 2048u             /* tokens in one stride (more: irregular) */
 #define DP_BUF (DP_STRIDE + 1024u + 32u)
 
 #define DP_ERR_RECORD 1u            /* "Invalid record in dist file"                 parser.c:205,236 */
@@ -116,9 +117,27 @@ __global__ void k_dp_insert(const char *names, const uint32_t *off, uint64_t n, 
   while (atomicCAS((unsigned long long *)&table[slot], 0ull, entry) != 0ull) slot = (slot + 1) & mask;
 }
 
+/* The staged text, read eight bytes at a time: a byte load from LDS costs a
+   round trip of ~100 cycles and the loops below walk the text byte by byte;
+   the cursor keeps the aligned 8-byte word of the last access in a register
+   pair (the walks go forward, so seven of eight accesses hit it). */
+struct DpText {
+  const uint8_t *base;    /* 8-byte aligned start of the LDS buffer */
+  uint32_t shift;         /* offset of text position 0 in it */
+  uint32_t blk;
+  uint64_t w;
+  __device__ __forceinline__ DpText(const uint8_t *b, uint32_t sh) : base(b), shift(sh), blk(0xFFFFFFFFu), w(0) {}
+  __device__ __forceinline__ uint8_t operator[](uint32_t i)
+  {
+    const uint32_t j = i + shift, b = j >> 3;
+    if (b != blk) { blk = b; w = *(const uint64_t *)(base + ((size_t)b << 3)); }
+    return (uint8_t)(w >> ((j & 7u) * 8u));
+  }
+};
+
 /* id of the name buf[a, b) (LDS), or GTS_NONE */
 #define DP_NONE 0xFFFFFFFFu
-__device__ __forceinline__ uint32_t dp_lookup(const uint8_t *buf, uint32_t a, uint32_t b, const char *names,
+__device__ __forceinline__ uint32_t dp_lookup(DpText &buf, uint32_t a, uint32_t b, const char *names,
                                               const uint32_t *off, const uint64_t *table, uint64_t mask)
 {
   if (a >= b) return DP_NONE;
@@ -131,9 +150,21 @@ __device__ __forceinline__ uint32_t dp_lookup(const uint8_t *buf, uint32_t a, ui
     const uint32_t id = (uint32_t)e - 1u;
     const uint32_t o = off[id], len = off[id + 1] - o;
     if (len != b - a) continue;
-    bool same = true;
-    for (uint32_t k = 0; k < len && same; ++k) same = (uint8_t)names[o + k] == buf[a + k];
-    if (same) return id;
+    /* the name itself, eight bytes per step from aligned words (the blob has
+       16 bytes of slack behind it); no early exit, so the loads of all steps
+       are in flight together */
+    uint64_t diff = 0;
+    for (uint32_t k = 0; k < len; k += 8) {
+      const uint32_t at = o + k, al = at & ~7u, sh = (at & 7u) * 8u;
+      const uint64_t lo = *(const uint64_t *)(names + al), hi = *(const uint64_t *)(names + al + 8);
+      const uint64_t wn = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+      uint64_t wt = 0;
+      const uint32_t m = len - k < 8 ? len - k : 8;
+      for (uint32_t j = 0; j < m; ++j) wt |= (uint64_t)buf[a + k + j] << (8u * j);
+      const uint64_t bytes_m = m < 8 ? (1ull << (8u * m)) - 1ull : ~0ull;
+      diff |= (wn ^ wt) & bytes_m;
+    }
+    if (diff == 0) return id;
   }
 }
 
@@ -150,7 +181,7 @@ struct DpRecord {
 __device__ __forceinline__ bool dp_digit(uint8_t c) { return c >= '0' && c <= '9'; }
 
 /* [+-]?digits, at most 18 digits.  0 ok, 1 sscanf would fail, 2 out of the regular form */
-__device__ __forceinline__ int dp_int(const uint8_t *buf, uint32_t &i, uint32_t e, int64_t &out)
+__device__ __forceinline__ int dp_int(DpText &buf, uint32_t &i, uint32_t e, int64_t &out)
 {
   bool neg = false;
   if (i < e && (buf[i] == '-' || buf[i] == '+')) { neg = buf[i] == '-'; ++i; }
@@ -164,7 +195,7 @@ __device__ __forceinline__ int dp_int(const uint8_t *buf, uint32_t &i, uint32_t 
 }
 
 /* the token buf[s, e) as sscanf("%1023[^>,],%ld,%ld,%f") sees it */
-__device__ __forceinline__ int dp_token(const uint8_t *buf, uint32_t s, uint32_t e, DpRecord &r)
+__device__ __forceinline__ int dp_token(DpText &buf, uint32_t s, uint32_t e, DpRecord &r)
 {
   if (e - s == 1 && buf[s] == ';') return DP_TOK_SEMI;
   const bool semi = buf[s] == ';';
@@ -232,7 +263,23 @@ __device__ __forceinline__ int dp_token(const uint8_t *buf, uint32_t s, uint32_t
 /* ---- the stride kernel ------------------------------------------------------
    EMIT = false: candidate slots per stride (cand_cnt[b]), irregular flags.
    EMIT = true : parses, looks the names up, writes the candidates of stride b
-                 from cand_base[b] on, first error, number of valid records. */
+                 from cand_base[b] on, first error, number of valid records.
+
+   Every step has ALL lanes on the same code:
+     1. each thread scans a slice of the staged bytes for line starts and token
+        starts (a token: a run of bytes other than ' ' and '\n'), two block
+        scans number them, a second walk writes line_start[] / tok_start[] /
+        tok_line[];
+     2. one thread per token: separator or not, first of its line or not; an
+        inclusive scan of "is a candidate" (neither) gives every record token
+        its slot, and the separators between a line's first token and a token
+        (its sense) are (tokens in between) - (candidates in between);
+     3. one thread per line: the root's id; a line with one token or none is the
+        reference's "Invalid record";
+     4. one thread per record token: conversion, look-up, the record.
+   (The first version parsed a line per thread: lanes of a wavefront were at
+   different places of the token loop most of the time, 72.8 k instructions per
+   wavefront of 15 busy lanes.) */
 template <bool EMIT>
 __global__ void __launch_bounds__(DP_THREADS)
 k_dp_stride(const char *text, uint64_t len, uint32_t *cand_cnt, const uint32_t *cand_base,
@@ -242,14 +289,16 @@ k_dp_stride(const char *text, uint64_t len, uint32_t *cand_cnt, const uint32_t *
 {
   __shared__ __attribute__((aligned(16))) uint8_t sbuf[DP_BUF];
   __shared__ uint16_t line_start[DP_MAXLINES + 1];
-  __shared__ uint16_t line_cand[DP_MAXLINES];
-  __shared__ uint32_t s_scan[DP_THREADS];
-  __shared__ uint32_t s_first[2], s_total, s_irregular;
+  __shared__ uint16_t first_tok[DP_MAXLINES];
+  __shared__ uint32_t root_of[EMIT ? DP_MAXLINES : 1];
+  __shared__ uint16_t tok_start[DP_MAXTOK], tok_line[DP_MAXTOK], tok_cand[DP_MAXTOK];
+  __shared__ uint32_t s_scan[DP_THREADS], s_scan2[DP_THREADS];
+  __shared__ uint32_t s_first[2], s_irregular, s_carry;
   const uint32_t tid = threadIdx.x;
   const uint64_t lo = (uint64_t)blockIdx.x * DP_STRIDE;
   const uint64_t hi = lo + DP_STRIDE < len ? lo + DP_STRIDE : len;
   if (tid < 2) s_first[tid] = 0xFFFFFFFFu;
-  if (tid == 0) { s_total = 0; s_irregular = 0; }
+  if (tid == 0) { s_irregular = 0; s_carry = 0; }
   __syncthreads();
   /* first line start at or after lo / hi: one past the first newline from
      position x - 1 on, within a line's length */
@@ -296,75 +345,69 @@ k_dp_stride(const char *text, uint64_t len, uint32_t *cand_cnt, const uint32_t *
     }
     __syncthreads();
   }
-  const uint8_t *buf = sbuf + (uint32_t)(start - (start & ~15ull));
-  /* line starts: every thread a slice of the bytes, counts, scan, write */
+  DpText txt(sbuf, (uint32_t)(start - (start & ~15ull)));
+  /* ---- 1. lines and tokens: count per slice, scan, write ---- */
   const uint32_t q = (n + DP_THREADS - 1) / DP_THREADS;
   const uint32_t b0 = tid * q < n ? tid * q : n, b1 = b0 + q < n ? b0 + q : n;
-  uint32_t cnt = 0;
+  uint32_t nl = 0, nt = 0;
   bool irregular = false;
-  for (uint32_t i = b0; i < b1; ++i) {
-    const uint8_t c = buf[i];
-    if (i == 0 || buf[i - 1] == '\n') ++cnt;
-    if ((c < 0x20 && c != '\n') || c == 0x7F) irregular = true;     /* tabs, CR, NUL, ... */
-    if (c == '\n' && i > 0 && buf[i - 1] == ' ') irregular = true;  /* pass 0 and pass 1 see different tokens */
+  {
+    uint8_t prev = b0 ? txt[b0 - 1] : (uint8_t)'\n';
+    for (uint32_t i = b0; i < b1; ++i) {
+      const uint8_t c = txt[i];
+      if (prev == '\n') ++nl;
+      if (c != ' ' && c != '\n' && (prev == ' ' || prev == '\n')) ++nt;
+      if ((c < 0x20 && c != '\n') || c == 0x7F) irregular = true;   /* tabs, CR, NUL, ... */
+      if (c == '\n' && prev == ' ') irregular = true;               /* pass 0 and pass 1 see different tokens */
+      prev = c;
+    }
   }
-  if (start + n == len && tid == DP_THREADS - 1 && buf[n - 1] != '\n') irregular = true;
-  s_scan[tid] = cnt;
+  if (start + n == len && tid == DP_THREADS - 1 && txt[n - 1] != '\n') irregular = true;
+  s_scan[tid] = nl; s_scan2[tid] = nt;
   __syncthreads();
   for (uint32_t off = 1; off < DP_THREADS; off <<= 1) {
-    const uint32_t v = tid >= off ? s_scan[tid - off] : 0;
+    const uint32_t v = tid >= off ? s_scan[tid - off] : 0, v2 = tid >= off ? s_scan2[tid - off] : 0;
     __syncthreads();
-    s_scan[tid] += v;
+    s_scan[tid] += v; s_scan2[tid] += v2;
     __syncthreads();
   }
-  const uint32_t nlines = s_scan[DP_THREADS - 1];
-  if (nlines > DP_MAXLINES) irregular = true;
+  const uint32_t nlines = s_scan[DP_THREADS - 1], ntok = s_scan2[DP_THREADS - 1];
+  if (nlines > DP_MAXLINES || ntok > DP_MAXTOK) irregular = true;   /* (degenerate text: the host's) */
   if (irregular) atomicOr(&s_irregular, 1u);
-  {
-    uint32_t w = s_scan[tid] - cnt;
-    if (nlines <= DP_MAXLINES)
-      for (uint32_t i = b0; i < b1; ++i)
-        if (i == 0 || buf[i - 1] == '\n') line_start[w++] = (uint16_t)i;
+  if (nlines <= DP_MAXLINES && ntok <= DP_MAXTOK) {
+    uint32_t wl = s_scan[tid] - nl, wt = s_scan2[tid] - nt;
+    uint8_t prev = b0 ? txt[b0 - 1] : (uint8_t)'\n';
+    for (uint32_t i = b0; i < b1; ++i) {
+      const uint8_t c = txt[i];
+      if (prev == '\n') line_start[wl++] = (uint16_t)i;
+      if (c != ' ' && c != '\n' && (prev == ' ' || prev == '\n')) {
+        tok_start[wt] = (uint16_t)i;
+        tok_line[wt] = (uint16_t)(wl - 1u);   /* a line start precedes every token: wl >= 1 */
+        ++wt;
+      }
+      prev = c;
+    }
   }
+  for (uint32_t j = tid; j < DP_MAXLINES; j += DP_THREADS) first_tok[j] = 0xFFFFu;
   __syncthreads();
   if (s_irregular) {
     if (tid == 0) atomicOr(res + 1, 1ull);
     if (!EMIT && tid == 0) cand_cnt[blockIdx.x] = 0;
     return;
   }
-  /* the last line of the range ends at n (with its newline at n - 1) */
-  /* pass A: candidate slots per line = tokens - root - separators */
-  uint32_t mine = 0;
-  for (uint32_t j = tid; j < nlines; j += DP_THREADS) {
-    const uint32_t ls = line_start[j], le = (j + 1 < nlines ? line_start[j + 1] : n) - 1u;
-    uint32_t ntok = 0, nsemi = 0;
-    if (le + 1u - ls > DP_MAXLINE) atomicOr(res + 1, 1ull);   /* the reference's fgets would split it */
-    for (uint32_t i = ls; i < le;) {
-      while (i < le && buf[i] == ' ') ++i;
-      if (i >= le) break;
-      const uint32_t s = i;
-      while (i < le && buf[i] != ' ') ++i;
-      ++ntok;
-      if (i - s == 1 && buf[s] == ';') ++nsemi;
+  /* ---- 2. per token: separator / first of its line / candidate; scan ---- */
+  for (uint32_t base = 0; base < ntok; base += DP_THREADS) {
+    const uint32_t t = base + tid;
+    uint32_t cand = 0;
+    if (t < ntok) {
+      const uint32_t s0 = tok_start[t];
+      const bool first = t == 0 || tok_line[t - 1] != tok_line[t];
+      const uint8_t c1 = s0 + 1u < n ? txt[s0 + 1u] : (uint8_t)'\n';
+      const bool semi = txt[s0] == ';' && (c1 == ' ' || c1 == '\n');
+      if (first) first_tok[tok_line[t]] = (uint16_t)t;
+      cand = (!first && !semi) ? 1u : 0u;
     }
-    const uint32_t c = ntok > 1 ? ntok - 1 - nsemi : 0;
-    line_cand[j] = (uint16_t)c;
-    mine += c;
-  }
-  if (!EMIT) {
-    atomicAdd(&s_total, mine);
-    __syncthreads();
-    if (tid == 0) cand_cnt[blockIdx.x] = s_total;
-    return;
-  }
-  __syncthreads();
-  /* exclusive scan of line_cand (thread t scans the lines t*per .. ) */
-  {
-    const uint32_t per = (nlines + DP_THREADS - 1) / DP_THREADS;
-    const uint32_t l0 = tid * per < nlines ? tid * per : nlines, l1 = l0 + per < nlines ? l0 + per : nlines;
-    uint32_t sum = 0;
-    for (uint32_t j = l0; j < l1; ++j) sum += line_cand[j];
-    s_scan[tid] = sum;
+    s_scan[tid] = cand;
     __syncthreads();
     for (uint32_t off = 1; off < DP_THREADS; off <<= 1) {
       const uint32_t v = tid >= off ? s_scan[tid - off] : 0;
@@ -372,61 +415,79 @@ k_dp_stride(const char *text, uint64_t len, uint32_t *cand_cnt, const uint32_t *
       s_scan[tid] += v;
       __syncthreads();
     }
-    /* line_cand becomes the line's first slot inside the stride: below 2^16,
-       a stride has at most (DP_STRIDE + DP_MAXLINE) / 2 = 8703 tokens */
-    uint32_t run = s_scan[tid] - sum;
-    for (uint32_t j = l0; j < l1; ++j) { const uint32_t c = line_cand[j]; line_cand[j] = (uint16_t)run; run += c; }
+    if (t < ntok) tok_cand[t] = (uint16_t)(s_carry + s_scan[tid]);   /* inclusive */
+    __syncthreads();
+    if (tid == DP_THREADS - 1) s_carry += s_scan[tid];
     __syncthreads();
   }
-  /* pass B: one line per thread */
-  const uint64_t base = cand_base[blockIdx.x];
+  if (!EMIT) {
+    /* a line above the reference's line buffer is the host's */
+    for (uint32_t j = tid; j < nlines; j += DP_THREADS)
+      if ((j + 1 < nlines ? line_start[j + 1] : n) - line_start[j] > DP_MAXLINE) atomicOr(res + 1, 1ull);
+    if (tid == 0) cand_cnt[blockIdx.x] = s_carry;
+    return;
+  }
+  /* ---- 3. per line: the root; lines without a second token ---- */
   unsigned long long first_err = ~0ull;
-  uint32_t nvalid = 0;
   for (uint32_t j = tid; j < nlines; j += DP_THREADS) {
-    const uint32_t ls = line_start[j], le = (j + 1 < nlines ? line_start[j + 1] : n) - 1u;
-    uint64_t slot = base + line_cand[j];
-    uint32_t ntok = 0, root = DP_NONE;
-    bool sense = true, irr = false;
-    for (uint32_t i = ls; i < le;) {
-      while (i < le && buf[i] == ' ') ++i;
-      if (i >= le) break;
-      const uint32_t s = i;
-      while (i < le && buf[i] != ' ') ++i;
-      if (ntok++ == 0) {
-        root = dp_lookup(buf, s, i, names, name_off, table, mask);
-        continue;
-      }
-      DpRecord r;
-      const int kind = dp_token(buf, s, i, r);
-      if (kind == DP_TOK_SEMI) { sense = !sense; continue; }
-      bool ok = false;
-      if (kind == DP_TOK_IRREGULAR) irr = true;
-      else if (root != DP_NONE) {
-        const unsigned long long at = (unsigned long long)(start + s) << 4;
-        if (kind == DP_TOK_FAIL) { if ((at | DP_ERR_RECORD) < first_err) first_err = at | DP_ERR_RECORD; }
-        else if (r.np < 0) { if ((at | DP_ERR_PAIRS) < first_err) first_err = at | DP_ERR_PAIRS; }
-        else if (r.last != '+' && r.last != '-') { if ((at | DP_ERR_SIGN) < first_err) first_err = at | DP_ERR_SIGN; }
-        else {
-          const uint32_t ctg = dp_lookup(buf, r.h0, r.h1, names, name_off, table, mask);
-          if (ctg != DP_NONE) {
-            ok = true;
-            o_root[slot] = root; o_ctg[slot] = ctg; o_dist[slot] = r.dist; o_np[slot] = r.np;
-            o_sd[slot] = r.sd;
-            o_flags[slot] = (uint8_t)((sense ? 1u : 0u) | (r.last == '+' ? 2u : 0u));
-          }
-        }
-      }
-      o_valid[slot] = ok ? 1 : 0;
-      nvalid += ok ? 1u : 0u;
-      ++slot;
+    const uint32_t f = first_tok[j];
+    uint32_t root = DP_NONE, ntl = 0;
+    if (f != 0xFFFFu) {
+      uint32_t e = tok_start[f];
+      while (e < n && txt[e] != ' ' && txt[e] != '\n') ++e;
+      root = dp_lookup(txt, tok_start[f], e, names, name_off, table, mask);
+      /* tokens of the line: up to the next line that has one */
+      uint32_t g = f + 1;
+      ntl = 1;
+      if (g < ntok && tok_line[g] == j) ntl = 2;
     }
+    root_of[j] = root;
     /* a line without a second token, whatever its first one (parser.c:203-208) */
-    if (ntok < 2) {
-      const unsigned long long at = ((unsigned long long)(start + ls) << 4) | DP_ERR_RECORD;
+    if (ntl < 2) {
+      const unsigned long long at = ((unsigned long long)(start + line_start[j]) << 4) | DP_ERR_RECORD;
       if (at < first_err) first_err = at;
     }
-    if (irr) atomicOr(res + 1, 1ull);
   }
+  __syncthreads();
+  /* ---- 4. per record token ---- */
+  const uint64_t base_slot = cand_base[blockIdx.x];
+  uint32_t nvalid = 0;
+  bool irr = false;
+  for (uint32_t t = tid; t < ntok; t += DP_THREADS) {
+    const uint32_t line = tok_line[t], f = first_tok[line];
+    if (t == f) continue;
+    const uint32_t s0 = tok_start[t];
+    uint32_t e = s0;
+    while (e < n && txt[e] != ' ' && txt[e] != '\n') ++e;
+    DpRecord r;
+    const int kind = dp_token(txt, s0, e, r);
+    if (kind == DP_TOK_SEMI) continue;
+    const uint64_t slot = base_slot + tok_cand[t] - 1u;
+    const uint32_t root = root_of[line];
+    /* separators between the line's first token and this one */
+    const uint32_t nsemi = (t - f) - ((uint32_t)tok_cand[t] - (uint32_t)tok_cand[f]);
+    const bool sense = (nsemi & 1u) == 0;
+    bool ok = false;
+    if (kind == DP_TOK_IRREGULAR) irr = true;
+    else if (root != DP_NONE) {
+      const unsigned long long at = (unsigned long long)(start + s0) << 4;
+      if (kind == DP_TOK_FAIL) { if ((at | DP_ERR_RECORD) < first_err) first_err = at | DP_ERR_RECORD; }
+      else if (r.np < 0) { if ((at | DP_ERR_PAIRS) < first_err) first_err = at | DP_ERR_PAIRS; }
+      else if (r.last != '+' && r.last != '-') { if ((at | DP_ERR_SIGN) < first_err) first_err = at | DP_ERR_SIGN; }
+      else {
+        const uint32_t ctg = dp_lookup(txt, r.h0, r.h1, names, name_off, table, mask);
+        if (ctg != DP_NONE) {
+          ok = true;
+          o_root[slot] = root; o_ctg[slot] = ctg; o_dist[slot] = r.dist; o_np[slot] = r.np;
+          o_sd[slot] = r.sd;
+          o_flags[slot] = (uint8_t)((sense ? 1u : 0u) | (r.last == '+' ? 2u : 0u));
+        }
+      }
+    }
+    o_valid[slot] = ok ? 1 : 0;
+    nvalid += ok ? 1u : 0u;
+  }
+  if (irr) atomicOr(res + 1, 1ull);
   if (first_err != ~0ull) atomicMin(res + 0, first_err);
   if (nvalid) atomicAdd(res + 2, (unsigned long long)nvalid);
 }
