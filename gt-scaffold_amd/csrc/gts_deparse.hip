@@ -194,6 +194,67 @@ __device__ __forceinline__ int dp_int(DpText &buf, uint32_t &i, uint32_t e, int6
   return 0;
 }
 
+/* %f on buf[i, e): sign, digits [. digits] | . digits, optional exponent, then
+   the end of the token.  0 ok, 1 sscanf would fail, 2 out of the regular form
+   (inf, nan, hex, more than 19 digits, trailing text, a value the double in
+   between cannot round for certain). */
+__device__ __forceinline__ int dp_float(DpText &buf, uint32_t &i, uint32_t e, float &out)
+{
+  bool neg = false;
+  if (i < e && (buf[i] == '-' || buf[i] == '+')) { neg = buf[i] == '-'; ++i; }
+  if (i >= e) return 1;
+  if (!dp_digit(buf[i]) && buf[i] != '.') return 2;   /* inf, nan, ... or a failure */
+  uint64_t m = 0;
+  uint32_t sig = 0, frac = 0, nd = 0;
+  while (i < e && dp_digit(buf[i])) {
+    if (m || buf[i] != '0') ++sig;
+    m = m * 10u + (uint64_t)(buf[i] - '0'); ++i; ++nd;
+    if (sig > 19) return 2;
+  }
+  if (i < e && buf[i] == '.') {
+    ++i;
+    while (i < e && dp_digit(buf[i])) {
+      if (m || buf[i] != '0') ++sig;
+      m = m * 10u + (uint64_t)(buf[i] - '0'); ++i; ++nd; ++frac;
+      if (sig > 19 || frac > 40) return 2;
+    }
+  }
+  if (nd == 0) return 2;            /* "." alone: a failure; rare enough for the host */
+  int32_t e10 = -(int32_t)frac;
+  if (i < e && (buf[i] == 'e' || buf[i] == 'E')) {
+    ++i;
+    bool eneg = false;
+    if (i < e && (buf[i] == '-' || buf[i] == '+')) { eneg = buf[i] == '-'; ++i; }
+    uint32_t ex = 0, ed = 0;
+    while (i < e && dp_digit(buf[i])) { ex = ex * 10u + (uint32_t)(buf[i] - '0'); ++i; if (++ed > 3) return 2; }
+    if (ed == 0) return 2;          /* "1.5e": the 'e' is not part of the number */
+    e10 += eneg ? -(int32_t)ex : (int32_t)ex;
+  }
+  if (i != e) return 2;             /* hex, trailing text */
+  if (e10 < -22 || e10 > 22) return 2;
+  /* m < 10^19 < 2^64; 10^|e10| (<= 10^22) is a double.  (double)m and the
+     quotient / product round once each: d is within 2^-52 of the decimal,
+     relatively (about one unit of its last place).  strtof rounds the decimal
+     to 24 bits; (float)d rounds d.  The two agree unless a float midpoint lies
+     between the decimal and d, i.e. unless d is within that distance of a
+     midpoint: the low 29 bits of d's fraction are then within a few units of
+     2^28.  Four units of margin; such a value goes to the host. */
+  double p10 = 1.0;
+  for (int32_t k = 0; k < (e10 < 0 ? -e10 : e10); ++k) p10 *= 10.0;
+  const double md = (double)m;
+  const double d = e10 < 0 ? md / p10 : md * p10;
+  const uint64_t bits = (uint64_t)__double_as_longlong(d);
+  const int64_t low = (int64_t)(bits & 0x1FFFFFFFull) - 0x10000000ll;
+  /* (an exact d -- 99936252, 8388608.5 -- may be a midpoint: both roundings
+     then break the tie to even) */
+  const bool exact = m < (1ull << 53) &&
+                     (e10 < 0 ? __fma_rn(d, p10, -md) == 0.0 : __fma_rn(md, p10, -d) == 0.0);
+  if (!exact && low >= -4 && low <= 4) return 2;
+  if (d != 0.0 && (d < 1.2e-38 || d > 3.4e38)) return 2;   /* float subnormals round on another grid; overflow */
+  out = neg ? -(float)d : (float)d;
+  return 0;
+}
+
 /* the token buf[s, e) as sscanf("%1023[^>,],%ld,%ld,%f") sees it */
 __device__ __forceinline__ int dp_token(DpText &buf, uint32_t s, uint32_t e, DpRecord &r)
 {
@@ -217,47 +278,65 @@ __device__ __forceinline__ int dp_token(DpText &buf, uint32_t s, uint32_t e, DpR
   if (rc) return rc == 1 ? DP_TOK_FAIL : DP_TOK_IRREGULAR;
   if (i >= e || buf[i] != ',') return DP_TOK_FAIL;
   ++i;
-  /* %f: sign, digits [. digits] | . digits, then the end of the token */
-  bool neg = false;
-  if (i < e && (buf[i] == '-' || buf[i] == '+')) { neg = buf[i] == '-'; ++i; }
-  if (i >= e) return DP_TOK_FAIL;
-  if (!dp_digit(buf[i]) && buf[i] != '.') return DP_TOK_IRREGULAR;   /* inf, nan, ... or a failure */
-  uint64_t m = 0;
-  uint32_t sig = 0, frac = 0, nd = 0;
-  while (i < e && dp_digit(buf[i])) {
-    if (m || buf[i] != '0') ++sig;
-    m = m * 10u + (uint64_t)(buf[i] - '0'); ++i; ++nd;
-    if (sig > 19) return DP_TOK_IRREGULAR;
-  }
-  if (i < e && buf[i] == '.') {
-    ++i;
-    while (i < e && dp_digit(buf[i])) {
-      if (m || buf[i] != '0') ++sig;
-      m = m * 10u + (uint64_t)(buf[i] - '0'); ++i; ++nd; ++frac;
-      if (sig > 19 || frac > 22) return DP_TOK_IRREGULAR;
+  rc = dp_float(buf, i, e, r.sd);
+  if (rc) return rc == 1 ? DP_TOK_FAIL : DP_TOK_IRREGULAR;
+  return DP_TOK_REC;
+}
+
+/* ---- a stride of text in LDS -------------------------------------------------
+   Workgroup b owns the lines that start in [b * DP_STRIDE, (b + 1) * DP_STRIDE):
+   from the first line start at or after the one bound to the first at or after
+   the other (one past the first newline from position x - 1 on; a line has at
+   most DP_MAXLINE bytes, or the file is the host's).  Stages them in sbuf with
+   16-byte loads (text position 0 of the range at offset start % 16).  false:
+   nothing starts here, or the file is irregular (flagged in res[1]). */
+__device__ __forceinline__ bool dp_stage_stride(const char *text, uint64_t len, uint8_t *sbuf, uint32_t *s_first,
+                                                unsigned long long *res, uint64_t &start, uint32_t &n)
+{
+  const uint32_t tid = threadIdx.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * DP_STRIDE;
+  const uint64_t hi = lo + DP_STRIDE < len ? lo + DP_STRIDE : len;
+  if (tid < 2) s_first[tid] = 0xFFFFFFFFu;
+  __syncthreads();
+  for (int w = 0; w < 2; ++w) {
+    const uint64_t x = w ? hi : lo;
+    if (x == 0 || x >= len) continue;
+    for (uint32_t k = tid; k < DP_MAXLINE + 1; k += DP_THREADS) {
+      const uint64_t q = x - 1 + k;
+      if (q < len && text[q] == '\n') atomicMin(&s_first[w], k);
     }
   }
-  if (nd == 0) return DP_TOK_IRREGULAR;            /* "." alone: a failure; rare enough for the host */
-  if (i != e) return DP_TOK_IRREGULAR;             /* exponent, hex, trailing text */
-  /* m < 10^19 < 2^64; 10^frac (frac <= 22) is a double.  (double)m and the
-     quotient round once each: d is within 2^-52 of the decimal, relatively
-     (about one unit of its last place).  strtof rounds the decimal to 24 bits;
-     (float)d rounds d.  The two agree unless a float midpoint lies between the
-     decimal and d, i.e. unless d is within that distance of a midpoint: the low
-     29 bits of d's fraction are then within a few units of 2^28.  Four units
-     of margin; such a value goes to the host. */
-  double p10 = 1.0;
-  for (uint32_t k = 0; k < frac; ++k) p10 *= 10.0;
-  const double d = (double)m / p10;
-  const uint64_t bits = (uint64_t)__double_as_longlong(d);
-  const int64_t low = (int64_t)(bits & 0x1FFFFFFFull) - 0x10000000ll;
-  /* (an exact d -- 99936252, 8388608.5 -- may be a midpoint: both roundings
-     then break the tie to even) */
-  const bool exact = m < (1ull << 53) && __fma_rn(d, p10, -(double)m) == 0.0;
-  if (!exact && low >= -4 && low <= 4) return DP_TOK_IRREGULAR;
-  if (d != 0.0 && d < 1.2e-38) return DP_TOK_IRREGULAR;   /* float subnormals round on another grid */
-  r.sd = neg ? -(float)d : (float)d;
-  return DP_TOK_REC;
+  __syncthreads();
+  uint64_t end = hi;
+  start = lo;
+  n = 0;
+  bool bad = false;
+  if (lo != 0) { if (s_first[0] == 0xFFFFFFFFu) bad = true; else start = lo + s_first[0]; }
+  if (hi < len) { if (s_first[1] == 0xFFFFFFFFu) bad = true; else end = hi + s_first[1]; }
+  if (bad) {
+    /* a line above the reference's buffer (or no newline up to the end of the
+       file): the host reports it */
+    if (tid == 0) atomicOr(res + 1, 1ull);
+    return false;
+  }
+  if (start >= end) return false;
+  n = (uint32_t)(end - start);     /* <= DP_STRIDE + DP_MAXLINE */
+  const uint64_t g0 = start & ~15ull;
+  const uint32_t shift = (uint32_t)(start - g0);
+  const uint32_t chunks = (shift + n + 15u) / 16u;
+  for (uint32_t c = tid; c < chunks; c += DP_THREADS) {
+    const uint64_t g = g0 + (uint64_t)c * 16u;
+    if (g >= start && g + 16u <= end && ((uintptr_t)(text + g) & 15u) == 0) {
+      *(uint4 *)(sbuf + (size_t)c * 16u) = *(const uint4 *)(text + g);
+    } else {
+      for (uint32_t k = 0; k < 16u; ++k) {
+        const uint64_t q = g + k;
+        sbuf[(size_t)c * 16u + k] = (q >= start && q < end) ? (uint8_t)text[q] : (uint8_t)'\n';
+      }
+    }
+  }
+  __syncthreads();
+  return true;
 }
 
 /* ---- the stride kernel ------------------------------------------------------
@@ -295,55 +374,12 @@ k_dp_stride(const char *text, uint64_t len, uint32_t *cand_cnt, const uint32_t *
   __shared__ uint32_t s_scan[DP_THREADS], s_scan2[DP_THREADS];
   __shared__ uint32_t s_first[2], s_irregular, s_carry;
   const uint32_t tid = threadIdx.x;
-  const uint64_t lo = (uint64_t)blockIdx.x * DP_STRIDE;
-  const uint64_t hi = lo + DP_STRIDE < len ? lo + DP_STRIDE : len;
-  if (tid < 2) s_first[tid] = 0xFFFFFFFFu;
   if (tid == 0) { s_irregular = 0; s_carry = 0; }
-  __syncthreads();
-  /* first line start at or after lo / hi: one past the first newline from
-     position x - 1 on, within a line's length */
-  for (int w = 0; w < 2; ++w) {
-    const uint64_t x = w ? hi : lo;
-    if (x == 0 || x >= len) continue;
-    for (uint32_t k = tid; k < DP_MAXLINE + 1; k += DP_THREADS) {
-      const uint64_t q = x - 1 + k;
-      if (q < len && text[q] == '\n') atomicMin(&s_first[w], k);
-    }
-  }
-  __syncthreads();
-  uint64_t start = lo, end = hi;
-  bool bad = false;
-  if (lo != 0) { if (s_first[0] == 0xFFFFFFFFu) bad = true; else start = lo + s_first[0]; }
-  if (hi < len) { if (s_first[1] == 0xFFFFFFFFu) bad = true; else end = hi + s_first[1]; }
-  if (bad) {
-    /* a line above the reference's buffer (or no newline up to the end of the
-       file): the host reports it */
-    if (tid == 0) atomicOr(res + 1, 1ull);
+  uint64_t start;
+  uint32_t n;
+  if (!dp_stage_stride(text, len, sbuf, s_first, res, start, n)) {
     if (!EMIT && tid == 0) cand_cnt[blockIdx.x] = 0;
     return;
-  }
-  if (start >= end) {
-    if (!EMIT && tid == 0) cand_cnt[blockIdx.x] = 0;
-    return;
-  }
-  const uint32_t n = (uint32_t)(end - start);     /* <= DP_STRIDE + DP_MAXLINE */
-  /* stage: 16-byte chunks of the aligned range, bytes at the ends */
-  {
-    const uint64_t g0 = start & ~15ull;
-    const uint32_t shift = (uint32_t)(start - g0);
-    const uint32_t chunks = (shift + n + 15u) / 16u;
-    for (uint32_t c = tid; c < chunks; c += DP_THREADS) {
-      const uint64_t g = g0 + (uint64_t)c * 16u;
-      if (g >= start && g + 16u <= end && ((uintptr_t)(text + g) & 15u) == 0) {
-        *(uint4 *)(sbuf + (size_t)c * 16u) = *(const uint4 *)(text + g);
-      } else {
-        for (uint32_t k = 0; k < 16u; ++k) {
-          const uint64_t q = g + k;
-          sbuf[(size_t)c * 16u + k] = (q >= start && q < end) ? (uint8_t)text[q] : (uint8_t)'\n';
-        }
-      }
-    }
-    __syncthreads();
   }
   DpText txt(sbuf, (uint32_t)(start - (start & ~15ull)));
   /* ---- 1. lines and tokens: count per slice, scan, write ---- */
@@ -492,6 +528,109 @@ k_dp_stride(const char *text, uint64_t len, uint32_t *cand_cnt, const uint32_t *
   if (nvalid) atomicAdd(res + 2, (unsigned long long)nvalid);
 }
 
+/* ---- A-statistic file (ref algorithms.c:108-153) --------------------------------
+   One record per line, scanned with "%s\t%ld\t%ld\t%ld\t%f\t%f" after the
+   line's last character is dropped (:121): header, three integers, copy number,
+   A-statistic; a contig that is found takes the two values (:139-144), a line
+   that does not scan is "Invalid record".  A thread per line (six tokens each:
+   the lanes stay together).  Regular: fields separated by blanks or tabs, the
+   integers plain, the two numbers as dp_float takes them, every contig named
+   once (the reference lets the last line win; a second mention goes to the host). */
+__global__ void __launch_bounds__(DP_THREADS)
+k_dp_astat(const char *text, uint64_t len, const char *names, const uint32_t *name_off, const uint64_t *table,
+           uint64_t mask, float *astat, float *copy_num, uint32_t *seen, unsigned long long *res)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t sbuf[DP_BUF];
+  __shared__ uint16_t line_start[DP_MAXLINES + 1];
+  __shared__ uint32_t s_scan[DP_THREADS];
+  __shared__ uint32_t s_first[2], s_irregular;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_irregular = 0;
+  uint64_t start;
+  uint32_t n;
+  if (!dp_stage_stride(text, len, sbuf, s_first, res, start, n)) return;
+  DpText txt(sbuf, (uint32_t)(start - (start & ~15ull)));
+  const uint32_t q = (n + DP_THREADS - 1) / DP_THREADS;
+  const uint32_t b0 = tid * q < n ? tid * q : n, b1 = b0 + q < n ? b0 + q : n;
+  uint32_t nl = 0;
+  bool irregular = false;
+  {
+    uint8_t prev = b0 ? txt[b0 - 1] : (uint8_t)'\n';
+    for (uint32_t i = b0; i < b1; ++i) {
+      const uint8_t c = txt[i];
+      if (prev == '\n') ++nl;
+      if ((c < 0x20 && c != '\n' && c != '\t') || c == 0x7F) irregular = true;
+      prev = c;
+    }
+  }
+  if (start + n == len && tid == DP_THREADS - 1 && txt[n - 1] != '\n') irregular = true;
+  s_scan[tid] = nl;
+  __syncthreads();
+  for (uint32_t off = 1; off < DP_THREADS; off <<= 1) {
+    const uint32_t v = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t nlines = s_scan[DP_THREADS - 1];
+  if (nlines > DP_MAXLINES) irregular = true;
+  if (irregular) atomicOr(&s_irregular, 1u);
+  if (nlines <= DP_MAXLINES) {
+    uint32_t wl = s_scan[tid] - nl;
+    uint8_t prev = b0 ? txt[b0 - 1] : (uint8_t)'\n';
+    for (uint32_t i = b0; i < b1; ++i) {
+      if (prev == '\n') line_start[wl++] = (uint16_t)i;
+      prev = txt[i];
+    }
+  }
+  __syncthreads();
+  if (s_irregular) {
+    if (tid == 0) atomicOr(res + 1, 1ull);
+    return;
+  }
+  unsigned long long first_err = ~0ull;
+  uint32_t nvalid = 0;
+  bool irr = false;
+  for (uint32_t j = tid; j < nlines; j += DP_THREADS) {
+    const uint32_t ls = line_start[j], le = (j + 1 < nlines ? line_start[j + 1] : n) - 1u;
+    if (le + 1u - ls > DP_MAXLINE) { irr = true; continue; }
+    uint32_t i = ls, h0 = 0, h1 = 0;
+    int64_t iv;
+    float cn = 0.0f, as = 0.0f;
+    int state = 0;   /* 0 ok, 1 the line does not scan, 2 irregular */
+    for (uint32_t f = 0; f < 6 && state == 0; ++f) {
+      while (i < le && (txt[i] == ' ' || txt[i] == '\t')) ++i;
+      if (i >= le) { state = 1; break; }
+      const uint32_t s0 = i;
+      while (i < le && txt[i] != ' ' && txt[i] != '\t') ++i;
+      uint32_t k = s0;
+      if (f == 0) { h0 = s0; h1 = i; }
+      else if (f < 4) {
+        const int rc = dp_int(txt, k, i, iv);
+        if (rc == 2 || (rc == 0 && k != i)) state = 2;   /* "12x": the next %ld starts inside the token */
+        else if (rc == 1) state = 1;
+      } else {
+        const int rc = dp_float(txt, k, i, f == 4 ? cn : as);
+        if (rc) state = rc;
+      }
+    }
+    if (state == 2) { irr = true; continue; }
+    if (state == 1) {
+      const unsigned long long at = ((unsigned long long)(start + ls) << 4) | DP_ERR_RECORD;
+      if (at < first_err) first_err = at;
+      continue;
+    }
+    const uint32_t id = dp_lookup(txt, h0, h1, names, name_off, table, mask);
+    if (id == DP_NONE) continue;
+    if (atomicAdd(&seen[id], 1u) != 0u) { irr = true; continue; }
+    astat[id] = as; copy_num[id] = cn;
+    ++nvalid;
+  }
+  if (irr) atomicOr(res + 1, 1ull);
+  if (first_err != ~0ull) atomicMin(res + 0, first_err);
+  if (nvalid) atomicAdd(res + 2, (unsigned long long)nvalid);
+}
+
 __global__ void k_dp_compact(const uint8_t *valid, const uint32_t *pos, uint64_t n, const uint32_t *root,
                              const uint32_t *ctg, const int64_t *dist, const int64_t *np, const float *sd,
                              const uint8_t *flags, uint32_t *root2, uint32_t *ctg2, int64_t *dist2,
@@ -558,6 +697,16 @@ void gtsg_deparser_destroy(GtsgDeParser *p)
 }
 
 const char *gtsg_deparser_last_error(const GtsgDeParser *p) { return p ? p->err : "no parser"; }
+
+void gtsg_deparser_trim(GtsgDeParser *p)
+{
+  if (!p) return;
+  hipSetDevice(p->device);
+  dp_free_parse(p);
+  if (p->text) hipFree(p->text);
+  p->text = nullptr; p->text_cap = 0;
+  p->n_records = 0; p->compacted = false;
+}
 
 int gtsg_deparser_set_names(GtsgDeParser *p, const char *blob, const uint64_t *offsets, uint64_t n)
 {
@@ -718,6 +867,71 @@ int gtsg_deparser_records(const GtsgDeParser *p, uint64_t *n, const uint32_t **r
   if (num_pairs) *num_pairs = c ? p->np2 : p->np;
   if (flags) *flags = c ? p->flags2 : p->flags;
   return 0;
+}
+
+/* A-statistic file: astat / copy_num (n names, in and out; host pointers or,
+   with arrays_on_device, device pointers) take the values of the lines whose
+   contig is known.  res->error 1 = "Invalid record in A-statistic file",
+   res->n_records = contigs set; res->irregular: nothing was written that the
+   host code would not write as well, parse the file there. */
+int gtsg_deparser_parse_astat(GtsgDeParser *p, const char *text, uint64_t len, int on_device, float *astat,
+                              float *copy_num, int arrays_on_device, GtsgDeParseResult *res)
+{
+  if (!p || !res || (len && !text) || !astat || !copy_num) return GTSG_EINVAL;
+  memset(res, 0, sizeof *res);
+  DPCHK(hipSetDevice(p->device));
+  if (!p->table) return dp_fail(p, GTSG_EINVAL, "gtsg_deparser_set_names has not been called");
+  if (len == 0 || p->n_names == 0) return 0;
+  if (len >= (1ull << 32)) return dp_fail(p, GTSG_ELIMIT, "A-statistic file of 4 GB or more");
+  const char *d_text = text;
+  if (!on_device) {
+    if (p->text_cap < len + 16) {
+      if (p->text) hipFree(p->text);
+      p->text = nullptr; p->text_cap = 0;
+      DPCHK(hipMalloc((void **)&p->text, len + 16));
+      p->text_cap = len + 16;
+    }
+    DPCHK(hipMemcpyAsync(p->text, text, len, hipMemcpyHostToDevice, p->st));
+    d_text = p->text;
+  }
+  const uint64_t n = p->n_names;
+  float *d_as = astat, *d_cn = copy_num, *work = nullptr;
+  uint32_t *seen = nullptr;
+  /* the kernel writes to a working copy: an irregular file must leave the
+     caller's arrays as they were */
+  DPCHK(hipMalloc((void **)&work, 2 * n * sizeof(float)));
+  if (hipMalloc((void **)&seen, n * sizeof(uint32_t)) != hipSuccess) {
+    hipFree(work);
+    return dp_fail(p, GTSG_ENOMEM, "out of device memory");
+  }
+  const hipMemcpyKind in = arrays_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const hipMemcpyKind back = arrays_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  hipError_t e1 = hipMemcpyAsync(work, d_as, n * sizeof(float), in, p->st);
+  hipError_t e2 = hipMemcpyAsync(work + n, d_cn, n * sizeof(float), in, p->st);
+  hipError_t e3 = hipMemsetAsync(seen, 0, n * sizeof(uint32_t), p->st);
+  unsigned long long init[4] = {~0ull, 0ull, 0ull, 0ull}, h[4] = {0, 0, 0, 0};
+  hipError_t e4 = hipMemcpyAsync(p->d_res, init, sizeof init, hipMemcpyHostToDevice, p->st);
+  const uint64_t nblocks = (len + DP_STRIDE - 1) / DP_STRIDE;
+  if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess)
+    k_dp_astat<<<(uint32_t)nblocks, DP_THREADS, 0, p->st>>>(d_text, len, p->names, p->name_off, p->table,
+                                                           p->table_mask, work, work + n, seen, p->d_res);
+  hipError_t e5 = hipMemcpyAsync(h, p->d_res, sizeof h, hipMemcpyDeviceToHost, p->st);
+  hipError_t e6 = hipStreamSynchronize(p->st);
+  hipError_t e7 = hipGetLastError();
+  int rc = 0;
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess ||
+      e6 != hipSuccess || e7 != hipSuccess)
+    rc = dp_fail(p, GTSG_EHIP, "HIP error in the A-statistic parser");
+  else if (h[1]) res->irregular = 1;
+  else if (h[0] != ~0ull) { res->error = (int)(h[0] & 15u); res->error_pos = h[0] >> 4; }
+  else {
+    res->n_records = h[2];
+    if (hipMemcpy(d_as, work, n * sizeof(float), back) != hipSuccess ||
+        hipMemcpy(d_cn, work + n, n * sizeof(float), back) != hipSuccess)
+      rc = dp_fail(p, GTSG_EHIP, "HIP error in the A-statistic parser");
+  }
+  hipFree(work); hipFree(seen);
+  return rc;
 }
 
 /* the records of the last parse copied to host arrays (tests, bindings) */

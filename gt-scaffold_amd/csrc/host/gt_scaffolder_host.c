@@ -415,17 +415,12 @@ static int read_distance_records(const GtScaffolderGraph *g, const char *path,
 static int g_host_parser = 0;
 void gt_scaffolder_set_distance_parser(int mode) { g_host_parser = mode; }
 
-/* The distance file through the GPU parser (gts_deparse.hip).  *used = 0: not
-   parsed there (no GPU, file outside the regular form or above its limits) --
-   the caller runs the host passes instead.  Otherwise res holds the outcome
-   and, without an error, the records are on the device. */
-static int gpu_parse_distances(GtScaffolderGraph *g, const char *path, GtsgDeParseResult *res,
-                               int *used, char *err, size_t errlen)
+/* The GPU parser of the graph with the sorted headers as its name table.
+   *have = 0: there is none (host-only mode, no GPU, too many names). */
+static int ensure_parser(GtScaffolderGraph *g, int *have, char *err, size_t errlen)
 {
-  size_t len = 0;
-  char *buf;
   int rc;
-  *used = 0;
+  *have = 0;
   if (g_host_parser == 1) return 0;
   sort_contigs(g);
   if (!g->dp) {
@@ -449,6 +444,23 @@ static int gpu_parse_distances(GtScaffolderGraph *g, const char *path, GtsgDePar
     if (rc) return seterr(err, errlen, "distance parser: %s", gtsg_deparser_last_error(g->dp));
     g->dp_names = true;
   }
+  *have = 1;
+  return 0;
+}
+
+/* The distance file through the GPU parser (gts_deparse.hip).  *used = 0: not
+   parsed there (no GPU, file outside the regular form or above its limits) --
+   the caller runs the host passes instead.  Otherwise res holds the outcome
+   and, without an error, the records are on the device. */
+static int gpu_parse_distances(GtScaffolderGraph *g, const char *path, GtsgDeParseResult *res,
+                               int *used, char *err, size_t errlen)
+{
+  size_t len = 0;
+  char *buf;
+  int rc, have = 0;
+  *used = 0;
+  if (ensure_parser(g, &have, err, errlen)) return -1;
+  if (!have) return 0;
   buf = slurp(path, &len);
   if (!buf) return seterr(err, errlen, "can not read distance file %s", path);
   rc = gtsg_deparser_parse(g->dp, buf, len, 0, res);
@@ -554,7 +566,7 @@ int gt_scaffolder_parser_read_distances(const char *filename, GtScaffolderGraph 
     rc = gtsg_build_from_records_ex(g->eng, r.n, r.root, r.ctg, r.dist, r.sd, r.np, r.flags, 0,
                                     ismatepair ? 1 : 0);
   free(seq); free(as); free(cn); rec_free(&r);
-  if (g->dp) { gtsg_deparser_destroy(g->dp); g->dp = NULL; g->dp_names = false; }
+  if (g->dp) gtsg_deparser_trim(g->dp);   /* the name table stays for the A-statistic file */
   if (rc) {
     engine_err(g, rc, err, errlen);
     gtsg_destroy(g->eng);
@@ -607,9 +619,36 @@ int gt_scaffolder_graph_mark_repeats(const char *filename, GtScaffolderGraph *g,
     char *buf = slurp(filename, &len), hdr[1025], line[1025];
     float *as, *cn;
     uint64_t i;
-    int rc;
+    int rc, have = 0, on_gpu = 0;
     if (!buf) return seterr(err, errlen, "can not read A-statistic file %s", filename);
-    while (pos < len) {
+    if (ensure_parser(g, &have, err, errlen)) { free(buf); return -1; }
+    if (have) {
+      /* the same scan on the GPU (gts_deparse.hip, k_dp_astat) */
+      GtsgDeParseResult res;
+      as = xcalloc(g->nof_vertices, sizeof *as);
+      cn = xcalloc(g->nof_vertices, sizeof *cn);
+      for (i = 0; i < g->nof_vertices; i++) { as[i] = g->ctg[i].astat; cn[i] = g->ctg[i].copy_num; }
+      rc = gtsg_deparser_parse_astat(g->dp, buf, len, 0, as, cn, 0, &res);
+      if (rc && !(rc == GTSG_ELIMIT && g_host_parser != 2)) {
+        free(as); free(cn); free(buf);
+        return seterr(err, errlen, "A-statistic parser: %s", gtsg_deparser_last_error(g->dp));
+      }
+      if (!rc && res.irregular && g_host_parser == 2) {
+        free(as); free(cn); free(buf);
+        return seterr(err, errlen, "A-statistic file %s is outside the GPU parser's regular form", filename);
+      }
+      if (!rc && !res.irregular) {
+        if (res.error) {
+          free(as); free(cn); free(buf);
+          return seterr(err, errlen, "Invalid record in A-statistic file %s", filename);
+        }
+        for (i = 0; i < g->nof_vertices; i++) { g->ctg[i].astat = as[i]; g->ctg[i].copy_num = cn[i]; }
+        on_gpu = 1;
+      }
+      free(as); free(cn);
+      gtsg_deparser_trim(g->dp);
+    }
+    while (!on_gpu && pos < len) {
       size_t ls = pos, ll;
       long n1, n2, n3;
       float copy_num = 0.0f, astat = 0.0f;

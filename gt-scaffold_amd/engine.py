@@ -22,7 +22,8 @@ SYMBOLS = [
     "gtsg_filter_get_lasthit", "gtsg_filter_set_lasthit", "gtsg_label_components",
     "gtsg_route_pack", "gtsg_route_unpack", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
     "gtsg_deparser_create", "gtsg_deparser_destroy", "gtsg_deparser_last_error", "gtsg_deparser_set_names",
-    "gtsg_deparser_parse", "gtsg_deparser_records", "gtsg_deparser_download",
+    "gtsg_deparser_parse", "gtsg_deparser_records", "gtsg_deparser_download", "gtsg_deparser_parse_astat",
+    "gtsg_deparser_trim",
 ]
 
 
@@ -138,6 +139,8 @@ def lib():
         L.gtsg_deparser_parse.argtypes = [vp, vp, u64, ci, C.POINTER(DeParseResult)]
         L.gtsg_deparser_records.argtypes = [vp, C.POINTER(u64)] + [C.POINTER(vp)] * 6
         L.gtsg_deparser_download.argtypes = [vp] + [vp] * 6
+        L.gtsg_deparser_parse_astat.argtypes = [vp, vp, u64, ci, vp, vp, ci, C.POINTER(DeParseResult)]
+        L.gtsg_deparser_trim.argtypes = [vp]
         _LIB = L
     return _LIB
 
@@ -189,6 +192,15 @@ class DeParser:
             import torch
             torch.cuda.current_stream().synchronize()   # the text must be complete before the call
             self._chk(self._L.gtsg_deparser_parse(self._h, text.data_ptr(), text.numel(), 1, C.byref(res)))
+        return res
+
+    def parse_astat(self, text, astat, copy_num):
+        """A-statistic file: astat / copy_num (float32 numpy arrays over the
+        names) are updated in place for the contigs the file names"""
+        res = DeParseResult()
+        assert astat.dtype == np.float32 and copy_num.dtype == np.float32
+        self._chk(self._L.gtsg_deparser_parse_astat(self._h, bytes(text), len(text), 0, astat.ctypes.data,
+                                                    copy_num.ctypes.data, 0, C.byref(res)))
         return res
 
     def records(self):

@@ -230,6 +230,16 @@ int gtsg_deparser_records(const GtsgDeParser *p, uint64_t *n, const uint32_t **r
 /* the same copied to host arrays of n_records elements (any may be NULL) */
 int gtsg_deparser_download(GtsgDeParser *p, uint32_t *root, uint32_t *ctg, int64_t *dist,
                            float *std_dev, int64_t *num_pairs, uint8_t *flags);
+/* A-statistic file (ref algorithms.c:108-153: "%s\t%ld\t%ld\t%ld\t%f\t%f" per
+   line): astat / copy_num -- arrays over the names, in and out, host pointers or
+   (arrays_on_device) device pointers -- take the two values of every line whose
+   contig is known.  error 1 = "Invalid record in A-statistic file"; irregular:
+   the arrays are untouched, parse the file on the host. */
+int gtsg_deparser_parse_astat(GtsgDeParser *p, const char *text, uint64_t len, int on_device,
+                              float *astat, float *copy_num, int arrays_on_device,
+                              GtsgDeParseResult *res);
+/* frees the text and the records of the last parse; the name table stays */
+void gtsg_deparser_trim(GtsgDeParser *p);
 
 /* per-kernel timing collected with hipEvents on the engine's stream while
    option "profile" is 1.  Fills up to cap entries, returns the number of

@@ -120,9 +120,10 @@ int gt_scaffolder_graph_get_edges(GtScaffolderGraph *g, uint32_t *start, uint32_
                                   uint8_t *flags);
 /* which GPU new_from_file / the algorithms use (default 0) */
 void gt_scaffolder_set_device(int device);
-/* who reads distance files: 0 (default) the GPU parser (gts_deparse.hip), the
-   host restatement of parser.c for a file outside its regular form; 1 the host
-   code only; 2 the GPU parser or an error */
+/* who reads distance and A-statistic files: 0 (default) the GPU parser
+   (gts_deparse.hip), the host restatement of parser.c / algorithms.c:108-153
+   for a file outside its regular form; 1 the host code only; 2 the GPU parser
+   or an error */
 void gt_scaffolder_set_distance_parser(int mode);
 
 #ifdef __cplusplus

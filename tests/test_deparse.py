@@ -140,7 +140,8 @@ def test_synthetic_files_both_parsers(tmp_path, n_contigs):
 
 
 IRREGULAR = {
-    "exponent": "c0 c1+,10,5,1.5e1 ;\n",
+    "exponent_without_digits": "c0 c1+,10,5,1.5e ;\n",
+    "hex_float": "c0 c1+,10,5,0x1p3 ;\n",
     "tab": "c0 c1+,10,5,1.5\t;\n",
     "crlf": "c0 c1+,10,5,1.5 ;\r\n",
     "no_final_newline": "c0 c1+,10,5,1.5 ;",
@@ -226,6 +227,11 @@ def test_decimal_fractions_round_like_strtof(tmp_path):
     write_fasta(fa, names)
     vals = ["0", "0.0", "-0", "1", "16777217", "16777216.5", "0.1", "0.5", "123456789012345", "0.000000000000001",
             "33554433", "8388608.5", "8388609.5", "1.0000000596046448", "340282346638528", ".5", "5.", "+2.5"]
+    assert len(vals) == 18
+    for _ in range(500):   # exponent forms
+        vals.append("%s%de%s%d" % (rng.choice(["", "0.", "1."]), rng.randrange(0, 10 ** rng.randrange(1, 9)),
+                                   rng.choice(["", "+", "-"]), rng.randrange(0, 12)))
+        vals.append("%.*E" % (rng.randrange(0, 9), rng.uniform(1e-9, 1e9)))
     for _ in range(1000):   # repr of a float32 (up to 17 digits), as synth.write_files writes them
         vals.append(repr(float(np.float32(rng.uniform(0.001, 10 ** rng.randrange(-2, 6))))))   # no exponent form
     for _ in range(3000):
@@ -248,3 +254,66 @@ def test_decimal_fractions_round_like_strtof(tmp_path):
         for i, v in enumerate(vals[18:]):
             f.write("c%d c%d+,%d,1,%s ;\n" % (i % 4, (i + 1) % 4, i, v))
     same_edges(graph_arrays(fa, de, 2), graph_arrays(fa, de, 1))
+
+
+def astat_states(tmp_path, fa, de, astat, mode):
+    """the .dot after mark_repeats with the A-statistic file read by `mode`"""
+    host_mode(mode)
+    G = engine.ScaffolderGraph.from_files(fa, de, DEFAULTS["min_ctg_len"])
+    G.mark_repeats(astat, DEFAULTS["copy_num_cutoff"], DEFAULTS["astat_cutoff"])
+    out = str(tmp_path / ("m%d.dot" % mode))
+    G.print_dot(out)
+    G.close()
+    return open(out, "rb").read()
+
+
+def test_reference_astat_file_on_the_gpu(tmp_path, golden_dir):
+    fa, de, astat = [golden_dir + x for x in ("/primary-contigs.fa", "/libPE.de", "/libPE.astat")]
+    a, b = astat_states(tmp_path, fa, de, astat, 2), astat_states(tmp_path, fa, de, astat, 1)
+    assert a == b and b"ivory3" in a
+    assert a == open(golden_dir + "/gt_scaffolder_algorithms_test_mark_repeats_expected.dot", "rb").read()
+
+
+def test_astat_values_record_by_record():
+    """contigs named in the file take copy number and A-statistic, the others
+    keep what they had; exponent forms, blanks or tabs between the fields"""
+    rng = random.Random(3)
+    names = sorted("c%05d" % i for i in range(5000))
+    lines, exp_as, exp_cn = [], {}, {}
+    for nm in rng.sample(names, 3500) + ["ghost1", "ghost2"]:
+        cn = rng.choice(["%.3f" % rng.uniform(0, 40), "%.6e" % rng.uniform(1e-4, 100), "%d" % rng.randrange(0, 50)])
+        a = rng.choice(["%.4f" % rng.uniform(-300, 300), "%.5E" % rng.uniform(-1e3, 1e3), "-0.0"])
+        sep = rng.choice(["\t", " ", "\t "])
+        lines.append(sep.join([nm, str(rng.randrange(100, 10 ** 6)), str(rng.randrange(0, 10 ** 4)),
+                               str(rng.randrange(0, 50)), cn, a]) + "\n")
+        exp_as[nm], exp_cn[nm] = np.float32(float(a)), np.float32(float(cn))
+    text = "".join(lines).encode()
+    p = engine.DeParser(names)
+    astat = np.full(len(names), 7.5, np.float32)
+    cnum = np.full(len(names), -1.25, np.float32)
+    res = p.parse_astat(text, astat, cnum)
+    assert not res.irregular and res.error == 0 and res.n_records == 3500
+    for i, nm in enumerate(names):
+        ea, ec = exp_as.get(nm, np.float32(7.5)), exp_cn.get(nm, np.float32(-1.25))
+        assert astat[i].view(np.uint32) == ea.view(np.uint32) and cnum[i].view(np.uint32) == ec.view(np.uint32), nm
+    # a contig named twice: the reference lets the last line win -- the host's business
+    a2, c2 = astat.copy(), cnum.copy()
+    res = p.parse_astat(text + lines[0].encode(), a2, c2)
+    assert res.irregular == 1 and np.array_equal(a2, astat) and np.array_equal(c2, cnum)
+    # five fields: the reference's "Invalid record"
+    res = p.parse_astat(b"c00001\t5\t5\t5\t1.0\n", a2, c2)
+    assert res.error == 1 and not res.irregular
+    # an integer field that is not one
+    assert p.parse_astat(b"c00001\t5x\t5\t5\t1.0\t2.0\n", a2, c2).irregular == 1
+    assert p.parse_astat(b"c00001\tx\t5\t5\t1.0\t2.0\n", a2, c2).error == 1
+    p.close()
+
+
+@pytest.mark.parametrize("n_contigs", [3000, 100000])
+def test_synthetic_astat_files_both_parsers(tmp_path, n_contigs):
+    from helpers import make_inputs
+    g = make_inputs(n_contigs, 78, repeat_degree=12)
+    pkg.synth.write_files(g, str(tmp_path / "syn"))
+    fa, de, astat = [str(tmp_path / ("syn" + x)) for x in (".fa", ".de", ".astat")]
+    a, b = astat_states(tmp_path, fa, de, astat, 2), astat_states(tmp_path, fa, de, astat, 1)
+    assert a == b and b"ivory3" in a
