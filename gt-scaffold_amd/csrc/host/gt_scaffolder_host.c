@@ -726,6 +726,33 @@ static int refresh(GtScaffolderGraph *g)
   return engine_err(g, rc, NULL, 0);
 }
 
+/* buffered text output without stdio's formatting */
+typedef struct { FILE *f; size_t n; int bad; char buf[1 << 16]; } OutBuf;
+static void ob_init(OutBuf *o, FILE *f) { o->f = f; o->n = 0; o->bad = 0; }
+static int ob_flush(OutBuf *o)
+{
+  if (o->n && fwrite(o->buf, 1, o->n, o->f) != o->n) o->bad = 1;
+  o->n = 0;
+  return o->bad;
+}
+static void ob_mem(OutBuf *o, const char *p, size_t len)
+{
+  while (len) {
+    size_t room = sizeof o->buf - o->n, k = len < room ? len : room;
+    memcpy(o->buf + o->n, p, k);
+    o->n += k; p += k; len -= k;
+    if (o->n == sizeof o->buf) ob_flush(o);
+  }
+}
+static void ob_str(OutBuf *o, const char *s) { ob_mem(o, s, strlen(s)); }
+static void ob_u64(OutBuf *o, uint64_t v)
+{
+  char t[24];
+  int k = 24;
+  do { t[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+  ob_mem(o, t + k, (size_t)(24 - k));
+}
+
 /* the edges in id order (accessor for bindings and tests; arrays of
    gt_scaffolder_graph_nof_edges elements, any may be NULL) */
 int gt_scaffolder_graph_get_edges(GtScaffolderGraph *g, uint32_t *start, uint32_t *end, int64_t *dist,
@@ -753,23 +780,36 @@ int gt_scaffolder_graph_print(const GtScaffolderGraph *cg, const char *filename,
                                       "red", "green", "magenta", "blue"};
   GtScaffolderGraph *g = (GtScaffolderGraph *)cg;
   FILE *f;
+  OutBuf ob;
   uint64_t i;
   if (refresh(g)) return seterr(err, errlen, "%s", g->err);
   f = fopen(filename, "w");
   if (!f) return seterr(err, errlen, "cannot open %s for writing", filename);
-  fputs("digraph {\n", f);
-  for (i = 0; i < g->nof_vertices; i++)
-    fprintf(f, "%lu [color=\"%s\" label=\"%s\"];\n", (unsigned long)i,
-            color[g->vstate[i] & 7], g->ctg[i].name);
-  for (i = 0; i < g->nof_edges; i++)
-    fprintf(f, "%lu -> %lu [color=\"%s\" label=\"%ld\" arrowhead=\"%s\"];\n",
-            (unsigned long)g->edges[i].start, (unsigned long)g->edges[i].end,
-            color[g->estate[i] & 7], (long)g->edges[i].dist,
-            (g->edges[i].flags & 1) ? "normal" : "inv");
-  fputs("}\n", f);
+  /* the lines of gt_scaffolder_graph_print_generic (graph.c:269-307), put
+     together by hand: fprintf costs more than everything the GPU does */
+  ob_init(&ob, f);
+  ob_str(&ob, "digraph {\n");
+  for (i = 0; i < g->nof_vertices; i++) {
+    ob_u64(&ob, i);
+    ob_str(&ob, " [color=\""); ob_str(&ob, color[g->vstate[i] & 7]);
+    ob_str(&ob, "\" label=\""); ob_str(&ob, g->ctg[i].name);
+    ob_str(&ob, "\"];\n");
+  }
+  for (i = 0; i < g->nof_edges; i++) {
+    const HEdge *e = g->edges + i;
+    ob_u64(&ob, e->start); ob_str(&ob, " -> "); ob_u64(&ob, e->end);
+    ob_str(&ob, " [color=\""); ob_str(&ob, color[g->estate[i] & 7]);
+    ob_str(&ob, "\" label=\"");
+    if (e->dist < 0) { ob_str(&ob, "-"); ob_u64(&ob, (uint64_t)0 - (uint64_t)e->dist); }
+    else ob_u64(&ob, (uint64_t)e->dist);
+    ob_str(&ob, (e->flags & 1) ? "\" arrowhead=\"normal\"];\n" : "\" arrowhead=\"inv\"];\n");
+  }
+  ob_str(&ob, "}\n");
+  if (ob_flush(&ob)) { fclose(f); return seterr(err, errlen, "cannot write %s", filename); }
   fclose(f);
   return 0;
 }
+
 
 /* ref gt_scaffolder_graph.c:421-500; exit status 2 stands for the reference's
    failing assertion */
