@@ -499,6 +499,36 @@ k_dp_astat(const char *text, uint64_t len, const char *names, const uint32_t *na
   if (nvalid) atomicAdd(res + 2, (unsigned long long)nvalid);
 }
 
+/* ---- contig headers in strcmp order (ref parser.c:172: qsort of the vertices) ----
+   Keys: the first 14 bytes of a name, big endian, seven to a 64-bit word (the
+   sort keeps bit 63 out of the order), zero padded -- a shorter name sorts
+   before the names it is a prefix of, as with strcmp.  Two stable 7-pass
+   sorts (low word, then high word); names that agree in all 14 bytes are
+   flagged and put in order by the caller. */
+__global__ void k_dp_name_keys(const char *names, const uint32_t *off, uint64_t n, uint64_t *khi, uint64_t *klo,
+                               uint32_t *idx)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t o = off[i], len = off[i + 1] - o;
+  uint64_t hi = 0, lo = 0;
+  for (uint32_t k = 0; k < 7; ++k) hi = (hi << 8) | (k < len ? (uint8_t)names[o + k] : 0u);
+  for (uint32_t k = 7; k < 14; ++k) lo = (lo << 8) | (k < len ? (uint8_t)names[o + k] : 0u);
+  khi[i] = hi; klo[i] = lo; idx[i] = (uint32_t)i;
+}
+__global__ void k_dp_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t n, uint64_t *dst)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_dp_name_ties(const uint64_t *khi_sorted, const uint64_t *klo, const uint32_t *perm, uint64_t n,
+                               uint8_t *tie)
+{
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  tie[i] = i > 0 && khi_sorted[i] == khi_sorted[i - 1] && klo[perm[i]] == klo[perm[i - 1]] ? 1 : 0;
+}
+
 __global__ void k_dp_compact(const uint8_t *valid, const uint32_t *pos, uint64_t n, const uint32_t *root,
                              const uint32_t *ctg, const int64_t *dist, const int64_t *np, const float *sd,
                              const uint8_t *flags, uint32_t *root2, uint32_t *ctg2, int64_t *dist2,
@@ -799,6 +829,67 @@ int gtsg_deparser_parse_astat(GtsgDeParser *p, const char *text, uint64_t len, i
       rc = dp_fail(p, GTSG_EHIP, "HIP error in the A-statistic parser");
   }
   hipFree(work); hipFree(seen);
+  return rc;
+}
+
+/* perm[j] = index of the name that is j-th in strcmp order by its first 14
+   bytes; tie[j] != 0: name perm[j] agrees with name perm[j - 1] in those bytes
+   (the caller orders such runs itself).  Host arrays of n elements. */
+int gtsg_sort_names(int device, const char *blob, const uint64_t *offsets, uint64_t n, uint32_t *perm,
+                    uint8_t *tie)
+{
+  if (n == 0) return 0;
+  if (!blob || !offsets || !perm || !tie) return GTSG_EINVAL;
+  if (n >= (1ull << 30) || offsets[n] >= 0xFFFFFFFFull) return GTSG_ELIMIT;
+  if (hipSetDevice(device) != hipSuccess) return GTSG_EHIP;
+  const uint64_t bytes = offsets[n];
+  char *d_names = nullptr;
+  uint32_t *d_off = nullptr, *v0 = nullptr, *v1 = nullptr, *tmp = nullptr;
+  uint64_t *khi = nullptr, *klo = nullptr, *k0 = nullptr, *k1 = nullptr;
+  uint8_t *d_tie = nullptr;
+  uint32_t *off32 = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));
+  int rc = 0;
+  hipStream_t st = nullptr;
+  if (!off32) return GTSG_ENOMEM;
+  for (uint64_t i = 0; i <= n; ++i) off32[i] = (uint32_t)offsets[i];
+#define SN(x) do { if (!rc && (x) != hipSuccess) rc = GTSG_EHIP; } while (0)
+  SN(hipMalloc((void **)&d_names, bytes + 16)); SN(hipMalloc((void **)&d_off, (n + 1) * 4));
+  SN(hipMalloc((void **)&khi, n * 8)); SN(hipMalloc((void **)&klo, n * 8));
+  SN(hipMalloc((void **)&k0, n * 8)); SN(hipMalloc((void **)&k1, n * 8));
+  SN(hipMalloc((void **)&v0, n * 4)); SN(hipMalloc((void **)&v1, n * 4));
+  SN(hipMalloc((void **)&tmp, gts_sort_tmp_elems(n) * 4)); SN(hipMalloc((void **)&d_tie, n));
+  SN(hipStreamCreate(&st));
+  if (!rc) {
+    const uint32_t grid = (uint32_t)((n + 255) / 256);
+    int shifts[7] = {0, 8, 16, 24, 32, 40, 48};
+    SN(hipMemcpyAsync(d_names, blob, bytes, hipMemcpyHostToDevice, st));
+    SN(hipMemcpyAsync(d_off, off32, (n + 1) * 4, hipMemcpyHostToDevice, st));
+    k_dp_name_keys<<<grid, 256, 0, st>>>(d_names, d_off, n, khi, klo, v0);
+    SN(hipMemcpyAsync(k0, klo, n * 8, hipMemcpyDeviceToDevice, st));
+    int w = gts_radix_sort<uint64_t>(k0, v0, k1, v1, n, shifts, 7, tmp, st);
+    if (w < 0) rc = GTSG_ELIMIT;
+    if (!rc) {
+      uint32_t *va = w ? v1 : v0, *vb = w ? v0 : v1;
+      uint64_t *ka = w ? k1 : k0, *kb = w ? k0 : k1;
+      k_dp_gather_u64<<<grid, 256, 0, st>>>(khi, va, n, ka);
+      w = gts_radix_sort<uint64_t>(ka, va, kb, vb, n, shifts, 7, tmp, st);
+      if (w < 0) rc = GTSG_ELIMIT;
+      if (!rc) {
+        const uint32_t *vf = w ? vb : va;
+        const uint64_t *kf = w ? kb : ka;
+        k_dp_name_ties<<<grid, 256, 0, st>>>(kf, klo, vf, n, d_tie);
+        SN(hipMemcpyAsync(perm, vf, n * 4, hipMemcpyDeviceToHost, st));
+        SN(hipMemcpyAsync(tie, d_tie, n, hipMemcpyDeviceToHost, st));
+      }
+    }
+    SN(hipStreamSynchronize(st));
+    SN(hipGetLastError());
+  }
+#undef SN
+  void *ptrs[] = {d_names, d_off, khi, klo, k0, k1, v0, v1, tmp, d_tie};
+  for (void *q : ptrs) if (q) hipFree(q);
+  if (st) hipStreamDestroy(st);
+  free(off32);
   return rc;
 }
 

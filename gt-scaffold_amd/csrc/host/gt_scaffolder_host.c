@@ -254,11 +254,42 @@ static int scan_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len
   return 0;
 }
 
-/* vertex ids = rank of the header, ref parser.c:172 */
+static int g_host_parser;   /* set by gt_scaffolder_set_distance_parser, below */
+
+/* vertex ids = rank of the header, ref parser.c:172.  Many headers: the first
+   14 bytes are sorted on the GPU (gtsg_sort_names, two radix sorts), runs that
+   agree in them with qsort / strcmp here. */
+#define GPU_SORT_MIN 50000u
 static void sort_contigs(GtScaffolderGraph *g)
 {
-  if (!g->sorted) qsort(g->ctg, g->nof_vertices, sizeof *g->ctg, contig_cmp);
+  uint64_t n = g->nof_vertices;
+  if (g->sorted) return;
   g->sorted = true;
+  if (n >= GPU_SORT_MIN && g_host_parser != 1) {
+    uint64_t i, total = 0, *off = xcalloc(n + 1, sizeof *off);
+    uint32_t *perm = xcalloc(n, sizeof *perm);
+    uint8_t *tie = xcalloc(n, 1);
+    char *blob;
+    for (i = 0; i < n; i++) { off[i] = total; total += strlen(g->ctg[i].name); }
+    off[n] = total;
+    blob = xcalloc(total + 1, 1);
+    for (i = 0; i < n; i++) memcpy(blob + off[i], g->ctg[i].name, off[i + 1] - off[i]);
+    if (gtsg_sort_names(g_device, blob, off, n, perm, tie) == 0) {
+      Contig *sorted = xcalloc(n, sizeof *sorted);
+      for (i = 0; i < n; i++) sorted[i] = g->ctg[perm[i]];
+      for (i = 0; i < n;) {
+        uint64_t j = i + 1;
+        while (j < n && tie[j]) j++;
+        if (j - i > 1) qsort(sorted + i, j - i, sizeof *sorted, contig_cmp);
+        i = j;
+      }
+      memcpy(g->ctg, sorted, n * sizeof *sorted);
+      free(sorted); free(blob); free(off); free(perm); free(tie);
+      return;
+    }
+    free(blob); free(off); free(perm); free(tie);   /* no GPU: the host sort */
+  }
+  qsort(g->ctg, n, sizeof *g->ctg, contig_cmp);
 }
 
 /* ref gt_scaffolder_parser.c:495 */
@@ -412,7 +443,6 @@ static int read_distance_records(const GtScaffolderGraph *g, const char *path,
 /* Which parser reads distance files: 0 the GPU parser with the host code as
    the fallback for files outside its regular form (default), 1 the host code
    only, 2 the GPU parser or an error (tests). */
-static int g_host_parser = 0;
 void gt_scaffolder_set_distance_parser(int mode) { g_host_parser = mode; }
 
 /* The GPU parser of the graph with the sorted headers as its name table.

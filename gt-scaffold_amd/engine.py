@@ -23,7 +23,7 @@ SYMBOLS = [
     "gtsg_route_pack", "gtsg_route_unpack", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
     "gtsg_deparser_create", "gtsg_deparser_destroy", "gtsg_deparser_last_error", "gtsg_deparser_set_names",
     "gtsg_deparser_parse", "gtsg_deparser_records", "gtsg_deparser_download", "gtsg_deparser_parse_astat",
-    "gtsg_deparser_trim",
+    "gtsg_deparser_trim", "gtsg_sort_names",
 ]
 
 
@@ -141,12 +141,30 @@ def lib():
         L.gtsg_deparser_download.argtypes = [vp] + [vp] * 6
         L.gtsg_deparser_parse_astat.argtypes = [vp, vp, u64, ci, vp, vp, ci, C.POINTER(DeParseResult)]
         L.gtsg_deparser_trim.argtypes = [vp]
+        L.gtsg_sort_names.argtypes = [ci, vp, vp, u64, vp, vp]
         _LIB = L
     return _LIB
 
 
 class EngineError(RuntimeError):
     pass
+
+
+def sort_names(names, device=0):
+    """strcmp order of contig headers by their first 14 bytes on the GPU
+    (gtsg_sort_names): (perm, tie) -- tie[j]: name perm[j] agrees with name
+    perm[j-1] in those bytes, the caller orders such runs."""
+    L = lib()
+    enc = [n.encode() if isinstance(n, str) else bytes(n) for n in names]
+    off = np.zeros(len(enc) + 1, dtype=np.uint64)
+    np.cumsum([len(x) for x in enc], out=off[1:])
+    blob = b"".join(enc)
+    perm = np.zeros(max(len(enc), 1), np.uint32)
+    tie = np.zeros(max(len(enc), 1), np.uint8)
+    rc = L.gtsg_sort_names(device, blob, off.ctypes.data, len(enc), perm.ctypes.data, tie.ctypes.data)
+    if rc != 0:
+        raise EngineError("gtsg_sort_names failed (code %d)" % rc)
+    return perm[:len(enc)], tie[:len(enc)]
 
 
 class DeParser:

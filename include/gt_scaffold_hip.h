@@ -240,6 +240,13 @@ int gtsg_deparser_parse_astat(GtsgDeParser *p, const char *text, uint64_t len, i
                               GtsgDeParseResult *res);
 /* frees the text and the records of the last parse; the name table stays */
 void gtsg_deparser_trim(GtsgDeParser *p);
+/* Contig headers into strcmp order (ref parser.c:172, the qsort that makes the
+   vertex ids): perm[j] = index of the j-th name by its first 14 bytes, tie[j]
+   != 0 where name perm[j] agrees with name perm[j-1] in those bytes -- the caller
+   orders such runs with strcmp.  blob / offsets as for set_names; perm and tie
+   are host arrays of n elements. */
+int gtsg_sort_names(int device, const char *blob, const uint64_t *offsets, uint64_t n,
+                    uint32_t *perm, uint8_t *tie);
 
 /* per-kernel timing collected with hipEvents on the engine's stream while
    option "profile" is 1.  Fills up to cap entries, returns the number of

@@ -317,3 +317,41 @@ def test_synthetic_astat_files_both_parsers(tmp_path, n_contigs):
     fa, de, astat = [str(tmp_path / ("syn" + x)) for x in (".fa", ".de", ".astat")]
     a, b = astat_states(tmp_path, fa, de, astat, 2), astat_states(tmp_path, fa, de, astat, 1)
     assert a == b and b"ivory3" in a
+
+
+def test_contig_headers_sorted_on_the_gpu():
+    """ids are the ranks of the headers in strcmp order (ref parser.c:172):
+    14 bytes on the GPU, runs that agree in them ordered by the caller"""
+    rng = random.Random(9)
+    names = set()
+    while len(names) < 120000:
+        k = rng.randrange(6)
+        if k == 0:
+            names.add(b"contig-%d" % rng.randrange(10 ** 7))
+        elif k == 1:
+            names.add(b"scaffold_with_a_long_prefix_%d" % rng.randrange(10 ** 6))     # agree in 14 bytes
+        elif k == 2:
+            names.add(bytes(rng.randrange(33, 256) for _ in range(rng.randrange(1, 20))).replace(b" ", b"_"))
+        elif k == 3:
+            names.add(b"k99_%d_%d" % (rng.randrange(1000), rng.randrange(1000)))
+        elif k == 4:
+            names.add(b"a" * rng.randrange(1, 30))
+        else:
+            names.add(b"%d" % rng.randrange(10 ** 9))
+    names = list(names)
+    rng.shuffle(names)
+    names += names[:50]   # repeated headers: a run of ties
+    perm, tie = engine.sort_names(names)
+    assert sorted(perm.tolist()) == list(range(len(names)))
+    got = [names[i] for i in perm]
+    assert tie[0] == 0
+    i = 0
+    while i < len(got):
+        j = i + 1
+        while j < len(got) and tie[j]:
+            j += 1
+        assert all(x[:14] == got[i][:14] for x in got[i:j])
+        got[i:j] = sorted(got[i:j])
+        i = j
+    assert got == sorted(names)
+    assert int(tie.sum()) >= 50
