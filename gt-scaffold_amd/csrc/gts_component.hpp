@@ -289,13 +289,14 @@ struct GtsComponent {
   uint32_t nodefer;     /* statistics: why try_defer declined */
   uint32_t *reach_bits; /* walk_task: bitmap of the vertices the walk labels */
   uint64_t ubases;      /* all_bases(), ~0 = not computed yet */
+  uint32_t walk_from;   /* reference search: the walk's start vertex */
   bool no_reference;    /* walk_task: leave a walk that needs the reference search to select_walks */
   bool needs_reference;
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), no_reference(false), needs_reference(false) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -609,6 +610,12 @@ struct GtsComponent {
   /* one lane's relaxation of edge ce (start's seeding when unconditional,
      ref algorithms.c:671-677; otherwise algorithms.c:706-723).  q selects the
      participating lanes; they must have distinct end slots nb. */
+  /* a queue entry: the edge; in the packed layout (edges below 2^16, vertices
+     below 2^12) also its start vertex, which the pop would otherwise have to
+     search for in the offsets (GtsLdsStartArr: nine dependent LDS reads) */
+  GTS_HD uint32_t q_entry(uint32_t ce, uint32_t from) const { return LDS ? (ce | from << 16) : ce; }
+
+  /* (called for the edges of the walk's start vertex: walk_from) */
   GTS_HD bool relax_distinct(bool q, uint32_t nb, uint32_t ce, float distance,
                              int64_t pushd, bool unconditional)
   {
@@ -624,7 +631,7 @@ struct GtsComponent {
       M.distmap[nb] = distance;
       M.edgemap[nb] = ce;
       const uint64_t slot = qbase + ((qn + W::popc_below(im, lane)) & (qcap - 1));
-      C.wq_edge[slot] = ce;
+      C.wq_edge[slot] = q_entry(ce, walk_from);
       C.wq_dist[slot] = pushd;
     }
     if (fresh) M.touched[ntouch + W::popc_below(fm, lane)] = nb;
@@ -665,6 +672,7 @@ struct GtsComponent {
       qbase = off; qcap = need;
     }
     qh = 0; qn = 0; ntouch = 0;
+    walk_from = start;
     uint32_t nwt = 0;
     bool ok = true;
     /* lastpop may share its storage with the labels of the linear walks */
@@ -720,12 +728,14 @@ struct GtsComponent {
       const uint32_t shift = (uint32_t)(qh - wbase);
       const uint32_t navail = (uint32_t)(wend - qh);
       const uint32_t src = (lane + shift) & (W::WIDTH - 1);
-      const uint32_t pe = W::shfl(w_edge, src);
+      const uint32_t pw = W::shfl(w_edge, src);
+      const uint32_t pe = LDS ? (pw & 0xFFFFu) : pw;
       const int64_t nd = (int64_t)W::shfl64((uint64_t)w_dist, src);
       uint32_t endv = 0, from = 0, eb = 0, deg = 0;
       bool dir = false;
       if (lane < navail) {
-        endv = M.cend[pe]; from = M.cstart[pe];
+        endv = M.cend[pe];
+        if constexpr (LDS) from = pw >> 16; else from = M.cstart[pe];
         dir = gts_next_dir(M.cflags[pe]);
         eb = M.coff[endv] - M.e0;
         const uint32_t ee = M.coff[endv + 1] - M.e0;
@@ -748,6 +758,7 @@ struct GtsComponent {
       const uint32_t rr = act ? r : 0;
       const uint32_t r_eb = W::shfl(eb, rr), r_excl = W::shfl(excl, rr);
       const uint32_t r_from = W::shfl(from, rr);
+      const uint32_t r_endv = W::shfl(endv, rr);
       const bool r_dir = W::shfl((uint32_t)dir, rr) != 0;
       const int64_t r_nd = (int64_t)W::shfl64((uint64_t)nd, rr);
       bool live = false, sense = false, q = false;
@@ -794,7 +805,7 @@ struct GtsComponent {
       const uint64_t fm = W::ballot(fresh);
       if (imp) {
         const uint64_t slot = qbase + ((qn + W::popc_below(im, lane)) & (qcap - 1));
-        C.wq_edge[slot] = ce;
+        C.wq_edge[slot] = q_entry(ce, r_endv);
         C.wq_dist[slot] = (int64_t)distance;
       }
       if (last) { M.distmap[nb] = distance; M.edgemap[nb] = ce; }
