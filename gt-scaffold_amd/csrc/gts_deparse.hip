@@ -529,6 +529,149 @@ __global__ void k_dp_name_ties(const uint64_t *khi_sorted, const uint64_t *klo, 
   tie[i] = i > 0 && khi_sorted[i] == khi_sorted[i - 1] && klo[perm[i]] == klo[perm[i - 1]] ? 1 : 0;
 }
 
+/* ---- FASTA: the record table (ref parser.c:399-494, the callback loops) -----------
+   A record starts at a '>' that is not inside a description line, i.e. at the
+   first '>' since the last newline; its description runs to the next newline;
+   its sequence is every later byte up to the next record start other than
+   newline, carriage return and blank.  Lines can be of any length, so the state
+   "a '>' has been seen since the last newline" is carried over the strides:
+   k_fa_summary reduces every stride to (has a newline, '>' after its last
+   newline or anywhere if none, '>' before its first newline, lines after the
+   first newline that hold a '>'), one thread chains the strides, k_fa_records
+   walks every stride with the state it starts in and writes, per record, the
+   offsets of its description and, summed in LDS first, its sequence length. */
+#define FA_STRIDE 16384u
+#define FA_THREADS 256u
+#define FA_SLICE (FA_STRIDE / FA_THREADS)
+#define FA_LREC 1024u
+
+struct FaSum { uint32_t n, a, f, s; };   /* see above; s counts lines */
+__device__ __forceinline__ FaSum fa_join(const FaSum &x, const FaSum &y)
+{
+  /* x then y */
+  FaSum r;
+  r.n = x.n | y.n;
+  r.a = y.n ? y.a : (x.a | y.a);
+  r.f = x.n ? x.f : (x.f | y.f);
+  /* lines of the join after its first newline that hold a '>': those of x,
+     those of y, and the line x ends / y begins with if x has a newline */
+  r.s = x.s + y.s + ((x.n && !x.a && y.f) ? 1u : 0u);
+  return r;
+}
+__device__ __forceinline__ FaSum fa_slice(const char *text, uint64_t lo, uint64_t hi)
+{
+  FaSum r = {0, 0, 0, 0};
+  bool gt = false;      /* '>' since the last newline of the slice (or its start) */
+  /* eight bytes a load (lo is a multiple of FA_SLICE, the buffer has 16 bytes of slack) */
+  for (uint64_t q = lo; q < hi; q += 8) {
+    uint64_t w = *(const uint64_t *)(text + q);
+    const uint32_t m = hi - q < 8 ? (uint32_t)(hi - q) : 8u;
+    for (uint32_t j = 0; j < m; ++j, w >>= 8) {
+      const char c = (char)(w & 0xFFu);
+      if (c == '\n') { r.n = 1; gt = false; }
+      else if (c == '>' && !gt) { gt = true; if (r.n) ++r.s; else r.f = 1; }
+    }
+  }
+  r.a = gt ? 1u : 0u;
+  return r;
+}
+/* block reduction of the slices' summaries in order; every thread gets the
+   summary of the slices before its own (sh[tid] exclusive) */
+__device__ __forceinline__ FaSum fa_block_scan(FaSum mine, FaSum *sh, FaSum *total)
+{
+  const uint32_t tid = threadIdx.x;
+  sh[tid] = mine;
+  __syncthreads();
+  for (uint32_t off = 1; off < FA_THREADS; off <<= 1) {
+    FaSum v = sh[tid];
+    if (tid >= off) v = fa_join(sh[tid - off], sh[tid]);
+    __syncthreads();
+    sh[tid] = v;
+    __syncthreads();
+  }
+  *total = sh[FA_THREADS - 1];
+  FaSum before = {0, 0, 0, 0};
+  if (tid) before = sh[tid - 1];
+  __syncthreads();
+  return before;
+}
+__global__ void __launch_bounds__(FA_THREADS)
+k_fa_summary(const char *text, uint64_t len, FaSum *sums)
+{
+  __shared__ FaSum sh[FA_THREADS];
+  const uint64_t lo = (uint64_t)blockIdx.x * FA_STRIDE + (uint64_t)threadIdx.x * FA_SLICE;
+  const uint64_t hi = lo + FA_SLICE < len ? lo + FA_SLICE : len;
+  FaSum total;
+  fa_block_scan(lo < len ? fa_slice(text, lo, hi) : FaSum{0, 0, 0, 0}, sh, &total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+/* carry[b] = '>' seen since the last newline at the start of stride b;
+   base[b] = records that start before stride b.  One thread: a few hundred
+   thousand strides for a file of gigabytes. */
+__global__ void k_fa_chain(const FaSum *sums, uint64_t nblocks, uint8_t *carry, uint64_t *base, uint64_t *nrec)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  uint32_t c = 0;
+  uint64_t r = 0;
+  for (uint64_t b = 0; b < nblocks; ++b) {
+    const FaSum s = sums[b];
+    carry[b] = (uint8_t)c;
+    base[b] = r;
+    r += s.s + ((s.f && !c) ? 1u : 0u);
+    c = s.n ? s.a : (c | s.a);
+  }
+  *nrec = r;
+}
+__global__ void __launch_bounds__(FA_THREADS)
+k_fa_records(const char *text, uint64_t len, const uint8_t *carry, const uint64_t *base, uint64_t *hs,
+             uint64_t *he, unsigned long long *slen)
+{
+  __shared__ FaSum sh[FA_THREADS];
+  __shared__ unsigned long long lsum[FA_LREC];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * FA_STRIDE + (uint64_t)tid * FA_SLICE;
+  const uint64_t hi = lo + FA_SLICE < len ? lo + FA_SLICE : len;
+  for (uint32_t k = tid; k < FA_LREC; k += FA_THREADS) lsum[k] = 0;
+  FaSum total;
+  const FaSum before = fa_block_scan(lo < len ? fa_slice(text, lo, hi) : FaSum{0, 0, 0, 0}, sh, &total);
+  const uint32_t c0 = carry[blockIdx.x];
+  const uint64_t b0 = base[blockIdx.x];
+  /* state at the slice's first byte */
+  bool gt = before.n ? before.a != 0 : (c0 | before.a) != 0;
+  /* records started before the slice: those before the stride + in the slices before */
+  uint64_t rec = b0 + before.s + ((before.f && !c0) ? 1u : 0u);   /* index of the NEXT record */
+  /* a description is open iff a '>' has been seen since the last newline */
+  unsigned long long cnt = 0;
+  for (uint64_t q = lo; q < hi; q += 8) {
+    uint64_t w = *(const uint64_t *)(text + q);
+    const uint32_t m = hi - q < 8 ? (uint32_t)(hi - q) : 8u;
+    for (uint32_t j = 0; j < m; ++j, w >>= 8) {
+      const char c = (char)(w & 0xFFu);
+      const uint64_t p = q + j;
+      if (c == '\n') {
+        if (gt && rec) he[rec - 1] = p;   /* (he is preset to "no newline": all ones) */
+        gt = false;
+      } else if (c == '>' && !gt) {
+        if (cnt && rec) {
+          const uint64_t l = rec - b0;   /* slot 0: the record open at the stride's start */
+          if (l < FA_LREC) atomicAdd(&lsum[l], cnt); else atomicAdd(&slen[rec - 1], cnt);
+        }
+        cnt = 0;
+        gt = true;
+        hs[rec] = p + 1;
+        ++rec;
+      } else if (!gt && c != '\r' && c != ' ') ++cnt;
+    }
+  }
+  if (cnt && rec) {
+    const uint64_t l = rec - b0;
+    if (l < FA_LREC) atomicAdd(&lsum[l], cnt); else atomicAdd(&slen[rec - 1], cnt);
+  }
+  __syncthreads();
+  for (uint32_t k = tid; k < FA_LREC; k += FA_THREADS)
+    if (lsum[k] && b0 + k >= 1) atomicAdd(&slen[b0 + k - 1], lsum[k]);
+}
+
 __global__ void k_dp_compact(const uint8_t *valid, const uint32_t *pos, uint64_t n, const uint32_t *root,
                              const uint32_t *ctg, const int64_t *dist, const int64_t *np, const float *sd,
                              const uint8_t *flags, uint32_t *root2, uint32_t *ctg2, int64_t *dist2,
@@ -891,6 +1034,72 @@ int gtsg_sort_names(int device, const char *blob, const uint64_t *offsets, uint6
   if (st) hipStreamDestroy(st);
   free(off32);
   return rc;
+}
+
+/* FASTA record table: for every record in file order the offsets of its
+   description (after the '>', up to its newline -- `len` if the file ends
+   first) and the number of sequence characters (everything up to the next
+   record start but newline, carriage return and blank).  The arrays are
+   malloc'ed here; the caller frees them. */
+int gtsg_fasta_records(int device, const char *text, uint64_t len, uint64_t *n_records, uint64_t **desc_start,
+                       uint64_t **desc_end, uint64_t **seq_len)
+{
+  if (!n_records || !desc_start || !desc_end || !seq_len || (len && !text)) return GTSG_EINVAL;
+  *n_records = 0; *desc_start = *desc_end = *seq_len = nullptr;
+  if (len == 0) return 0;
+  if (hipSetDevice(device) != hipSuccess) return GTSG_EHIP;
+  const uint64_t nblocks = (len + FA_STRIDE - 1) / FA_STRIDE;
+  if (nblocks >= 0x7FFFFFFFull) return GTSG_ELIMIT;
+  char *d_text = nullptr;
+  FaSum *sums = nullptr;
+  uint8_t *carry = nullptr;
+  uint64_t *base = nullptr, *d_n = nullptr, *hs = nullptr, *he = nullptr, *sl = nullptr;
+  hipStream_t st = nullptr;
+  int rc = 0;
+  uint64_t nrec = 0;
+#define FR(x) do { if (!rc && (x) != hipSuccess) rc = GTSG_EHIP; } while (0)
+  FR(hipStreamCreate(&st));
+  FR(hipMalloc((void **)&d_text, len + 16));
+  FR(hipMalloc((void **)&sums, nblocks * sizeof(FaSum)));
+  FR(hipMalloc((void **)&carry, nblocks)); FR(hipMalloc((void **)&base, nblocks * 8));
+  FR(hipMalloc((void **)&d_n, 8));
+  if (!rc) {
+    FR(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, st));
+    k_fa_summary<<<(uint32_t)nblocks, FA_THREADS, 0, st>>>(d_text, len, sums);
+    k_fa_chain<<<1, 1, 0, st>>>(sums, nblocks, carry, base, d_n);
+    FR(hipMemcpyAsync(&nrec, d_n, 8, hipMemcpyDeviceToHost, st));
+    FR(hipStreamSynchronize(st));
+    FR(hipGetLastError());
+  }
+  if (!rc && nrec) {
+    FR(hipMalloc((void **)&hs, nrec * 8)); FR(hipMalloc((void **)&he, nrec * 8)); FR(hipMalloc((void **)&sl, nrec * 8));
+    if (!rc) {
+      FR(hipMemsetAsync(sl, 0, nrec * 8, st));
+      FR(hipMemsetAsync(he, 0xFF, nrec * 8, st));
+      k_fa_records<<<(uint32_t)nblocks, FA_THREADS, 0, st>>>(d_text, len, carry, base, hs, he,
+                                                            (unsigned long long *)sl);
+      *desc_start = (uint64_t *)malloc(nrec * 8); *desc_end = (uint64_t *)malloc(nrec * 8);
+      *seq_len = (uint64_t *)malloc(nrec * 8);
+      if (!*desc_start || !*desc_end || !*seq_len) rc = GTSG_ENOMEM;
+      if (!rc) {
+        FR(hipMemcpyAsync(*desc_start, hs, nrec * 8, hipMemcpyDeviceToHost, st));
+        FR(hipMemcpyAsync(*desc_end, he, nrec * 8, hipMemcpyDeviceToHost, st));
+        FR(hipMemcpyAsync(*seq_len, sl, nrec * 8, hipMemcpyDeviceToHost, st));
+      }
+      FR(hipStreamSynchronize(st));
+      FR(hipGetLastError());
+      if (!rc)
+        for (uint64_t i = 0; i < nrec; ++i)
+          if ((*desc_end)[i] == ~0ull) (*desc_end)[i] = len;   /* the file ends inside the description */
+    }
+  }
+#undef FR
+  void *ptrs[] = {d_text, sums, carry, base, d_n, hs, he, sl};
+  for (void *q : ptrs) if (q) hipFree(q);
+  if (st) hipStreamDestroy(st);
+  if (rc) { free(*desc_start); free(*desc_end); free(*seq_len); *desc_start = *desc_end = *seq_len = nullptr; return rc; }
+  *n_records = nrec;
+  return 0;
 }
 
 /* the records of the last parse copied to host arrays (tests, bindings) */

@@ -180,6 +180,52 @@ static bool find_contig(const GtScaffolderGraph *g, const char *name, uint32_t *
   return false;
 }
 
+/* the records of a FASTA text: description [ds, de) (after the '>', up to the
+   newline) and the number of sequence characters (blanks and line ends do not
+   count), in file order */
+typedef struct { uint64_t n, *ds, *de, *sl; } FaTable;
+static void fa_free(FaTable *t) { free(t->ds); free(t->de); free(t->sl); memset(t, 0, sizeof *t); }
+
+static void fasta_table_host(const char *buf, size_t len, FaTable *t)
+{
+  size_t i = 0;
+  uint64_t cap = 0;
+  memset(t, 0, sizeof *t);
+  while (i < len && buf[i] == '>') {
+    size_t ds = ++i, de;
+    uint64_t slen = 0;
+    while (i < len && buf[i] != '\n') i++;
+    de = i;
+    if (i < len) i++;
+    while (i < len && buf[i] != '>') {
+      char c = buf[i++];
+      if (c != '\n' && c != '\r' && c != ' ') slen++;
+    }
+    if (t->n == cap) {
+      cap = cap ? 2 * cap : 1024;
+      t->ds = xrealloc(t->ds, cap * sizeof *t->ds);
+      t->de = xrealloc(t->de, cap * sizeof *t->de);
+      t->sl = xrealloc(t->sl, cap * sizeof *t->sl);
+    }
+    t->ds[t->n] = ds; t->de[t->n] = de; t->sl[t->n] = slen;
+    t->n++;
+  }
+}
+
+static int g_host_parser;   /* set by gt_scaffolder_set_distance_parser, below */
+
+/* the same table from the GPU (gtsg_fasta_records) for large files */
+#define GPU_FASTA_MIN (32u << 20)
+static void fasta_table(const char *buf, size_t len, FaTable *t)
+{
+  if (len >= GPU_FASTA_MIN && g_host_parser != 1) {
+    memset(t, 0, sizeof *t);
+    if (gtsg_fasta_records(g_device, buf, len, &t->n, &t->ds, &t->de, &t->sl) == 0) return;
+    memset(t, 0, sizeof *t);   /* no GPU, or the file is above its limits: the host loop */
+  }
+  fasta_table_host(buf, len, t);
+}
+
 /* FASTA: '>' description newline, then sequence characters up to the next
    '>' (blanks and line ends do not count).  With a graph: keeps contigs longer
    than min_ctg_len (ref parser.c:481), header cut at the first blank
@@ -189,27 +235,22 @@ static bool find_contig(const GtScaffolderGraph *g, const char *name, uint32_t *
 static int scan_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len,
                         bool annotated, uint64_t *count, char *err, size_t errlen)
 {
-  size_t len, i = 0;
+  size_t len;
   char *buf = slurp(path, &len);
-  uint64_t cap = g ? g->max_nof_vertices : 0;
+  uint64_t cap = g ? g->max_nof_vertices : 0, r;
+  FaTable t;
   if (!buf) return seterr(err, errlen, "cannot open file %s", path);
   if (len == 0) { free(buf); return seterr(err, errlen, "sequence file %s is empty", path); }
   if (buf[0] != '>') {
     free(buf);
     return seterr(err, errlen, "the first character of fasta file %s has to be '>'", path);
   }
-  while (i < len && buf[i] == '>') {
-    size_t ds = ++i, de;
-    uint64_t slen = 0;
+  fasta_table(buf, len, &t);
+  for (r = 0; r < t.n; r++) {
+    size_t ds = t.ds[r], de = t.de[r];
+    uint64_t slen = t.sl[r];
     float astat = 0.0f, copynum = 0.0f;
-    while (i < len && buf[i] != '\n') i++;
-    de = i;
     if (de > ds && buf[de - 1] == '\r') de--;
-    if (i < len) i++;
-    while (i < len && buf[i] != '>') {
-      char c = buf[i++];
-      if (c != '\n' && c != '\r' && c != ' ') slen++;
-    }
     {
       char save = buf[de];
       char *desc = buf + ds, *sp;
@@ -219,12 +260,12 @@ static int scan_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len
         long n1, n2;
         if (sscanf(desc, "%1023s length=%ld depth=%ld k=%f astat=%f", part, &n1, &n2,
                    &copynum, &astat) != 5) {
-          free(buf);
+          free(buf); fa_free(&t);
           return seterr(err, errlen, "No A-statistic/copy number was found in header");
         }
       }
-      if (g && de == ds) { free(buf); return seterr(err, errlen, "Invalid header length"); }
-      if (slen == 0) { free(buf); return seterr(err, errlen, "Invalid sequence length"); }
+      if (g && de == ds) { free(buf); fa_free(&t); return seterr(err, errlen, "Invalid header length"); }
+      if (slen == 0) { free(buf); fa_free(&t); return seterr(err, errlen, "Invalid sequence length"); }
       sp = strchr(desc, ' ');
       if (sp) *sp = '\0';
       if (!g) {
@@ -246,15 +287,13 @@ static int scan_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len
       buf[de] = save;
     }
   }
-  free(buf);
+  free(buf); fa_free(&t);
   if (g) {
     g->max_nof_vertices = cap;
     g->sorted = false;
   }
   return 0;
 }
-
-static int g_host_parser;   /* set by gt_scaffolder_set_distance_parser, below */
 
 /* vertex ids = rank of the header, ref parser.c:172.  Many headers: the first
    14 bytes are sorted on the GPU (gtsg_sort_names, two radix sorts), runs that

@@ -23,7 +23,7 @@ SYMBOLS = [
     "gtsg_route_pack", "gtsg_route_unpack", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
     "gtsg_deparser_create", "gtsg_deparser_destroy", "gtsg_deparser_last_error", "gtsg_deparser_set_names",
     "gtsg_deparser_parse", "gtsg_deparser_records", "gtsg_deparser_download", "gtsg_deparser_parse_astat",
-    "gtsg_deparser_trim", "gtsg_sort_names",
+    "gtsg_deparser_trim", "gtsg_sort_names", "gtsg_fasta_records",
 ]
 
 
@@ -142,12 +142,31 @@ def lib():
         L.gtsg_deparser_parse_astat.argtypes = [vp, vp, u64, ci, vp, vp, ci, C.POINTER(DeParseResult)]
         L.gtsg_deparser_trim.argtypes = [vp]
         L.gtsg_sort_names.argtypes = [ci, vp, vp, u64, vp, vp]
+        L.gtsg_fasta_records.argtypes = [ci, vp, u64, C.POINTER(u64)] + [C.POINTER(C.POINTER(u64))] * 3
         _LIB = L
     return _LIB
 
 
 class EngineError(RuntimeError):
     pass
+
+
+def fasta_records(text, device=0):
+    """record table of a FASTA text on the GPU (gtsg_fasta_records):
+    (desc_start, desc_end, seq_len) numpy arrays, one entry per record"""
+    L = lib()
+    n = C.c_uint64()
+    ptrs = [C.POINTER(C.c_uint64)() for _ in range(3)]
+    rc = L.gtsg_fasta_records(device, bytes(text), len(text), C.byref(n), *[C.byref(p) for p in ptrs])
+    if rc != 0:
+        raise EngineError("gtsg_fasta_records failed (code %d)" % rc)
+    out = [np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64) for p in ptrs]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for p in ptrs:
+        if n.value:
+            libc.free(C.cast(p, C.c_void_p))
+    return out
 
 
 def sort_names(names, device=0):

@@ -240,6 +240,15 @@ int gtsg_deparser_parse_astat(GtsgDeParser *p, const char *text, uint64_t len, i
                               GtsgDeParseResult *res);
 /* frees the text and the records of the last parse; the name table stays */
 void gtsg_deparser_trim(GtsgDeParser *p);
+/* FASTA record table (ref parser.c:399-494, the description / sequence-length
+   callbacks of the reference's two passes over the contig file): for every
+   record in file order the offsets of its description (after the '>' up to its
+   newline, `len` if the file ends first) and the number of sequence characters
+   (everything up to the next record start but newline, carriage return and
+   blank; a record starts at the first '>' since the last newline).  The three
+   arrays are malloc'ed by the call, the caller frees them. */
+int gtsg_fasta_records(int device, const char *text, uint64_t len, uint64_t *n_records,
+                       uint64_t **desc_start, uint64_t **desc_end, uint64_t **seq_len);
 /* Contig headers into strcmp order (ref parser.c:172, the qsort that makes the
    vertex ids): perm[j] = index of the j-th name by its first 14 bytes, tie[j]
    != 0 where name perm[j] agrees with name perm[j-1] in those bytes -- the caller

@@ -355,3 +355,61 @@ def test_contig_headers_sorted_on_the_gpu():
         i = j
     assert got == sorted(names)
     assert int(tie.sum()) >= 50
+
+
+def fasta_table_by_hand(text):
+    """the record table as the reference's callbacks see the file (a '>' starts
+    a record unless it is in a description; blanks and line ends do not count)"""
+    ds, de, sl = [], [], []
+    i, n = 0, len(text)
+    while i < n and text[i:i + 1] == b">":
+        i += 1
+        ds.append(i)
+        j = text.find(b"\n", i)
+        j = n if j < 0 else j
+        de.append(j)
+        i = min(j + 1, n)
+        k = text.find(b">", i)
+        k = n if k < 0 else k
+        seq = text[i:k]
+        sl.append(len(seq) - seq.count(b"\n") - seq.count(b"\r") - seq.count(b" "))
+        i = k
+    return np.array(ds, np.uint64), np.array(de, np.uint64), np.array(sl, np.uint64)
+
+
+def test_fasta_record_table_on_the_gpu():
+    """lines of any length, '>' inside descriptions and in the middle of
+    sequence lines, CRLF, blanks, records of a few bytes and of megabytes,
+    a file that ends inside a description"""
+    rng = random.Random(13)
+    parts = []
+    for r in range(3000):
+        desc = b"ctg%d some text" % r + (b" with > inside" if rng.random() < 0.1 else b"")
+        L = rng.choice([0, 1, 5, 60, 61, 300, 5000, 70000]) if r % 50 else 3_000_000
+        seq = bytes(rng.choice(b"ACGT") for _ in range(min(L, 2000))) * (L // 2000 + 1)
+        seq = seq[:L]
+        w = rng.choice([60, 70, 10 ** 9])
+        eol = b"\r\n" if rng.random() < 0.2 else b"\n"
+        lines = [seq[k:k + w] for k in range(0, len(seq), w)]
+        if rng.random() < 0.1 and lines:
+            lines[0] = lines[0][:3] + b" " + lines[0][3:]
+        body = eol.join(lines) + (eol if rng.random() < 0.9 else b"")   # the next '>' may follow sequence bytes directly
+        parts.append(b">" + desc + eol + body)
+    text = b"".join(parts)
+    for t in (text, text + b">last record without newline"):
+        exp = fasta_table_by_hand(t)
+        got = engine.fasta_records(t)
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b)
+    assert len(text) > 60_000_000
+
+
+def test_file_api_with_the_gpu_fasta_scan(tmp_path):
+    """a contig file large enough for the GPU scan (and the GPU sort of the
+    headers): the graph is the one the host scan gives"""
+    from helpers import make_inputs
+    g = make_inputs(60000, 91)
+    pkg.synth.write_files(g, str(tmp_path / "syn"))
+    fa, de = str(tmp_path / "syn.fa"), str(tmp_path / "syn.de")
+    assert os.path.getsize(fa) > (32 << 20)
+    same_edges(graph_arrays(fa, de, 0), graph_arrays(fa, de, 1))
