@@ -76,7 +76,6 @@ struct GtsgDeParser {
   uint8_t *flags, *valid;
   uint32_t *cand_cnt;               /* per stride, then its exclusive scan */
   uint32_t *scan_tmp;
-  uint32_t *pos;                    /* compaction */
   uint64_t cap_cand, cap_blocks;
   /* compacted copies (only when a candidate is not a record) */
   uint32_t *root2, *ctg2;
@@ -713,10 +712,10 @@ int gtsg_deparser_create(GtsgDeParser **out, int device, void *stream)
 
 static void dp_free_parse(GtsgDeParser *p)
 {
-  void *ptrs[] = {p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->valid, p->cand_cnt, p->scan_tmp, p->pos,
+  void *ptrs[] = {p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->valid, p->cand_cnt, p->scan_tmp,
                   p->root2, p->ctg2, p->dist2, p->np2, p->sd2, p->flags2};
   for (void *q : ptrs) if (q) hipFree(q);
-  p->root = p->ctg = p->root2 = p->ctg2 = p->cand_cnt = p->scan_tmp = p->pos = nullptr;
+  p->root = p->ctg = p->root2 = p->ctg2 = p->cand_cnt = p->scan_tmp = nullptr;
   p->dist = p->np = p->dist2 = p->np2 = nullptr;
   p->sd = p->sd2 = nullptr;
   p->flags = p->valid = p->flags2 = nullptr;
@@ -835,9 +834,9 @@ int gtsg_deparser_parse(GtsgDeParser *p, const char *text, uint64_t len, int on_
   if (h[1]) { res->irregular = 1; return 0; }
   if (ncand >= (1ull << 31)) return dp_fail(p, GTSG_ELIMIT, "2^31 records or more in the distance file");
   if (p->cap_cand < ncand + 1) {
-    void *ptrs[] = {p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->valid, p->pos};
+    void *ptrs[] = {p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->valid};
     for (void *q : ptrs) if (q) hipFree(q);
-    p->root = p->ctg = p->pos = nullptr; p->dist = p->np = nullptr; p->sd = nullptr; p->flags = p->valid = nullptr;
+    p->root = p->ctg = nullptr; p->dist = p->np = nullptr; p->sd = nullptr; p->flags = p->valid = nullptr;
     p->cap_cand = 0;
     const uint64_t c = ncand + 1;
     DPCHK(hipMalloc((void **)&p->root, c * 4)); DPCHK(hipMalloc((void **)&p->ctg, c * 4));
