@@ -2747,6 +2747,18 @@ int gtsg_get_edges(GtsgEngine *e, uint32_t *start, uint32_t *end, int64_t *dist,
   return sync_stream(e);
 }
 
+/* adjacency lists as the reference keeps them: row[v] .. row[v + 1] index adj[],
+   adj[] holds the edge ids of vertex v in creation order */
+int gtsg_get_csr(GtsgEngine *e, uint32_t *row, uint32_t *adj)
+{
+  if (!e || !row || !adj) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->row) return fail(e, GTSG_EINVAL, "no graph has been built");
+  HIPCHK(hipMemcpyAsync(row, e->row, ((size_t)e->n + 1) * 4, hipMemcpyDeviceToHost, e->st));
+  if (e->m) HIPCHK(hipMemcpyAsync(adj, e->eid, (size_t)e->m * 4, hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+
 int gtsg_state_digest(GtsgEngine *e, uint64_t *vd, uint64_t *ed)
 {
   if (!e || !vd || !ed) return GTSG_EINVAL;

@@ -971,9 +971,21 @@ gt_scaffolder_graph_iterate_scaffolds(GtScaffolderGraph *g, uint64_t **scaf_seql
   row = xcalloc(n + 1, sizeof *row);
   adj = xcalloc(m, sizeof *adj);
   fill = xcalloc(n, sizeof *fill);
-  for (k = 0; k < m; k++) row[g->edges[k].start + 1]++;
-  for (v = 0; v < n; v++) row[v + 1] += row[v];
-  for (k = 0; k < m; k++) { uint32_t s = g->edges[k].start; adj[row[s] + fill[s]++] = k; }
+  if (g->eng) {
+    /* the engine's lists are the reference's: edge ids per vertex in creation order */
+    uint32_t *row32 = xcalloc(n + 1, sizeof *row32), *adj32 = xcalloc(m, sizeof *adj32);
+    if (gtsg_get_csr(g->eng, row32, adj32) != 0) {
+      free(row32); free(adj32); free(row); free(adj); free(fill); free(r);
+      return NULL;
+    }
+    for (v = 0; v <= n; v++) row[v] = row32[v];
+    for (k = 0; k < m; k++) adj[k] = adj32[k];
+    free(row32); free(adj32);
+  } else {
+    for (k = 0; k < m; k++) row[g->edges[k].start + 1]++;
+    for (v = 0; v < n; v++) row[v + 1] += row[v];
+    for (k = 0; k < m; k++) { uint32_t s = g->edges[k].start; adj[row[s] + fill[s]++] = k; }
+  }
   vs = g->vstate;
   for (v = 0; v < n; v++)
     if (!v_marked(vs[v]) && vs[v] != 6) vs[v] = 0;

@@ -17,7 +17,7 @@ SYMBOLS = [
     "gtsg_create", "gtsg_destroy", "gtsg_last_error", "gtsg_set_contigs",
     "gtsg_build_from_records", "gtsg_build_from_records_ex", "gtsg_set_vertex_times", "gtsg_set_astat", "gtsg_mark_repeats", "gtsg_filter",
     "gtsg_removecycles", "gtsg_makescaffold", "gtsg_num_vertices", "gtsg_num_edges",
-    "gtsg_get_vertex_states", "gtsg_get_edge_states", "gtsg_get_edges", "gtsg_state_digest",
+    "gtsg_get_vertex_states", "gtsg_get_edge_states", "gtsg_get_edges", "gtsg_get_csr", "gtsg_state_digest",
     "gtsg_set_option", "gtsg_selftest_ambiguous", "gtsg_filter_begin", "gtsg_filter_end",
     "gtsg_filter_get_lasthit", "gtsg_filter_set_lasthit", "gtsg_label_components",
     "gtsg_route_pack", "gtsg_route_unpack", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
@@ -91,6 +91,7 @@ def lib():
         L.gtsg_get_vertex_states.argtypes = [vp, vp]
         L.gtsg_get_edge_states.argtypes = [vp, vp]
         L.gtsg_get_edges.argtypes = [vp] + [vp] * 6
+        L.gtsg_get_csr.argtypes = [vp, vp, vp]
         L.gtsg_state_digest.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.gtsg_selftest_ambiguous.argtypes = [vp, u64, vp, vp, vp, vp, f32, vp]
         L.gtsg_set_option.argtypes = [vp, C.c_char_p, i64]

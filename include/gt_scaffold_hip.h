@@ -155,6 +155,10 @@ int gtsg_get_vertex_states(GtsgEngine *e, uint8_t *out);
 int gtsg_get_edge_states(GtsgEngine *e, uint8_t *out);
 int gtsg_get_edges(GtsgEngine *e, uint32_t *start, uint32_t *end, int64_t *dist,
                    float *std_dev, int64_t *num_pairs, uint8_t *flags);
+/* the adjacency lists: row has num_vertices + 1 offsets into adj, adj holds the
+   edge ids of a vertex in creation order (the order of the reference's
+   vertex->edges array, graph.c:137-160) */
+int gtsg_get_csr(GtsgEngine *e, uint32_t *row, uint32_t *adj);
 /* order-independent 64-bit digest of (vertex states, edge states by id),
    computed on the device: used to compare full-size runs */
 int gtsg_state_digest(GtsgEngine *e, uint64_t *vertex_digest,
