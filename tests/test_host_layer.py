@@ -35,6 +35,20 @@ def test_no_gpu_means_loud_failure(golden_dir):
         engine.ScaffolderGraph.from_files(golden_dir + "/primary-contigs.fa", golden_dir + "/libPE.de")
 
 
+def test_gpu_steps_of_the_file_api_fail_cleanly_without_a_gpu():
+    """header sort, FASTA record table and the distance parser report an error
+    (the host layer then runs its own code) instead of crashing"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(engine.EngineError):
+        engine.sort_names([b"b", b"a"])
+    with pytest.raises(engine.EngineError):
+        engine.fasta_records(b">a\nACGT\n")
+    with pytest.raises(engine.EngineError):
+        engine.DeParser([b"a", b"b"])
+
+
 def test_graph_module_toy_graph(tmp_path, golden_dir):
     # ref testsuite/scaffolder_include.rb:1-56 (exit status 2 = failed assertion)
     L = engine.lib()
