@@ -85,6 +85,13 @@ struct GtsgDeParser {
   uint64_t cap2;
   bool compacted;
   uint64_t n_records;
+  /* records of several parses back to back (a file in pieces) */
+  bool accumulate;
+  uint32_t *a_root, *a_ctg;
+  int64_t *a_dist, *a_np;
+  float *a_sd;
+  uint8_t *a_flags;
+  uint64_t a_n, a_cap;
   unsigned long long *d_res;        /* [0] first error, [1] irregular, [2] valid, [3] candidates */
   char err[256];
 };
@@ -710,6 +717,14 @@ int gtsg_deparser_create(GtsgDeParser **out, int device, void *stream)
   return 0;
 }
 
+static void dp_free_acc(GtsgDeParser *p)
+{
+  void *ptrs[] = {p->a_root, p->a_ctg, p->a_dist, p->a_np, p->a_sd, p->a_flags};
+  for (void *q : ptrs) if (q) hipFree(q);
+  p->a_root = p->a_ctg = nullptr; p->a_dist = p->a_np = nullptr; p->a_sd = nullptr; p->a_flags = nullptr;
+  p->a_n = p->a_cap = 0;
+}
+
 static void dp_free_parse(GtsgDeParser *p)
 {
   void *ptrs[] = {p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->valid, p->cand_cnt, p->scan_tmp,
@@ -727,6 +742,7 @@ void gtsg_deparser_destroy(GtsgDeParser *p)
   if (!p) return;
   hipSetDevice(p->device);
   dp_free_parse(p);
+  dp_free_acc(p);
   if (p->names) hipFree(p->names);
   if (p->name_off) hipFree(p->name_off);
   if (p->table) hipFree(p->table);
@@ -738,10 +754,25 @@ void gtsg_deparser_destroy(GtsgDeParser *p)
 
 const char *gtsg_deparser_last_error(const GtsgDeParser *p) { return p ? p->err : "no parser"; }
 
+/* on != 0: from now on the records of every gtsg_deparser_parse are appended to
+   those of the parses before (a file handed over in pieces that end at line
+   ends); gtsg_deparser_records then returns all of them.  on == 0: back to
+   "the last parse", the collected records are dropped. */
+int gtsg_deparser_accumulate(GtsgDeParser *p, int on)
+{
+  if (!p) return GTSG_EINVAL;
+  hipSetDevice(p->device);
+  dp_free_acc(p);
+  p->accumulate = on != 0;
+  return 0;
+}
+
 void gtsg_deparser_trim(GtsgDeParser *p)
 {
   if (!p) return;
   hipSetDevice(p->device);
+  dp_free_acc(p);
+  p->accumulate = false;
   dp_free_parse(p);
   if (p->text) hipFree(p->text);
   p->text = nullptr; p->text_cap = 0;
@@ -890,6 +921,39 @@ int gtsg_deparser_parse(GtsgDeParser *p, const char *text, uint64_t len, int on_
     DPCHK(hipGetLastError());
     p->compacted = true;
   }
+  if (p->accumulate && nvalid) {
+    const uint64_t need = p->a_n + nvalid;
+    if (need > p->a_cap) {
+      uint64_t cap = p->a_cap ? p->a_cap : 1u << 20;
+      while (cap < need) cap *= 2;
+      uint32_t *r2 = nullptr, *c2 = nullptr; int64_t *d2 = nullptr, *n2 = nullptr; float *s2 = nullptr; uint8_t *f2 = nullptr;
+      DPCHK(hipMalloc((void **)&r2, cap * 4)); DPCHK(hipMalloc((void **)&c2, cap * 4));
+      DPCHK(hipMalloc((void **)&d2, cap * 8)); DPCHK(hipMalloc((void **)&n2, cap * 8));
+      DPCHK(hipMalloc((void **)&s2, cap * 4)); DPCHK(hipMalloc((void **)&f2, cap));
+      if (p->a_n) {
+        DPCHK(hipMemcpyAsync(r2, p->a_root, p->a_n * 4, hipMemcpyDeviceToDevice, p->st));
+        DPCHK(hipMemcpyAsync(c2, p->a_ctg, p->a_n * 4, hipMemcpyDeviceToDevice, p->st));
+        DPCHK(hipMemcpyAsync(d2, p->a_dist, p->a_n * 8, hipMemcpyDeviceToDevice, p->st));
+        DPCHK(hipMemcpyAsync(n2, p->a_np, p->a_n * 8, hipMemcpyDeviceToDevice, p->st));
+        DPCHK(hipMemcpyAsync(s2, p->a_sd, p->a_n * 4, hipMemcpyDeviceToDevice, p->st));
+        DPCHK(hipMemcpyAsync(f2, p->a_flags, p->a_n, hipMemcpyDeviceToDevice, p->st));
+        DPCHK(hipStreamSynchronize(p->st));
+      }
+      const uint64_t keep = p->a_n;
+      dp_free_acc(p);
+      p->a_root = r2; p->a_ctg = c2; p->a_dist = d2; p->a_np = n2; p->a_sd = s2; p->a_flags = f2;
+      p->a_n = keep; p->a_cap = cap;
+    }
+    const bool c = p->compacted;
+    DPCHK(hipMemcpyAsync(p->a_root + p->a_n, c ? p->root2 : p->root, nvalid * 4, hipMemcpyDeviceToDevice, p->st));
+    DPCHK(hipMemcpyAsync(p->a_ctg + p->a_n, c ? p->ctg2 : p->ctg, nvalid * 4, hipMemcpyDeviceToDevice, p->st));
+    DPCHK(hipMemcpyAsync(p->a_dist + p->a_n, c ? p->dist2 : p->dist, nvalid * 8, hipMemcpyDeviceToDevice, p->st));
+    DPCHK(hipMemcpyAsync(p->a_np + p->a_n, c ? p->np2 : p->np, nvalid * 8, hipMemcpyDeviceToDevice, p->st));
+    DPCHK(hipMemcpyAsync(p->a_sd + p->a_n, c ? p->sd2 : p->sd, nvalid * 4, hipMemcpyDeviceToDevice, p->st));
+    DPCHK(hipMemcpyAsync(p->a_flags + p->a_n, c ? p->flags2 : p->flags, nvalid, hipMemcpyDeviceToDevice, p->st));
+    DPCHK(hipStreamSynchronize(p->st));
+    p->a_n += nvalid;
+  }
   return 0;
 }
 
@@ -898,6 +962,16 @@ int gtsg_deparser_records(const GtsgDeParser *p, uint64_t *n, const uint32_t **r
                           const uint8_t **flags)
 {
   if (!p || !n) return GTSG_EINVAL;
+  if (p->accumulate) {
+    *n = p->a_n;
+    if (root) *root = p->a_root;
+    if (ctg) *ctg = p->a_ctg;
+    if (dist) *dist = p->a_dist;
+    if (std_dev) *std_dev = p->a_sd;
+    if (num_pairs) *num_pairs = p->a_np;
+    if (flags) *flags = p->a_flags;
+    return 0;
+  }
   *n = p->n_records;
   const bool c = p->compacted;
   if (root) *root = c ? p->root2 : p->root;

@@ -532,7 +532,33 @@ static int gpu_parse_distances(GtScaffolderGraph *g, const char *path, GtsgDePar
   if (!have) return 0;
   buf = slurp(path, &len);
   if (!buf) return seterr(err, errlen, "can not read distance file %s", path);
-  rc = gtsg_deparser_parse(g->dp, buf, len, 0, res);
+  {
+    /* the parser takes less than 4 GB at a time: a larger file goes over in
+       pieces that end at line ends, the records are collected on the device
+       (GTS_DE_CHUNK, bytes: a smaller piece size, for tests) */
+    size_t chunk = (size_t)3 << 30, start = 0;
+    const char *env = getenv("GTS_DE_CHUNK");
+    uint64_t total = 0, cand = 0;
+    if (env && atol(env) > 0) chunk = (size_t)atol(env);
+    memset(res, 0, sizeof *res);
+    rc = gtsg_deparser_accumulate(g->dp, len > chunk);
+    while (!rc && start < len) {
+      size_t end = len - start > chunk ? start + chunk : len;
+      GtsgDeParseResult part;
+      if (end < len) {                       /* up to and including the next newline */
+        const char *nl = memchr(buf + end, '\n', len - end);
+        end = nl ? (size_t)(nl - buf) + 1 : len;
+      }
+      rc = gtsg_deparser_parse(g->dp, buf + start, end - start, 0, &part);
+      if (rc) break;
+      total += part.n_records; cand += part.n_candidates;
+      if (part.irregular) { res->irregular = 1; break; }
+      if (part.error) { res->error = part.error; res->error_pos = start + part.error_pos; break; }
+      start = end;
+    }
+    res->n_records = total; res->n_candidates = cand;
+    if (len == 0 && !rc) rc = gtsg_deparser_parse(g->dp, buf, 0, 0, res);
+  }
   free(buf);
   if (rc == GTSG_ELIMIT && g_host_parser != 2) return 0;
   if (rc) return seterr(err, errlen, "distance parser: %s", gtsg_deparser_last_error(g->dp));

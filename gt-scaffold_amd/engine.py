@@ -23,7 +23,7 @@ SYMBOLS = [
     "gtsg_route_pack", "gtsg_route_unpack", "gtsg_get_kernel_times", "gtsg_reset_kernel_times", "gtsg_get_stat",
     "gtsg_deparser_create", "gtsg_deparser_destroy", "gtsg_deparser_last_error", "gtsg_deparser_set_names",
     "gtsg_deparser_parse", "gtsg_deparser_records", "gtsg_deparser_download", "gtsg_deparser_parse_astat",
-    "gtsg_deparser_trim", "gtsg_sort_names", "gtsg_fasta_records",
+    "gtsg_deparser_trim", "gtsg_sort_names", "gtsg_fasta_records", "gtsg_deparser_accumulate",
 ]
 
 
@@ -142,6 +142,7 @@ def lib():
         L.gtsg_deparser_download.argtypes = [vp] + [vp] * 6
         L.gtsg_deparser_parse_astat.argtypes = [vp, vp, u64, ci, vp, vp, ci, C.POINTER(DeParseResult)]
         L.gtsg_deparser_trim.argtypes = [vp]
+        L.gtsg_deparser_accumulate.argtypes = [vp, ci]
         L.gtsg_sort_names.argtypes = [ci, vp, vp, u64, vp, vp]
         L.gtsg_fasta_records.argtypes = [ci, vp, u64, C.POINTER(u64)] + [C.POINTER(C.POINTER(u64))] * 3
         _LIB = L

@@ -242,6 +242,10 @@ int gtsg_deparser_download(GtsgDeParser *p, uint32_t *root, uint32_t *ctg, int64
 int gtsg_deparser_parse_astat(GtsgDeParser *p, const char *text, uint64_t len, int on_device,
                               float *astat, float *copy_num, int arrays_on_device,
                               GtsgDeParseResult *res);
+/* on != 0: the records of every later parse are appended to those before (a
+   file of 4 GB or more handed over in pieces that end at line ends), `records`
+   returns all of them; on == 0: back to "the last parse" */
+int gtsg_deparser_accumulate(GtsgDeParser *p, int on);
 /* frees the text and the records of the last parse; the name table stays */
 void gtsg_deparser_trim(GtsgDeParser *p);
 /* FASTA record table (ref parser.c:399-494, the description / sequence-length

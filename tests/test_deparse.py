@@ -413,3 +413,19 @@ def test_file_api_with_the_gpu_fasta_scan(tmp_path):
     fa, de = str(tmp_path / "syn.fa"), str(tmp_path / "syn.de")
     assert os.path.getsize(fa) > (32 << 20)
     same_edges(graph_arrays(fa, de, 0), graph_arrays(fa, de, 1))
+
+
+def test_distance_file_in_pieces(tmp_path, monkeypatch):
+    """a file above the parser's 4 GB goes over in pieces that end at line ends
+    and the records are collected on the device; here with pieces of 1 MB"""
+    from helpers import make_inputs
+    g = make_inputs(60000, 92)
+    pkg.synth.write_files(g, str(tmp_path / "syn"))
+    fa, de = str(tmp_path / "syn.fa"), str(tmp_path / "syn.de")
+    assert os.path.getsize(de) > (8 << 20)
+    whole = graph_arrays(fa, de, 2)
+    monkeypatch.setenv("GTS_DE_CHUNK", str(1 << 20))
+    pieces = graph_arrays(fa, de, 2)
+    monkeypatch.delenv("GTS_DE_CHUNK")
+    same_edges(pieces, whole)
+    same_edges(pieces, graph_arrays(fa, de, 1))
