@@ -45,7 +45,7 @@
 #include "gts_defs.h"
 
 enum { GTS_MODE_REMOVECYCLES = 0, GTS_MODE_MAKESCAFFOLD = 1 };
-enum { GTS_CERR_NONE = 0, GTS_CERR_WALKQ_OVERFLOW = 1, GTS_CERR_WALK_LOOP = 2 };
+enum { GTS_CERR_NONE = 0, GTS_CERR_WALKQ_OVERFLOW = 1, GTS_CERR_WALK_LOOP = 2, GTS_CERR_PATH_OVERFLOW = 3 };
 
 struct GtsCompView {
   GtsGraphView G;            /* global graph (marks are mirrored there) */
@@ -79,6 +79,7 @@ struct GtsCompView {
   uint64_t max_pops;         /* bound on queue pops of one walk */
   /* linear-time walk (create_walk_fast) */
   int fast_walks;            /* 0: always run the reference's search */
+  int batch_walks;           /* LDS-resident clean components: the walks of a cc side by side */
   int64_t *nd;               /* slot -> integer label pushed with the node */
   uint64_t *plen;            /* slot -> contig length of the tree path */
   uint8_t *tight;            /* slot -> number of tight in-arcs (saturating) */
@@ -93,6 +94,14 @@ struct GtsCompView {
   uint32_t defer_min_nv;     /* 0: never defer */
   uint64_t defer_min_work;   /* defer only if terminals x contigs reaches this: the walks of a
                                 component cost about that many vertex steps when made in place */
+  uint32_t defer_ref_min_nv; /* 0: never.  A component of at least this many contigs that meets a walk
+                                the linear-time walks cannot make (it needs the reference's search,
+                                which can take 10^5 .. 10^6 queue pops) stops there and hands the
+                                walks of the ccs it has not decided yet to tasks: the walks of a cc
+                                are independent (ref algorithms.c:809-832), each task replays the
+                                search on a wavefront of its own with a ring of its own */
+  int task_reference;        /* walk tasks replay the reference's search themselves (else select_walks
+                                does, one after the other) */
   uint8_t *defer_flag;       /* ncomp */
   uint32_t *comp_task0, *comp_ncc, *comp_nterm;   /* ncomp */
   unsigned long long *ntasks, *path_used;         /* device counters */
@@ -244,6 +253,12 @@ struct GtsCompMemT {
   GTS_P(uint8_t) gorient;
   GTS_P(idx_t) topo;
   GTS_P(idx_t) tpos;
+  /* packed LDS layout only: the walk scratch (distmap ... st_par) is one
+     contiguous region that the batched clean walks re-view as `wslots` walk
+     slots of gts_walk_slot_bytes(nv) each (walks_clean_batch); slot 0 starts
+     with distmap.  0 slots: no batched walks (global arrays). */
+  GTS_P(char) wbase;
+  uint32_t wslots;
 };
 typedef GtsCompMemT<false> GtsCompMem;
 
@@ -256,14 +271,45 @@ GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
   b += (((nv + 1) * 2 + a - 1) / a) * a * 2;          /* coff, ccoff */
   /* scratch that is never live at the same time shares storage: st_cur (cycle
      search) with cc_best (walks), touched (reference search) with visited,
-     lastpop (reference search, zeroed on entry) with nd (linear walks) */
-  b += ((nv * 2 + a - 1) / a) * a * 11;               /* queue .. cc_best, par, topo, tpos */
-  b += ((nv * 4 + a - 1) / a) * a * 4;                /* distmap, cseq, nd, plen */
+     lastpop (reference search, zeroed on entry) with nd (linear walks).
+     The walk scratch -- distmap, plen, edgemap, par | nd, queue, visited,
+     st_v, wterm, st_par -- comes last and in one piece: two walk slots
+     (gts_walk_slot_bytes), more if the launcher has room behind it */
+  b += ((nv * 2 + a - 1) / a) * a * 11;               /* term, cc_best, topo, tpos | edgemap, par, queue, visited, st_v, wterm, st_par */
+  b += ((nv * 4 + a - 1) / a) * a * 4;                /* cseq | distmap, plen, nd */
   b += ((nv + a - 1) / a) * a * 4;                    /* vst, st_dir, tight, gorient */
   b += ((ne * 2 + a - 1) / a) * a;                    /* cend */
   b += ((ne * 4 + a - 1) / a) * a;                    /* cdist */
   b += ((ne + a - 1) / a) * a;                        /* flags + state */
   return b;
+}
+/* One walk slot of the batched clean walks: label (f32), tree-path length
+   (u32), edgemap and parent (u16) per contig.  The scratch region of the
+   layout above (3 arrays of 4 bytes, 7 of 2 bytes per contig) holds two. */
+GTS_HD uint32_t gts_walk_slot_bytes(uint32_t nv)
+{
+  const uint32_t p4 = ((nv * 4 + 15) / 16) * 16, p2 = ((nv * 2 + 15) / 16) * 16;
+  return 2 * p4 + 2 * p2;
+}
+#define GTS_WALK_SLOTS_MAX 8u
+#define GTS_WALK_LANES 8u   /* lanes of a walk in a batch: 8 walks per wavefront */
+/* LDS bytes a component asks for: its footprint plus, from `big_nv` contigs
+   on, room for up to `big_slots` walk slots (as many as fit `limit`): the
+   walks of a large component are the critical path of the launch, and a cc's
+   walks are independent (ref algorithms.c:809-832), so they are swept side by
+   side (walks_clean_batch).  Smaller components use what their last page has
+   left. */
+GTS_HD uint32_t gts_comp_lds_want(uint32_t nv, uint32_t ne, uint32_t big_nv, uint32_t big_slots,
+                                  uint32_t limit)
+{
+  uint32_t need = gts_comp_lds_bytes(nv, ne);
+  if (big_nv && nv >= big_nv && need <= limit) {
+    const uint32_t sb = gts_walk_slot_bytes(nv);
+    uint32_t extra = big_slots > 2 ? big_slots - 2 : 0;
+    while (extra && need + extra * sb > limit) --extra;
+    need += extra * sb;
+  }
+  return need;
 }
 /* the packed layout addresses at most this many slots / edges */
 #define GTS_LDS_MAX_INDEX 65000u
@@ -290,13 +336,15 @@ struct GtsComponent {
   uint32_t *reach_bits; /* walk_task: bitmap of the vertices the walk labels */
   uint64_t ubases;      /* all_bases(), ~0 = not computed yet */
   uint32_t walk_from;   /* reference search: the walk's start vertex */
-  bool no_reference;    /* walk_task: leave a walk that needs the reference search to select_walks */
+  bool no_reference;    /* do not run the reference search in place: walk_task leaves it to
+                           select_walks (task_reference = 0), makescaffold hands it to a task */
   bool needs_reference;
+  bool deferred_late;   /* makescaffold stopped at a cc and published the rest as tasks */
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -315,6 +363,7 @@ struct GtsComponent {
     m.ccoff = C.ccoff + s0 + comp; m.st_dir = C.st_dir + s0; m.tight = C.tight + s0;
     m.distmap = C.distmap + s0; m.nd = C.nd + s0; m.plen = C.plen + s0;
     m.gorient = C.gorient + s0; m.topo = C.topo + s0; m.tpos = C.tpos + s0;
+    m.wbase = nullptr; m.wslots = 0;
     return m;
   }
 
@@ -661,16 +710,36 @@ struct GtsComponent {
      terminal `start`, evaluates the reached terminals and, if the best walk is
      longer than cc_len, stores it in cc_best (edge order as the reference:
      from the far terminal back to start).  Returns false on error. ---- */
+  /* The ring of the walk's FIFO is carved from the pool on first use (rings are
+     powers of two: positions are masked, not divided).  A walk that overflows
+     its ring leaves the maps clean, takes a ring eight times as large and
+     starts over; only when the pool has none left does the error reach the
+     host, which runs the whole call again with a larger pool. */
   GTS_HD bool create_walk_reference(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
-    const uint32_t lane = W::lane();
-    if (qcap == 0) {
-      uint64_t need = 64;   /* power of two: ring positions are masked, not divided */
-      while (need < C.wq_factor * (uint64_t)M.ne + 64) need <<= 1;
+    for (;;) {
+      if (qcap == 0) {
+        uint64_t need = 64;
+        while (need < C.wq_factor * (uint64_t)M.ne + 64) need <<= 1;
+        const uint64_t off = W::alloc(C.wq_used, need);
+        if (off + need > C.wq_pool) { err = GTS_CERR_WALKQ_OVERFLOW; return false; }
+        qbase = off; qcap = need;
+      }
+      const uint64_t len0 = cc_len;
+      const uint32_t n0 = cc_n;
+      if (create_walk_reference_once(start, cc_len, cc_n)) return true;
+      if (err != GTS_CERR_WALKQ_OVERFLOW) return false;
+      const uint64_t need = qcap * 8;
       const uint64_t off = W::alloc(C.wq_used, need);
-      if (off + need > C.wq_pool) { err = GTS_CERR_WALKQ_OVERFLOW; return false; }
-      qbase = off; qcap = need;
+      if (off + need > C.wq_pool) return false;
+      qbase = off; qcap = need; err = 0;
+      cc_len = len0; cc_n = n0;
     }
+  }
+
+  GTS_HD bool create_walk_reference_once(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
+  {
+    const uint32_t lane = W::lane();
     qh = 0; qn = 0; ntouch = 0;
     walk_from = start;
     uint32_t nwt = 0;
@@ -1611,6 +1680,192 @@ struct GtsComponent {
     return !bad;
   }
 
+
+  /* ---- the walks of one cc side by side (LDS-resident clean components) ----
+     The reference makes every walk of a cc before it marks anything
+     (algorithms.c:809-832), so they are independent.  On a clean component a
+     walk is one sweep over the topological order (create_walk_clean); here the
+     wavefront is split into groups of L lanes, group g sweeps for terminal
+     j0 + g with labels, tree lengths, edgemap and parents in walk slot g
+     (GtsCompMemT::wbase), all groups in lock step: an iteration looks at the
+     next L positions of a group's sweep or relaxes up to L arcs of its current
+     vertex, lane = (walk, arc).  The groups share the graph in LDS and nothing
+     else; the forward and the mirror sheet are swept at the same time.
+     A tie (two in-arcs attaining a label, two terminals with the longest
+     walk) or a start with live edges in both senses sets `bad`: the caller
+     then makes the walks of this cc one by one (create_walk), which resolves
+     them (pushed_after) or runs the reference's search.
+     Slots must be clean (labels unset) on entry; clear_walk_slots() after. */
+  template <uint32_t L>
+  GTS_HD void walks_clean_batch(uint32_t j0, uint32_t nb, uint32_t &r_len, uint32_t &r_t, bool &r_bad)
+  {
+    typedef typename GtsCompMemT<LDS>::idx_t idx_t;
+    const uint32_t lane = W::lane(), g = lane / L, a = lane % L;
+    const uint32_t gsh = g * L;
+    const uint64_t gm = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
+    const uint32_t p4 = ((nv * 4 + 15) / 16) * 16, p2 = ((nv * 2 + 15) / 16) * 16;
+    bool active = g < nb;
+    auto sbase = M.wbase + (active ? g : 0u) * (2 * p4 + 2 * p2);
+    auto dist = (GTS_P(float))sbase;
+    auto plen = (GTS_P(uint32_t))(sbase + p4);
+    auto emap = (GTS_P(idx_t))(sbase + 2 * p4);
+    auto par = (GTS_P(idx_t))(sbase + 2 * p4 + p2);
+    const uint32_t start = active ? (uint32_t)M.term[j0 + g] : 0u;
+    /* the start's live edges pick the sheet */
+    const uint32_t sb0 = M.coff[start], se0 = M.coff[start + 1];
+    bool hs = false, ha = false;
+    for (uint32_t cur0 = sb0; W::ballot(active && cur0 < se0); cur0 += L) {
+      const uint32_t ce = cur0 + a;
+      const bool in = active && ce < se0;
+      const uint32_t fs = edge_bits(in ? ce : sb0);
+      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+      const bool sense = (fs & GTS_F_SENSE) != 0;
+      const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
+      hs |= ((bs >> gsh) & gm) != 0;
+      ha |= ((ba >> gsh) & gm) != 0;
+    }
+    bool bad = active && hs && ha;
+    if (bad || !(hs || ha)) active = false;          /* (nothing reachable: empty walk) */
+    const bool forward = hs == ((M.gorient[start] & 3u) == 2);
+    const int32_t step = forward ? 1 : -1;
+    int32_t pos = (int32_t)M.tpos[start] + step;
+    /* the group's current vertex: the start first */
+    bool have_u = active, is_start = true;
+    uint32_t u = start, cur = sb0, ub = sb0, ue = se0;
+    bool du = hs, us = false, ua = false;
+    int32_t ndu = 0;
+    uint32_t plu = (uint32_t)M.cseq[start];
+    uint32_t pending = 0, best_len = 0, best_t = GTS_NONE;
+    while (W::ballot(active)) {
+      /* (1) the next labelled vertex in sweep order, L positions at a time */
+      const bool scan = active && !have_u;
+      const int32_t p = pos + (int32_t)a * step;
+      const bool inr = scan && p >= 0 && p < (int32_t)nv;
+      const uint32_t cv = M.topo[inr ? (uint32_t)p : 0u];
+      const float lbl = dist[cv];
+      const uint64_t rb = (W::ballot(inr && lbl != GTS_DIST_UNSET) >> gsh) & gm;
+      if (scan) {
+        if (rb) {
+          const uint32_t k = W::ctz(rb);
+          const int32_t p1 = pos + (int32_t)k * step;
+          u = M.topo[(uint32_t)p1];
+          pos = p1 + step;
+          have_u = true; is_start = false; us = ua = false;
+          --pending;
+          ub = cur = M.coff[u]; ue = M.coff[u + 1];
+          du = ((M.gorient[u] & 3u) == 2) == forward;
+          ndu = (int32_t)dist[u];                   /* the integer the reference pushes with the node */
+          plu = plen[u];
+        } else {
+          pos += (int32_t)L * step;
+          if (pos < 0 || pos >= (int32_t)nv) active = false;
+        }
+      }
+      /* (2) up to L arcs of the current vertex (its label is final) */
+      const bool proc = active && have_u;
+      const uint32_t ce = cur + a;
+      const bool in = proc && ce < ue;
+      const uint32_t cec = in ? ce : ub;
+      const uint32_t fs = edge_bits(cec);
+      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+      const bool sense = (fs & GTS_F_SENSE) != 0;
+      const bool arc = live && sense == du;
+      const uint32_t v = M.cend[cec];
+      const float cand = (float)(ndu + (int32_t)M.cdist[cec]);
+      const float old = dist[v];
+      const bool imp = arc && (old == GTS_DIST_UNSET || old > cand);
+      const bool tie = arc && !imp && old == cand;
+      const bool fresh = imp && old == GTS_DIST_UNSET;
+      if (imp) {
+        dist[v] = cand;
+        emap[v] = (idx_t)ce;
+        par[v] = (idx_t)u;
+        plen[v] = plu + (uint32_t)M.cseq[v];
+      }
+      const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
+      const uint64_t fm = W::ballot(fresh), tm = W::ballot(tie);
+      us |= ((bs >> gsh) & gm) != 0;
+      ua |= ((ba >> gsh) & gm) != 0;
+      pending += W::popc((fm >> gsh) & gm);
+      if ((tm >> gsh) & gm) bad = true;
+      if (proc) {
+        cur += L;
+        if (cur >= ue) {
+          /* reached terminal (algorithms.c:694): candidate end of the walk */
+          if (!is_start && !(us && ua)) {
+            if (plu > best_len) { best_len = plu; best_t = u; }
+            else if (plu == best_len && best_t != GTS_NONE) bad = true;
+          }
+          have_u = false;
+          if (pending == 0) active = false;
+        }
+      }
+      if (bad) active = false;
+      W::fence();
+    }
+    r_len = best_len; r_t = best_t; r_bad = bad;
+  }
+
+  /* labels of the walk slots back to "unset" (slot 0's are distmap) */
+  GTS_HD void clear_walk_slots(uint32_t nslots)
+  {
+    const uint32_t lane = W::lane();
+    const uint32_t sbytes = gts_walk_slot_bytes(nv);
+    for (uint32_t k = 0; k < nslots; ++k) {
+      auto dist = (GTS_P(float))(M.wbase + k * sbytes);
+      for (uint32_t s = lane; s < nv; s += W::WIDTH) dist[s] = GTS_DIST_UNSET;
+    }
+    W::fence();
+  }
+
+  /* the walks of the cc with terminals [tb, te) in batches; false if a walk
+     met a tie (nothing is kept then, the caller makes the walks one by one) */
+  template <uint32_t L>
+  GTS_HD bool cc_walks_batched(uint32_t tb, uint32_t te, uint64_t &cc_len, uint32_t &cc_n)
+  {
+    typedef typename GtsCompMemT<LDS>::idx_t idx_t;
+    const uint32_t G = W::WIDTH / L;
+    const uint32_t per = M.wslots < G ? M.wslots : G;
+    const uint32_t sbytes = gts_walk_slot_bytes(nv);
+    const uint32_t p4 = ((nv * 4 + 15) / 16) * 16, p2 = ((nv * 2 + 15) / 16) * 16;
+    bool ok = true;
+    uint32_t used = 0;
+    const uint32_t nfast0 = nfast;
+    for (uint32_t j0 = tb; j0 < te && ok; j0 += per) {
+      if (cc_len == all_bases()) break;             /* as makescaffold(): nothing can be strictly longer */
+      const uint32_t nb = te - j0 < per ? te - j0 : per;
+      clear_walk_slots(nb);       /* between ccs the slots behind the first hold other scratch */
+      used = nb;
+      uint32_t r_len, r_t;
+      bool r_bad;
+      walks_clean_batch<L>(j0, nb, r_len, r_t, r_bad);
+      if (W::ballot(r_bad)) { ok = false; break; }
+      /* first strictly longest walk in terminal order, algorithms.c:826-832 */
+      uint32_t wg = GTS_NONE;
+      for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t len = W::bcast(r_len, k * L);
+        if ((uint64_t)len > cc_len) { cc_len = len; wg = k; }
+      }
+      if (wg != GTS_NONE) {
+        auto sbase = M.wbase + wg * sbytes;
+        auto emap = (GTS_P(idx_t))(sbase + 2 * p4);
+        auto par = (GTS_P(idx_t))(sbase + 2 * p4 + p2);
+        const uint32_t start = W::uni((uint32_t)M.term[j0 + wg]);
+        uint32_t cv = W::bcast(r_t, wg * L), n = 0;
+        while (cv != start) {
+          const uint32_t re = W::uni((uint32_t)emap[cv]);
+          M.cc_best[n++] = (idx_t)re;
+          cv = W::uni((uint32_t)par[cv]);
+        }
+        cc_n = n;
+      }
+      nfast += nb;
+    }
+    if (used) clear_walk_slots(1);   /* distmap: unset between walks */
+    if (!ok) nfast = nfast0;
+    return ok;
+  }
+
   GTS_HD bool create_walk(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     /* (the reference's test for a start without any edge, algorithms.c:655,
@@ -1651,22 +1906,55 @@ struct GtsComponent {
       for (uint32_t k = lane; k < (nv + 31) / 32; k += W::WIDTH) ((uint32_t *)&M.st_cur[0])[k] = 0;
     W::fence();
     auto ccoff = M.ccoff;
-    for (uint32_t i = 0; i < ncc && !err; ++i) {
-      const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
-      if (te - tb == 1) lonesome(W::uni(M.term[tb]));
-      if (te - tb > 1) {
-        uint64_t cc_len = 0;
-        uint32_t cc_n = 0;
-        for (uint32_t j = tb; j < te; ++j) {
-          /* a walk is a simple path inside the component: none can be STRICTLY
-             longer (algorithms.c:826) than one that holds every contig of it --
-             the usual outcome on a clean chain, whose other end needs no walk */
-          if (cc_len == all_bases()) break;
-          if (!create_walk(W::uni(M.term[j]), cc_len, cc_n)) break;
-        }
-        if (err) break;
-        mark_best(M.cc_best, cc_n);
+    /* walks fan out (try_defer): a large component from the start, any component
+       of defer_ref_min_nv contigs from the first cc with a walk that needs the
+       reference's search.  (One call site: the body is inlined.) */
+    bool want_defer = C.defer_min_nv && nv >= C.defer_min_nv, forced = false;
+    bool may_late = C.defer_ref_min_nv && nv >= C.defer_ref_min_nv;
+    uint32_t i0 = 0;
+    for (;;) {
+      if (want_defer) {
+        if (try_defer(i0, forced)) { deferred_late = true; return; }
+        /* (the task tables are full, or the component is too small to gain:) here after all */
+        want_defer = false;
+        if (forced) may_late = false;
       }
+      for (uint32_t i = i0; i < ncc && !err && !want_defer; ++i) {
+        const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
+        if (te - tb == 1) lonesome(W::uni(M.term[tb]));
+        if (te - tb > 1) {
+          uint64_t cc_len = 0;
+          uint32_t cc_n = 0;
+          bool batched = false;
+          if constexpr (LDS) {
+            if (clean && C.fast_walks && C.batch_walks && M.wslots >= 2) {
+              const uint64_t tw0 = W::clock();
+              batched = cc_walks_batched<GTS_WALK_LANES>(tb, te, cc_len, cc_n);
+              tfast += W::clock() - tw0;
+              if (!batched) { cc_len = 0; cc_n = 0; }
+            }
+          }
+          for (uint32_t j = tb; j < te && !batched; ++j) {
+            /* a walk is a simple path inside the component: none can be STRICTLY
+               longer (algorithms.c:826) than one that holds every contig of it --
+               the usual outcome on a clean chain, whose other end needs no walk */
+            if (cc_len == all_bases()) break;
+            no_reference = may_late;
+            if (!create_walk(W::uni(M.term[j]), cc_len, cc_n)) break;
+            no_reference = false;
+            if (needs_reference) {
+              /* this walk needs the reference's search: the walks of this cc and
+                 of the ccs after it become tasks */
+              needs_reference = false;
+              want_defer = true; forced = true; i0 = i;
+              break;
+            }
+          }
+          if (err || want_defer) break;
+          mark_best(M.cc_best, cc_n);
+        }
+      }
+      if (!want_defer) break;
     }
   }
 
@@ -1727,15 +2015,20 @@ struct GtsComponent {
      labelled such a vertex, and otherwise hands the ccs from there on to the
      next round -- only the walks that did touch such a vertex run again.  The
      first pending cc of a pass is always accepted, so the rounds end. */
-  GTS_HD bool try_defer()
+  /* first_cc: the ccs before it are decided already (their marks are in the
+     working copy); forced: no size test (makescaffold met a walk that needs the
+     reference's search) */
+  GTS_HD bool try_defer(uint32_t first_cc = 0, bool forced = false)
   {
     const uint32_t lane = W::lane();
-    if (!C.defer_min_nv || nv < C.defer_min_nv) return false;
-    if (nterm < 2) { nodefer = 2; return false; }
-    if ((uint64_t)nterm * nv < C.defer_min_work) { nodefer = 1; return false; }
+    if (!forced) {
+      if (!C.defer_min_nv || nv < C.defer_min_nv) return false;
+      if (nterm < 2) { nodefer = 2; return false; }
+      if ((uint64_t)nterm * nv < C.defer_min_work) { nodefer = 1; return false; }
+    }
     auto ccoff = M.ccoff;
     uint32_t npend = 0;
-    for (uint32_t i = 0; i < ncc; ++i) {
+    for (uint32_t i = first_cc; i < ncc; ++i) {
       const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
       if (te - tb >= 2) npend += te - tb;
     }
@@ -1751,7 +2044,7 @@ struct GtsComponent {
     const uint32_t kl = W::uni((uint32_t)C.comp_klass[c]);
     const uint64_t q0 = C.tq_base[kl] + W::alloc(C.tq_cnt + kl, npend);
     npend = 0;
-    for (uint32_t i = 0; i < ncc; ++i) {
+    for (uint32_t i = first_cc; i < ncc; ++i) {
       const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
       const bool skip = te - tb < 2;
       for (uint32_t j = tb + lane; j < te; j += W::WIDTH) {
@@ -1787,7 +2080,7 @@ struct GtsComponent {
       C.comp_task0[c] = (uint32_t)t0;
       C.comp_ncc[c] = ncc;
       C.comp_nterm[c] = nterm;
-      C.comp_next_cc[c] = 0;
+      C.comp_next_cc[c] = first_cc;
       C.comp_ring[2 * (uint64_t)c] = 0; C.comp_ring[2 * (uint64_t)c + 1] = 0;
     }
     const uint64_t dl = W::alloc(C.ndeferred, 1);
@@ -1805,7 +2098,7 @@ struct GtsComponent {
     clean = W::uni((uint32_t)C.defer_flag[c]) == 2;   /* revived twins do not change D */
     const uint32_t nw = (nv + 31) / 32;
     reach_bits = C.paths + C.task_roff[t];
-    no_reference = true;
+    no_reference = !C.task_reference;
     for (uint32_t k = lane; k < nw; k += W::WIDTH) reach_bits[k] = 0;
     for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }   /* as makescaffold */
     if constexpr (!LDS)   /* (host harness: tasks run on the global arrays) */
@@ -1820,7 +2113,7 @@ struct GtsComponent {
     if (needs_reference) { len = 0; n = GTS_NONE; }   /* select_walks runs the reference search */
     else if (n) {
       po = W::alloc(C.path_used, n);
-      if (po + n > C.path_cap) { err = GTS_CERR_WALKQ_OVERFLOW; n = 0; len = 0; }
+      if (po + n > C.path_cap) { err = GTS_CERR_PATH_OVERFLOW; n = 0; len = 0; }
       for (uint32_t k = lane; k < n; k += W::WIDTH) C.paths[po + k] = M.cc_best[k];
     }
     if (lane == 0) {
@@ -1830,7 +2123,9 @@ struct GtsComponent {
       C.task_skip[t] = 1;
       if (err) C.cerr[c] = err;
       if (nfast) W::count_n(C.stat_fast + c, nfast);
+      if (nslow) W::count_n(C.stat_slow + c, nslow);
       W::add64(C.tstat + 5 * (uint64_t)c + 2, tfast);
+      if (tslow) W::add64(C.tstat + 5 * (uint64_t)c + 3, tslow);
       W::add64(C.tstat + 5 * (uint64_t)c + 4, npops);
       W::add64((uint64_t *)C.task_bytes, (uint64_t)M.ne * 19 + (uint64_t)nv * 27);
     }
@@ -1898,7 +2193,7 @@ struct GtsComponent {
         uint64_t po = 0;
         if (n) {
           po = W::alloc(C.path_used, n);
-          if (po + n > C.path_cap) { prog.err = GTS_CERR_WALKQ_OVERFLOW; n = 0; len = 0; }
+          if (po + n > C.path_cap) { prog.err = GTS_CERR_PATH_OVERFLOW; n = 0; len = 0; }
           for (uint32_t k = lane; k < n; k += W::WIDTH) C.paths[po + k] = prog.M.cc_best[k];
         }
         if (lane == 0) {
@@ -1975,11 +2270,8 @@ struct GtsComponent {
     const bool was_clean = clean;
     bool deferred = false;
     if (mode == GTS_MODE_MAKESCAFFOLD) {
-      if (C.defer_min_nv && nv >= C.defer_min_nv) {
-        if (!reuse_cc) { calc_cc(); reuse_cc = true; }   /* makescaffold's terminal search */
-        deferred = try_defer();
-      }
-      if (!deferred) makescaffold();
+      makescaffold();
+      deferred = deferred_late;
     }
     const uint64_t t2 = W::clock();
     for (uint32_t s = lane; s < nv; s += W::WIDTH) {

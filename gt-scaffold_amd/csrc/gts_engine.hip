@@ -112,7 +112,9 @@ struct GtsgEngine {
   size_t pool_cap = 0, pool_used = 0;
   uint32_t *d_scalars = nullptr;   /* 16 x u64 device scalars */
   /* options */
-  int64_t walk_queue_factor = 64, max_walk_pops = 1ll << 32, hub_degree = 32;
+  /* ring of a reference search: walk_queue_factor x compact edges of its
+     component to begin with (a walk that overflows it takes a larger one) */
+  int64_t walk_queue_factor = 8, max_walk_pops = 1ll << 32, hub_degree = 32;
   int64_t walk_pool_entries = 1ll << 26;
   int64_t class_streams = GTS_NSTREAMS;
 
@@ -126,11 +128,22 @@ struct GtsgEngine {
      deferral at all is fastest: 55.8 ms per step against 60.0 with every
      component of 256 contigs deferred (gpurun_out/r02m) */
   int64_t defer_min_work = 1ll << 17;
+  /* a component of at least this many contigs hands a walk that needs the
+     reference's search (and the walks of the ccs behind it) to tasks instead of
+     replaying the search in line: 15 such walks of one 248-contig component
+     took 273 ms one after the other on its wavefront (profiles/r02x_*) */
+  int64_t defer_ref_min_contigs = 48;
+  int64_t task_reference_walks = 1;
   int64_t pool_components = 1;        /* all LDS components in one launch (k_components_pool) */
   int64_t pool_waves = GTS_POOL_WAVES; /* wavefronts per workgroup of that launch */
   int64_t lds_poison = -1;             /* test aid: fill a component's pages with this byte before staging */
+  int64_t pool_wait_limit_us = 10000000; /* bound of every wait inside that launch (0: test aid, a wait gives up at once) */
   int n_cus = 256;
   int64_t fast_walks = 1, lds_components = 1;
+  /* clean LDS-resident components sweep the walks of a cc side by side
+     (walks_clean_batch); from batch_big_contigs contigs on a component asks for
+     LDS for batch_big_slots walk slots */
+  int64_t batch_walks = 1, batch_big_contigs = 128, batch_big_slots = 4;
   /* walks of global-memory components fan out only on request: the components
      that end up there on the 50 M workload are scaffolds tied together by an
      unmarked hub, where every accepted cc revives an arc out of the hub and
@@ -1017,7 +1030,7 @@ k_components(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t coun
   /* a component of this class defers its walks only on request (option
      "defer_global_components"): its tasks run from global memory,
      k_walk_tasks_global */
-  if (!defer_global) C.defer_min_nv = 0;
+  if (!defer_global) { C.defer_min_nv = 0; C.defer_ref_min_nv = 0; }
   const GtsCompMem M = GtsComponent<GtsWave64>::global_mem(C, c);
   GtsComponent<GtsWave64> prog(C, M, c);
   prog.run(mode);
@@ -1040,7 +1053,7 @@ __device__ __forceinline__ T __attribute__((address_space(3))) *lds_carve(gts_ld
 /* stages component c into the workgroup's LDS (packed layout) and points M at
    it; with_analysis also loads the strands / sweep order a deferred walk needs */
 __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c, char *smem,
-                                                GtsCompMemT<true> &M, bool with_analysis)
+                                                GtsCompMemT<true> &M, bool with_analysis, uint32_t avail)
 {
   const GtsCompMem G0 = GtsComponent<GtsWave64>::global_mem(C, c);
   const uint32_t nv = G0.nv, ne = G0.ne, lane = threadIdx.x & (GTS_WAVE - 1u);
@@ -1049,24 +1062,31 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   M.nv = nv; M.ne = ne; M.e0 = 0;
   auto coff = lds_carve<idx_t>(p, nv + 1);
   M.ccoff = lds_carve<idx_t>(p, nv + 1);
-  M.queue = lds_carve<idx_t>(p, nv); M.term = lds_carve<idx_t>(p, nv);
-  M.visited = lds_carve<idx_t>(p, nv); M.st_v = lds_carve<idx_t>(p, nv);
-  M.st_par = lds_carve<idx_t>(p, nv);
-  M.edgemap = lds_carve<idx_t>(p, nv); M.wterm = lds_carve<idx_t>(p, nv);
-  M.par = lds_carve<idx_t>(p, nv);
-  M.cc_best = lds_carve<idx_t>(p, nv);
+  M.term = lds_carve<idx_t>(p, nv); M.cc_best = lds_carve<idx_t>(p, nv);
   M.topo = lds_carve<idx_t>(p, nv); M.tpos = lds_carve<idx_t>(p, nv);
-  M.distmap = lds_carve<float>(p, nv);
   auto cseq = lds_carve<int32_t>(p, nv);
-  M.nd = lds_carve<int32_t>(p, nv); M.plen = lds_carve<uint32_t>(p, nv);
-  /* never live at the same time (gts_comp_lds_bytes) */
-  M.st_cur = M.cc_best; M.touched = M.visited;
-  M.lastpop = (uint32_t __attribute__((address_space(3))) *)M.nd;
   M.vst = lds_carve<uint8_t>(p, nv); M.st_dir = lds_carve<uint8_t>(p, nv);
   M.tight = lds_carve<uint8_t>(p, nv); M.gorient = lds_carve<uint8_t>(p, nv);
   auto cend = lds_carve<idx_t>(p, ne);
   auto cdist = lds_carve<int32_t>(p, ne);
   auto cfs = lds_carve<uint8_t>(p, ne);   /* flags | state << 4 */
+  /* the walk scratch, in one piece (gts_comp_lds_bytes): slot 0 of the batched
+     walks is distmap, plen, edgemap, par */
+  M.wbase = (char __attribute__((address_space(3))) *)p;
+  M.distmap = lds_carve<float>(p, nv); M.plen = lds_carve<uint32_t>(p, nv);
+  M.edgemap = lds_carve<idx_t>(p, nv); M.par = lds_carve<idx_t>(p, nv);
+  M.nd = lds_carve<int32_t>(p, nv);
+  M.queue = lds_carve<idx_t>(p, nv); M.visited = lds_carve<idx_t>(p, nv);
+  M.st_v = lds_carve<idx_t>(p, nv); M.wterm = lds_carve<idx_t>(p, nv);
+  M.st_par = lds_carve<idx_t>(p, nv);
+  {
+    const uint32_t need = (uint32_t)(p - (gts_lds_cursor)smem);
+    const uint32_t more = avail > need ? (avail - need) / gts_walk_slot_bytes(nv) : 0u;
+    M.wslots = 2u + more < GTS_WALK_SLOTS_MAX ? 2u + more : GTS_WALK_SLOTS_MAX;
+  }
+  /* never live at the same time (gts_comp_lds_bytes) */
+  M.st_cur = M.cc_best; M.touched = M.visited;
+  M.lastpop = (uint32_t __attribute__((address_space(3))) *)M.nd;
   M.cflags.b = cfs; M.cstate.b = cfs;
   M.coff = coff; M.cseq = cseq; M.cend = cend; M.cdist = cdist;
   M.cstart.coff = coff; M.cstart.nv = nv;
@@ -1085,13 +1105,14 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 __global__ void __launch_bounds__(GTS_WAVE)
-k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode)
+k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
+                 uint32_t lds_bytes)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (blockIdx.x >= count) return;
   const uint32_t c = order[first + blockIdx.x];
   GtsCompMemT<true> M;
-  stage_component(C, c, smem, M, false);
+  stage_component(C, c, smem, M, false, lds_bytes);
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.run(mode);
 }
@@ -1164,18 +1185,25 @@ __device__ __forceinline__ uint32_t pool_find(gts_pool_bits used, uint32_t n, bo
   }
   return GTS_NONE;
 }
-/* Every wait of the pool is bounded: after GTS_POOL_SPINS rounds (seconds) the
-   wavefront gives up, counts the place in pstat[6 + where] and carries on as
-   if it had been served -- the launch ends, the host reports GTSG_EINTERNAL. */
-#define GTS_POOL_SPINS (1u << 22)
-__device__ __forceinline__ void pool_lock(GtsPoolCtl *ctl, unsigned long long *pstat)
+/* Every wait of the pool is bounded by the wall clock (100 MHz counter;
+   `limit` ticks, ten seconds by default -- a count of spins would depend on the
+   clock the chip happens to run at): a wavefront that runs into the bound counts
+   the place in pstat[6 + where] and does NOT enter what it was waiting for -- no
+   claim, no pages, a lock not taken means a critical section not run --, so the
+   control block stays consistent, the launch ends, and the host restores the
+   states from its snapshot and reports GTSG_EINTERNAL. */
+__device__ __forceinline__ bool pool_lock(GtsPoolCtl *ctl, unsigned long long *pstat, uint64_t limit)
 {
   uint32_t spins = 0;
+  uint64_t t0 = 0;
+  bool got = true;
   while (atomicCAS(&ctl->lock, 0u, 1u) != 0u) {
+    if (spins == 0) t0 = GtsWave64::clock();
+    if ((spins++ & 255u) == 0 && GtsWave64::clock() - t0 >= limit) { atomicAdd(pstat + 6, 1ull); got = false; break; }
     __builtin_amdgcn_s_sleep(2);
-    if (++spins == GTS_POOL_SPINS) { atomicAdd(pstat + 6, 1ull); break; }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return got;
 }
 __device__ __forceinline__ void pool_unlock(GtsPoolCtl *ctl)
 {
@@ -1185,7 +1213,8 @@ __device__ __forceinline__ void pool_unlock(GtsPoolCtl *ctl)
 __global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
 k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_key, uint32_t first,
                   uint32_t count, int mode,
-                  unsigned long long *cursor, unsigned long long *pstat, uint32_t nbig, int poison)
+                  unsigned long long *cursor, unsigned long long *pstat, uint32_t nbig, int poison,
+                  uint64_t wait_limit)
 {
   /* pstat (100 MHz ticks, summed over the wavefronts): [0] staging + program,
      [1] waiting for pages, [2] whole life of the wavefront; [3] first exit,
@@ -1208,10 +1237,11 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
     /* role, claim, pages: lane 0; the rest of the wavefront waits at the broadcast */
     uint32_t idx = GTS_NONE, pos = 0, npages = 0, need = 0;
     if (lane == 0) {
-      bool front;
+      bool front = false;
+      const uint64_t tc0 = GtsWave64::clock();
       for (uint32_t spins = 0;;) {
         bool more;
-        pool_lock(ctl, pstat);
+        if (!pool_lock(ctl, pstat, wait_limit)) break;      /* no claim: this wavefront leaves */
         volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
         front = v->front_busy == 0;
         if (front) {
@@ -1241,7 +1271,7 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
         more = idx == GTS_NONE && !(v->f_done && v->f_next == v->f_end);
         pool_unlock(ctl);
         if (!more) break;
-        if (++spins == GTS_POOL_SPINS) { atomicAdd(pstat + 7, 1ull); break; }
+        if ((spins++ & 63u) == 0 && GtsWave64::clock() - tc0 >= wait_limit) { atomicAdd(pstat + 7, 1ull); break; }
         __builtin_amdgcn_s_sleep(16);
       }
       if (idx != GTS_NONE) {
@@ -1250,7 +1280,10 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
         bool waiting = false;
         const uint64_t tw0 = GtsWave64::clock();
         for (uint32_t spins = 0;;) {
-          pool_lock(ctl, pstat);
+          /* a lock not taken: the component is not run (its state stays as it is);
+             its front claim stays with this wavefront, the others of the
+             workgroup run into their own bounds: the launch ends */
+          if (!pool_lock(ctl, pstat, wait_limit)) { idx = GTS_NONE; break; }
           volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
           const uint32_t floor = front ? 0u : v->wait_pages;
           const gts_pool_bits bits = pool_bits_load(v->used);
@@ -1261,8 +1294,8 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
           } else if (front && !waiting) {
             v->wait_pages = npages; waiting = true;
           }
-          if (pos == GTS_NONE && ++spins == GTS_POOL_SPINS) {
-            /* give up: the component is not run (its state stays as it is), the host sees the count */
+          if (pos == GTS_NONE && (spins++ & 63u) == 0 && GtsWave64::clock() - tw0 >= wait_limit) {
+            /* give up: the component is not run, the host sees the count */
             atomicAdd(pstat + 8, 1ull);
             if (front) { v->front_busy = 0; v->wait_pages = 0; }
             pool_unlock(ctl);
@@ -1279,11 +1312,11 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
     idx = GtsWave64::uni(idx);
     if (idx == GTS_NONE) break;
     pos = GtsWave64::uni(pos); npages = GtsWave64::uni(npages); need = GtsWave64::uni(need);
-    /* the components of a workgroup are neighbours in LDS: a word behind the
-       footprint (where the last page has room for one) shows a program that
-       wrote past its arrays */
-    volatile uint32_t *canary = need + 4u <= npages * GTS_POOL_PAGE
-                                    ? (volatile uint32_t *)(smem + pos * GTS_POOL_PAGE + need) : nullptr;
+    /* the components of a workgroup are neighbours in LDS: a word at the end of
+       the last page (when the footprint leaves room) shows a program that wrote
+       past its pages' arrays */
+    volatile uint32_t *canary = need + 16u <= npages * GTS_POOL_PAGE
+                                    ? (volatile uint32_t *)(smem + (pos + npages) * GTS_POOL_PAGE - 4u) : nullptr;
     if (poison >= 0) {
       /* test aid: the pages hold this byte instead of what the last component
          left there -- a program that reads scratch it has not written shows */
@@ -1297,7 +1330,8 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
       const uint64_t tr0 = GtsWave64::clock();
       const uint32_t c = order[first + idx];
       GtsCompMemT<true> M;
-      stage_component(C, c, smem + pos * GTS_POOL_PAGE, M, false);
+      /* what the last page has left behind the footprint: more walk slots */
+      stage_component(C, c, smem + pos * GTS_POOL_PAGE, M, false, npages * GTS_POOL_PAGE - (canary ? 16u : 0u));
       GtsComponent<GtsWave64, true> prog(C, M, c);
       prog.run(mode);
       t_run += GtsWave64::clock() - tr0;
@@ -1305,10 +1339,11 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane == 0) {
       if (canary && *canary != 0x5CAFF01Du) atomicAdd(pstat + 9, 1ull);
-      pool_lock(ctl, pstat);
-      volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
-      pool_bits_store(v->used, pool_bits_load(v->used) & ~pool_run_mask(pos, npages));
-      pool_unlock(ctl);
+      if (pool_lock(ctl, pstat, wait_limit)) {     /* (else the pages stay taken: the launch is lost anyway) */
+        volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
+        pool_bits_store(v->used, pool_bits_load(v->used) & ~pool_run_mask(pos, npages));
+        pool_unlock(ctl);
+      }
     }
   }
   if (lane == 0) {
@@ -1330,7 +1365,7 @@ k_walk_tasks(GtsCompView C, uint32_t klass, uint32_t count)
   const uint32_t t = C.tq[C.tq_base[klass] + blockIdx.x];
   const uint32_t c = C.task_comp[t];
   GtsCompMemT<true> M;
-  stage_component(C, c, smem, M, true);
+  stage_component(C, c, smem, M, true, 0u);
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.walk_task(t);
 }
@@ -1347,7 +1382,7 @@ k_walk_tasks_mixed(GtsCompView C, GtsTaskPrefix P)
   const uint32_t t = C.tq[C.tq_base[k] + blockIdx.x - P.pre[k]];
   const uint32_t c = C.task_comp[t];
   GtsCompMemT<true> M;
-  stage_component(C, c, smem, M, true);
+  stage_component(C, c, smem, M, true, 0u);
   GtsComponent<GtsWave64, true> prog(C, M, c);
   prog.walk_task(t);
 }
@@ -1402,7 +1437,7 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 const uint8_t *comp_wide, const unsigned long long *comp_len,
                                 uint8_t *comp_klass, const uint32_t *klass, uint32_t nklass,
                                 uint32_t *klass_count, unsigned long long *klass_bytes,
-                                uint32_t *klass_slots)
+                                uint32_t *klass_slots, uint32_t big_nv, uint32_t big_slots)
 {
   /* counters are summed per workgroup in LDS first: seven global counters hit by
      every component serialise */
@@ -1414,7 +1449,8 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
   if (c < ncomp) {
     const uint32_t s0 = comp_off[c], s1 = comp_off[c + 1];
     const uint32_t cnv = s1 - s0, cne = coff[s1] - coff[s0];
-    uint32_t need = gts_comp_lds_bytes(cnv, cne);
+    /* footprint, and room for walk slots from big_nv contigs on (gts_comp_lds_want) */
+    uint32_t need = gts_comp_lds_want(cnv, cne, big_nv, big_slots, GTS_POOL_BYTES - 16u);
     /* not representable in the packed LDS layout: run from global memory */
     if (comp_wide[c] || cnv >= 4096u || cne > GTS_LDS_MAX_INDEX || comp_len[c] >= (1ull << 32))
       need = 0x7FFFFFFFu;
@@ -1445,11 +1481,12 @@ __global__ void k_task_queue_bases(const uint32_t *klass_slots, uint32_t *tq_bas
   for (int k = 0; k <= GTS_NKLASS; ++k) { tq_base[k] = acc; acc += klass_slots[k]; }
 }
 __global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
-                               uint32_t *out /* [0]=overflow, [1]=loop */)
+                               uint32_t *out /* [0]=ring pool, [1]=loop, [3]=path pool */)
 {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncomp) return;
   if (cerr[c] == GTS_CERR_WALKQ_OVERFLOW) atomicAdd(&out[0], 1u);
+  else if (cerr[c] == GTS_CERR_PATH_OVERFLOW) atomicAdd(&out[3], 1u);
   else if (cerr[c] != 0) atomicAdd(&out[1], 1u);
 }
 /* statistics: the lanes of a wave add up (or take the maximum) first, one
@@ -1653,11 +1690,17 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "hub_degree") && value >= 1) e->hub_degree = value;
   else if (!strcmp(name, "fast_walks")) e->fast_walks = value != 0;
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
+  else if (!strcmp(name, "batch_walks")) e->batch_walks = value != 0;
+  else if (!strcmp(name, "batch_big_contigs") && value >= 0) e->batch_big_contigs = value;
+  else if (!strcmp(name, "batch_big_slots") && value >= 2 && value <= GTS_WALK_SLOTS_MAX) e->batch_big_slots = value;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
   else if (!strcmp(name, "defer_min_work") && value >= 0) e->defer_min_work = value;
+  else if (!strcmp(name, "defer_ref_min_contigs") && value >= 0) e->defer_ref_min_contigs = value;
+  else if (!strcmp(name, "task_reference_walks")) e->task_reference_walks = value != 0;
   else if (!strcmp(name, "pool_components")) e->pool_components = value != 0;
   else if (!strcmp(name, "pool_waves") && value >= 1 && value <= GTS_POOL_WAVES) e->pool_waves = value;
   else if (!strcmp(name, "lds_poison") && value >= -1 && value <= 255) e->lds_poison = value;
+  else if (!strcmp(name, "pool_wait_limit_us") && value >= 0) e->pool_wait_limit_us = value;
   else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NSTREAMS) e->class_streams = value;
   else if (!strcmp(name, "mixed_task_limit") && value >= 0) e->mixed_task_limit = value;
 
@@ -1778,6 +1821,7 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
     int where;
     { ProfScope ps(e, "build_sort_pairs");
       where = gts_radix_sort<uint64_t>(k0, v0, k1, v1, nrec, shifts, np, stmp, e->st); }
+    if (where < 0) return fail(e, GTSG_ELIMIT, "too many records for the pair sort");
     uint64_t *ks = where ? k1 : k0;
     uint32_t *vs = where ? v1 : v0;
     /* reuse the other value buffer and fresh arrays for the segment fold */
@@ -2227,6 +2271,7 @@ static int run_components(GtsgEngine *e, int mode)
       ProfScope ps(e, "comp_sort_slots");
       const int where = gts_radix_sort<uint32_t>(lk0, sv0, lk1, sv1, nslots, shifts, np,
                                                  stmp, e->st);
+      if (where < 0) return fail(e, GTSG_ELIMIT, "too many contigs for the slot sort");
       if (where) { uint32_t *t = lk0; lk0 = lk1; lk1 = t; t = sv0; sv0 = sv1; sv1 = t; }
     }
     uint32_t *labels = lk0, *slot_v = sv0, *head = lk1, *cidx = sv1;
@@ -2309,12 +2354,15 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, nklass * sizeof(uint32_t), hipMemcpyHostToDevice, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
            ncomp, comp_wide, comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? nklass : 0), klass_count,
-           (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS);
+           (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS,
+           (uint32_t)(e->batch_walks && mode == GTS_MODE_MAKESCAFFOLD ? e->batch_big_contigs : 0),
+           (uint32_t)e->batch_big_slots);
     LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + GTS_S_KSLOTS, e->d_scalars + GTS_S_TQBASE);
     const uint32_t *order, *order_key;   /* order_key[i] = ~footprint of component order[i] */
     {
       int shifts[4] = {0, 8, 16, 24};
       const int where = gts_radix_sort<uint32_t>(ok0, ov0, ok1, ov1, ncomp, shifts, 4, otmp, e->st);
+      if (where < 0) return fail(e, GTSG_ELIMIT, "too many components for the footprint sort");
       order = where ? ov1 : ov0;
       order_key = where ? ok1 : ok0;
     }
@@ -2342,11 +2390,13 @@ static int run_components(GtsgEngine *e, int mode)
     C.distmap = s_distmap; C.ccoff = s_ccoff; C.wq_edge = wq_edge; C.wq_used = wq_used;
     C.wq_pool = wq_pool; C.wq_factor = (uint64_t)factor;
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
-    C.fast_walks = (int)e->fast_walks; C.nd = s_nd; C.plen = s_plen; C.tight = s_tight;
+    C.fast_walks = (int)e->fast_walks; C.batch_walks = (int)e->batch_walks; C.nd = s_nd; C.plen = s_plen; C.tight = s_tight;
     C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat; C.stat_clean = stat_clean;
     C.gorient = s_gorient; C.topo = s_topo; C.tpos = s_tpos;
     C.defer_min_nv = mode == GTS_MODE_MAKESCAFFOLD && e->lds_components ? (uint32_t)e->defer_min_contigs : 0u;
     C.defer_min_work = (uint64_t)e->defer_min_work;
+    C.defer_ref_min_nv = mode == GTS_MODE_MAKESCAFFOLD && e->lds_components ? (uint32_t)e->defer_ref_min_contigs : 0u;
+    C.task_reference = (int)e->task_reference_walks;
     C.defer_flag = defer_flag; C.comp_task0 = comp_task0; C.comp_ncc = comp_ncc; C.comp_nterm = comp_nterm;
     C.ntasks = (unsigned long long *)(e->d_scalars + 128); C.path_used = (unsigned long long *)(e->d_scalars + 130);
     C.task_bytes = (unsigned long long *)(e->d_scalars + GTS_S_NDEF + 2);
@@ -2406,7 +2456,8 @@ static int run_components(GtsgEngine *e, int mode)
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
         const uint32_t pw = (uint32_t)e->pool_waves;
         k_components_pool<<<e->n_cus, pw * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, order, order_key, first, pooled, mode,
-                                                                          cursor, pstat, nbig, (int)e->lds_poison);
+                                                                          cursor, pstat, nbig, (int)e->lds_poison,
+                                                                          (uint64_t)e->pool_wait_limit_us * 100ull);
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_pool"
                                                                               : "components_removecycles_pool",
@@ -2429,7 +2480,7 @@ static int run_components(GtsgEngine *e, int mode)
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
-        k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode);
+        k_components_lds<<<kcount[k], GTS_WAVE, klass_h[k], ss>>>(C, order, first, kcount[k], mode, klass_h[k]);
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({klass_event(mode == GTS_MODE_MAKESCAFFOLD, klass_h[k]), _a, _b}); }
         HIPCHK(hipEventRecord(e->ev_join[k], ss));
@@ -2452,7 +2503,7 @@ static int run_components(GtsgEngine *e, int mode)
          per pending walk, grouped by LDS class, and an in-order select pass */
       uint64_t ntasks = 0, walks_run = 0, task_launches = 0;
       uint32_t rounds = 0;
-      if (C.defer_min_nv) {
+      if (C.defer_min_nv || C.defer_ref_min_nv) {
         uint64_t pend[GTS_NKLASS + 1], ndef = 0;
         HIPCHK(hipMemcpyAsync(pend, e->d_scalars + GTS_S_TQCNT, sizeof pend, hipMemcpyDeviceToHost, e->st));
         HIPCHK(hipMemcpyAsync(&ndef, e->d_scalars + GTS_S_NDEF, 8, hipMemcpyDeviceToHost, e->st));
@@ -2555,23 +2606,28 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 64, hipMemcpyDeviceToHost, e->st));
     uint64_t pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 80, hipMemcpyDeviceToHost, e->st));
-    uint32_t res[3] = {0, 0, 0};
+    uint32_t res[4] = {0, 0, 0, 0};
     uint64_t wstat[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 12, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 16, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 32, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
-    if (pst[9]) {
+    if (pst[6] | pst[7] | pst[8] | pst[9]) {
+      /* some components have written their marks, others have not run: the graph
+         goes back to its state before the call (as for GTSG_EWALK), the caller
+         may call again */
       e->stats["pool_lds_overruns"] = (int64_t)pst[9];
-      return fail(e, GTSG_EINTERNAL, "component pool: %llu program(s) wrote past their LDS arrays",
-                  (unsigned long long)pst[9]);
-    }
-    if (pst[6] | pst[7] | pst[8]) {
       e->stats["pool_gave_up_lock"] = (int64_t)pst[6];
       e->stats["pool_gave_up_claim"] = (int64_t)pst[7];
       e->stats["pool_gave_up_pages"] = (int64_t)pst[8];
-      fprintf(stderr, "gts: k_components_pool gave up waiting (lock %llu, claim %llu, pages %llu)\n",
-              (unsigned long long)pst[6], (unsigned long long)pst[7], (unsigned long long)pst[8]);
-      return fail(e, GTSG_EINTERNAL, "component pool: a wavefront gave up waiting");
+      HIPCHK(hipMemcpyAsync(e->vstate, snap_v, n, hipMemcpyDeviceToDevice, e->st));
+      if (m) HIPCHK(hipMemcpyAsync(e->state, snap_e, m, hipMemcpyDeviceToDevice, e->st));
+      HIPCHK(hipStreamSynchronize(e->st));
+      if (pst[9])
+        return fail(e, GTSG_EINTERNAL, "component pool: %llu program(s) wrote past their LDS arrays; "
+                    "states restored", (unsigned long long)pst[9]);
+      return fail(e, GTSG_EINTERNAL, "component pool: a wavefront gave up waiting (lock %llu, claim %llu, "
+                  "pages %llu); states restored", (unsigned long long)pst[6], (unsigned long long)pst[7],
+                  (unsigned long long)pst[8]);
     }
     if (pool_ran) {   /* 100 MHz ticks -> microseconds */
       e->stats["pool_us_sum_run"] = (int64_t)(pst[0] / 100);
@@ -2683,12 +2739,15 @@ static int run_components(GtsgEngine *e, int mode)
       return fail(e, GTSG_EWALK, "%u components exceeded max_walk_pops=%lld or hold a "
                   "cyclic distance map; states restored", res[1], (long long)e->max_walk_pops);
     }
-    if (!res[0]) break;
-    /* walk queue too small somewhere: restore and retry with more room */
+    if (!res[0] && !res[3]) break;
+    /* the pool of walk rings or the pool of task paths was too small somewhere:
+       restore and run again with more of what ran out (a single ring that is
+       too small is replaced on the device, create_walk_reference) */
     HIPCHK(hipMemcpyAsync(e->vstate, snap_v, n, hipMemcpyDeviceToDevice, e->st));
     if (m) HIPCHK(hipMemcpyAsync(e->state, snap_e, m, hipMemcpyDeviceToDevice, e->st));
     HIPCHK(hipStreamSynchronize(e->st));
-    factor *= 4; pool_entries *= 4; path_entries *= 4;
+    if (res[0]) pool_entries *= 8;
+    if (res[3]) path_entries *= 4;
     if (++retries > 6) return fail(e, GTSG_EWALK, "walk queues keep overflowing");
   }
   e->stats["walk_retries"] = retries;
@@ -2756,6 +2815,64 @@ int gtsg_get_csr(GtsgEngine *e, uint32_t *row, uint32_t *adj)
   if (!e->row) return fail(e, GTSG_EINVAL, "no graph has been built");
   HIPCHK(hipMemcpyAsync(row, e->row, ((size_t)e->n + 1) * 4, hipMemcpyDeviceToHost, e->st));
   if (e->m) HIPCHK(hipMemcpyAsync(adj, e->eid, (size_t)e->m * 4, hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+
+/* ref gt_scaffolder_graph.c:174-193 (find_edge): the first edge of vertex_1's
+   list -- creation order -- that ends in vertex_2.  Reads the one list back. */
+int gtsg_find_edge(GtsgEngine *e, uint64_t vertex_1, uint64_t vertex_2, uint64_t *eid)
+{
+  if (!e || !eid) return GTSG_EINVAL;
+  *eid = GTSG_NO_EDGE;
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->built) return fail(e, GTSG_EINVAL, "graph not built");
+  if (vertex_1 >= e->n || vertex_2 >= e->n) return fail(e, GTSG_EINVAL, "vertex out of range");
+  uint32_t be[2];
+  HIPCHK(hipMemcpyAsync(be, e->row + vertex_1, 8, hipMemcpyDeviceToHost, e->st));
+  int rc;
+  if ((rc = sync_stream(e))) return rc;
+  const size_t deg = be[1] - be[0];
+  if (!deg) return 0;
+  std::vector<uint32_t> ends(deg), ids(deg);
+  HIPCHK(hipMemcpyAsync(ends.data(), e->eend + be[0], deg * 4, hipMemcpyDeviceToHost, e->st));
+  HIPCHK(hipMemcpyAsync(ids.data(), e->eid + be[0], deg * 4, hipMemcpyDeviceToHost, e->st));
+  if ((rc = sync_stream(e))) return rc;
+  for (size_t k = 0; k < deg; ++k)
+    if (ends[k] == vertex_2) { *eid = ids[k]; break; }
+  return 0;
+}
+
+/* ref gt_scaffolder_graph.c:219-235 (alter_edge): new attributes for one edge;
+   its state and its twin's attributes stay.  The stored flags carry a bit
+   derived from the senses of an edge and its twin (k_emit_edges), which is
+   redone for both. */
+int gtsg_alter_edge(GtsgEngine *e, uint64_t eid, int64_t dist, float std_dev, uint64_t num_pairs,
+                    int sense, int same)
+{
+  if (!e) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->built) return fail(e, GTSG_EINVAL, "graph not built");
+  if (eid >= e->m) return fail(e, GTSG_EINVAL, "edge out of range");
+  if (e->filter_open) return fail(e, GTSG_EINVAL, "gtsg_filter_begin without gtsg_filter_end");
+  int rc;
+  uint32_t p = 0, t = 0;
+  uint8_t fp = 0, ft = 0;
+  HIPCHK(hipMemcpyAsync(&p, e->pos_of_eid + eid, 4, hipMemcpyDeviceToHost, e->st));
+  if ((rc = sync_stream(e))) return rc;
+  HIPCHK(hipMemcpyAsync(&t, e->twin + p, 4, hipMemcpyDeviceToHost, e->st));
+  if ((rc = sync_stream(e))) return rc;
+  HIPCHK(hipMemcpyAsync(&ft, e->flags + t, 1, hipMemcpyDeviceToHost, e->st));
+  if ((rc = sync_stream(e))) return rc;
+  fp = (uint8_t)((sense ? GTS_F_SENSE : 0u) | (same ? GTS_F_SAME : 0u));
+  ft &= 3u;
+  if (((ft & GTS_F_SENSE) != 0) == gts_next_dir(fp)) fp |= GTS_F_UTURN;
+  if (((fp & GTS_F_SENSE) != 0) == gts_next_dir(ft)) ft |= GTS_F_UTURN;
+  const int64_t np = (int64_t)num_pairs;
+  HIPCHK(hipMemcpyAsync(e->dist + p, &dist, 8, hipMemcpyHostToDevice, e->st));
+  HIPCHK(hipMemcpyAsync(e->sd + p, &std_dev, 4, hipMemcpyHostToDevice, e->st));
+  HIPCHK(hipMemcpyAsync(e->npairs + p, &np, 8, hipMemcpyHostToDevice, e->st));
+  HIPCHK(hipMemcpyAsync(e->flags + p, &fp, 1, hipMemcpyHostToDevice, e->st));
+  if (t != p) HIPCHK(hipMemcpyAsync(e->flags + t, &ft, 1, hipMemcpyHostToDevice, e->st));
   return sync_stream(e);
 }
 

@@ -156,6 +156,67 @@ int gt_scaffolder_graph_add_edge(GtScaffolderGraph *g, uint64_t vstart,
   return 0;
 }
 
+/* ref gt_scaffolder_graph.c:174-193: the first edge of vertex_1's list that
+   ends in vertex_2 (an edge id; GT_SCAFFOLDER_NO_EDGE where the reference
+   returns NULL) */
+uint64_t gt_scaffolder_graph_find_edge(GtScaffolderGraph *g, uint64_t vertex_1, uint64_t vertex_2)
+{
+  uint64_t i, eid = GT_SCAFFOLDER_NO_EDGE;
+  if (!g || vertex_1 >= g->nof_vertices || vertex_2 >= g->nof_vertices) return GT_SCAFFOLDER_NO_EDGE;
+  if (g->eng) {
+    if (gtsg_find_edge(g->eng, vertex_1, vertex_2, &eid) != 0) {
+      snprintf(g->err, sizeof g->err, "%s", gtsg_last_error(g->eng));
+      return GT_SCAFFOLDER_NO_EDGE;
+    }
+    return eid;
+  }
+  /* hand-built graph: a vertex' list is its edges in creation order */
+  for (i = 0; i < g->nof_edges; i++)
+    if (g->edges[i].start == vertex_1 && g->edges[i].end == vertex_2) return i;
+  return GT_SCAFFOLDER_NO_EDGE;
+}
+
+/* ref gt_scaffolder_graph.c:237-244: a vertex IS its id here (the reference
+   subtracts the base of the vertex array); out of range: GT_SCAFFOLDER_NO_VERTEX */
+uint64_t gt_scaffolder_graph_get_vertex_id(const GtScaffolderGraph *g, uint64_t vertex)
+{
+  return g && vertex < g->nof_vertices ? vertex : GT_SCAFFOLDER_NO_VERTEX;
+}
+
+/* ref gt_scaffolder_graph.c:196-216: binary search over the vertices, which
+   are in header order once the distance file has been counted or read
+   (parser.c:172); like the reference it assumes that order */
+bool gt_scaffolder_graph_get_vertex(const GtScaffolderGraph *g, uint64_t *vertex,
+                                    const char *header_seq)
+{
+  uint64_t lo = 0, hi;
+  if (!g || !vertex || !header_seq) return false;
+  hi = g->nof_vertices;
+  while (lo < hi) {
+    uint64_t mid = lo + (hi - lo) / 2;
+    int c = strcmp(g->ctg[mid].name, header_seq);
+    if (c == 0) { *vertex = mid; return true; }
+    if (c < 0) lo = mid + 1; else hi = mid;
+  }
+  return false;
+}
+
+/* ref gt_scaffolder_graph.c:219-235 */
+int gt_scaffolder_graph_alter_edge(GtScaffolderGraph *g, uint64_t edge, int64_t dist,
+                                   float std_dev, uint64_t num_pairs, bool sense, bool same)
+{
+  if (!g || edge >= g->nof_edges) return -1;
+  if (g->eng) {
+    int rc = gtsg_alter_edge(g->eng, edge, dist, std_dev, num_pairs, sense, same);
+    if (rc) { snprintf(g->err, sizeof g->err, "%s", gtsg_last_error(g->eng)); return -1; }
+    if (!g->edges_cached) return 0;   /* the next download sees the new values */
+  }
+  g->edges[edge].dist = dist; g->edges[edge].std_dev = std_dev;
+  g->edges[edge].num_pairs = (int64_t)num_pairs;
+  g->edges[edge].flags = (uint8_t)((sense ? 1 : 0) | (same ? 2 : 0));
+  return 0;
+}
+
 uint64_t gt_scaffolder_graph_nof_vertices(const GtScaffolderGraph *g) { return g ? g->nof_vertices : 0; }
 uint64_t gt_scaffolder_graph_nof_edges(const GtScaffolderGraph *g) { return g ? g->nof_edges : 0; }
 const char *gt_scaffolder_graph_last_error(const GtScaffolderGraph *g) { return g ? g->err : ""; }
@@ -291,6 +352,7 @@ static int scan_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len
   if (g) {
     g->max_nof_vertices = cap;
     g->sorted = false;
+    g->dp_names = false;   /* the GPU parser's name table is that of the old vertex set */
   }
   return 0;
 }

@@ -24,6 +24,7 @@ SYMBOLS = [
     "gtsg_deparser_create", "gtsg_deparser_destroy", "gtsg_deparser_last_error", "gtsg_deparser_set_names",
     "gtsg_deparser_parse", "gtsg_deparser_records", "gtsg_deparser_download", "gtsg_deparser_parse_astat",
     "gtsg_deparser_trim", "gtsg_sort_names", "gtsg_fasta_records", "gtsg_deparser_accumulate",
+    "gtsg_find_edge", "gtsg_alter_edge",
 ]
 
 
@@ -40,6 +41,8 @@ HOST_SYMBOLS = [
     "gt_scaffolder_parser_count_contigs", "gt_scaffolder_parser_read_contigs",
     "gt_scaffolder_parser_count_distances", "gt_scaffolder_parser_read_distances",
     "gt_scaffolder_set_distance_parser", "gt_scaffolder_graph_get_edges",
+    "gt_scaffolder_graph_find_edge", "gt_scaffolder_graph_get_vertex_id",
+    "gt_scaffolder_graph_get_vertex", "gt_scaffolder_graph_alter_edge",
 ]
 
 
@@ -92,6 +95,8 @@ def lib():
         L.gtsg_get_edge_states.argtypes = [vp, vp]
         L.gtsg_get_edges.argtypes = [vp] + [vp] * 6
         L.gtsg_get_csr.argtypes = [vp, vp, vp]
+        L.gtsg_find_edge.argtypes = [vp, u64, u64, C.POINTER(u64)]
+        L.gtsg_alter_edge.argtypes = [vp, u64, i64, f32, u64, ci, ci]
         L.gtsg_state_digest.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.gtsg_selftest_ambiguous.argtypes = [vp, u64, vp, vp, vp, vp, f32, vp]
         L.gtsg_set_option.argtypes = [vp, C.c_char_p, i64]
@@ -132,6 +137,13 @@ def lib():
         L.gt_scaffolder_parser_read_distances.argtypes = [cp, vp, b, cp, sz]
         L.gt_scaffolder_set_distance_parser.argtypes = [ci]
         L.gt_scaffolder_graph_get_edges.argtypes = [vp] * 7
+        L.gt_scaffolder_graph_find_edge.argtypes = [vp, u64, u64]
+        L.gt_scaffolder_graph_find_edge.restype = u64
+        L.gt_scaffolder_graph_get_vertex_id.argtypes = [vp, u64]
+        L.gt_scaffolder_graph_get_vertex_id.restype = u64
+        L.gt_scaffolder_graph_get_vertex.argtypes = [vp, C.POINTER(u64), cp]
+        L.gt_scaffolder_graph_get_vertex.restype = b
+        L.gt_scaffolder_graph_alter_edge.argtypes = [vp, u64, i64, f32, u64, b, b]
         L.gtsg_deparser_create.argtypes = [C.POINTER(vp), ci, vp]
         L.gtsg_deparser_destroy.argtypes = [vp]
         L.gtsg_deparser_last_error.argtypes = [vp]
@@ -453,6 +465,18 @@ class Engine:
                                                     ("start", "end", "dist", "std_dev",
                                                      "num_pairs", "flags")]))
         return {k: v[:m] for k, v in o.items()}
+
+    def find_edge(self, vertex_1, vertex_2):
+        """id of the first edge of vertex_1's list that ends in vertex_2, or None
+        (ref gt_scaffolder_graph.c:174-193)"""
+        eid = C.c_uint64()
+        self._chk(self._L.gtsg_find_edge(self._h, int(vertex_1), int(vertex_2), C.byref(eid)))
+        return None if eid.value == 2 ** 64 - 1 else eid.value
+
+    def alter_edge(self, eid, dist, std_dev, num_pairs, sense, same):
+        """ref gt_scaffolder_graph.c:219-235"""
+        self._chk(self._L.gtsg_alter_edge(self._h, int(eid), int(dist), float(std_dev), int(num_pairs),
+                                          int(bool(sense)), int(bool(same))))
 
     def digest(self):
         a, b = C.c_uint64(), C.c_uint64()

@@ -159,6 +159,16 @@ int gtsg_get_edges(GtsgEngine *e, uint32_t *start, uint32_t *end, int64_t *dist,
    edge ids of a vertex in creation order (the order of the reference's
    vertex->edges array, graph.c:137-160) */
 int gtsg_get_csr(GtsgEngine *e, uint32_t *row, uint32_t *adj);
+/* ref gt_scaffolder_graph.c:174-193 gt_scaffolder_graph_find_edge: the id of
+   the first edge in vertex_1's list (creation order) that ends in vertex_2,
+   GTSG_NO_EDGE if there is none */
+#define GTSG_NO_EDGE UINT64_MAX
+int gtsg_find_edge(GtsgEngine *e, uint64_t vertex_1, uint64_t vertex_2, uint64_t *eid);
+/* ref gt_scaffolder_graph.c:219-235 gt_scaffolder_graph_alter_edge: new
+   distance, deviation, pair count and sense / same for edge `eid`; its state
+   and the edge created with it in the other direction are left alone */
+int gtsg_alter_edge(GtsgEngine *e, uint64_t eid, int64_t dist, float std_dev, uint64_t num_pairs,
+                    int sense, int same);
 /* order-independent 64-bit digest of (vertex states, edge states by id),
    computed on the device: used to compare full-size runs */
 int gtsg_state_digest(GtsgEngine *e, uint64_t *vertex_digest,

@@ -39,6 +39,27 @@ int gt_scaffolder_graph_add_vertex(GtScaffolderGraph *graph, const char *header_
 int gt_scaffolder_graph_add_edge(GtScaffolderGraph *graph, uint64_t vstart,
                                  uint64_t vend, int64_t dist, float std_dev,
                                  uint64_t num_pairs, bool dir, bool same);
+/* ref gt_scaffolder_graph.h:127-146, gt_scaffolder_graph.c:174-244.  Vertices
+   and edges are named by their ids (the reference hands out pointers into its
+   two arrays; an id is that pointer minus the array base):
+     find_edge      the first edge of vertex_1's list that ends in vertex_2,
+                    GT_SCAFFOLDER_NO_EDGE where the reference returns NULL
+     get_vertex_id  the id of a vertex (the identity here; GT_SCAFFOLDER_NO_VERTEX
+                    out of range)
+     get_vertex     the vertex with this header (binary search: the vertices
+                    are in header order after count_distances / read_distances)
+     alter_edge     new distance, deviation, pair count, sense and same for one
+                    edge, before or after the graph has moved to the GPU; -1 for
+                    an edge that does not exist (the reference asserts) */
+#define GT_SCAFFOLDER_NO_EDGE UINT64_MAX
+#define GT_SCAFFOLDER_NO_VERTEX UINT64_MAX
+uint64_t gt_scaffolder_graph_find_edge(GtScaffolderGraph *graph, uint64_t vertex_1,
+                                       uint64_t vertex_2);
+uint64_t gt_scaffolder_graph_get_vertex_id(const GtScaffolderGraph *graph, uint64_t vertex);
+bool gt_scaffolder_graph_get_vertex(const GtScaffolderGraph *graph, uint64_t *vertex,
+                                    const char *header_seq);
+int gt_scaffolder_graph_alter_edge(GtScaffolderGraph *graph, uint64_t edge, int64_t dist,
+                                   float std_dev, uint64_t num_pairs, bool sense, bool same);
 /* ref gt_scaffolder_graph.c:346 */
 int gt_scaffolder_graph_new_from_file(GtScaffolderGraph **graph_par,
                                       const char *ctg_filename,

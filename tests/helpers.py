@@ -71,7 +71,7 @@ def hostsim():
         L.hs_filter.argtypes = [C.c_uint32, C.c_uint32] + [vp] * 12 + [C.c_float, C.c_float, C.c_int64]
         L.hs_filter.restype = C.c_uint32
         L.hs_components.argtypes = [C.c_uint32, C.c_uint32] + [vp] * 8 + [C.c_int, C.c_uint32,
-                                                                         C.c_uint64, vp, vp, C.c_int, vp, vp, vp, C.c_uint32, vp]
+                                                                         C.c_uint64, vp, vp, C.c_int, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32]
         L.hs_components.restype = C.c_uint32
         _HS = L
     return _HS
@@ -101,7 +101,8 @@ class HostSimGraph:
                                 _p(g["eid"]), pcutoff, cncutoff, ocutoff)
         self.rounds = (r >> 16, r & 0xFFFF)
 
-    def _components(self, mode, wq_factor=8, max_pops=1 << 40, fast_walks=1, defer_min_nv=0):
+    def _components(self, mode, wq_factor=8, max_pops=1 << 40, fast_walks=1, defer_min_nv=0,
+                    defer_ref_min_nv=0):
         g = self.g
         nc = C.c_uint32()
         mc = C.c_uint32()
@@ -114,7 +115,8 @@ class HostSimGraph:
                                        _p(self.vstate), _p(g["end"]), _p(g["dist"]), _p(g["flags"]),
                                        _p(self.state), _p(g["twin"]), mode, wq_factor, max_pops,
                                        C.byref(nc), C.byref(mc), fast_walks, C.byref(nf),
-                                       C.byref(ns), C.byref(ncl), defer_min_nv, C.byref(ndf), C.byref(nrd))
+                                       C.byref(ns), C.byref(ncl), defer_min_nv, C.byref(ndf), C.byref(nrd),
+                                       defer_ref_min_nv)
         self.ncomp, self.maxcomp = nc.value, mc.value
         self.fast_walks, self.slow_walks, self.clean_components = nf.value, ns.value, ncl.value
         self.deferred_components = ndf.value

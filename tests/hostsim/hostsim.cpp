@@ -130,7 +130,8 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
                        uint64_t max_pops, uint32_t *out_ncomp,
                        uint32_t *out_maxcomp, int fast_walks,
                        uint64_t *out_fast, uint64_t *out_slow, uint64_t *out_clean,
-                       uint32_t defer_min_nv, uint64_t *out_deferred, uint64_t *out_rounds)
+                       uint32_t defer_min_nv, uint64_t *out_deferred, uint64_t *out_rounds,
+                       uint32_t defer_ref_min_nv)
 {
   GtsGraphView G = {n, m, row, seq_len, nullptr, nullptr, vstate, end, dist,
                     nullptr, flags, state, twin, nullptr};
@@ -227,7 +228,7 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   C.cerr = cerr.data(); C.max_pops = max_pops;
   std::vector<int64_t> nd(S); std::vector<uint64_t> plen(S); std::vector<uint8_t> tight(S, 0);
   std::vector<uint32_t> sf(ncomp ? ncomp : 1, 0), ss(ncomp ? ncomp : 1, 0);
-  C.fast_walks = fast_walks; C.nd = nd.data(); C.plen = plen.data(); C.tight = tight.data();
+  C.fast_walks = fast_walks; C.batch_walks = 0; C.nd = nd.data(); C.plen = plen.data(); C.tight = tight.data();
   std::vector<uint64_t> tstat(5 * (size_t)(ncomp ? ncomp : 1), 0);
   unsigned long long why[8] = {0};
   std::vector<uint8_t> gorient(S); std::vector<uint32_t> topo(S), tpos(S), sclean(ncomp ? ncomp : 1, 0);
@@ -246,6 +247,7 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   std::vector<uint32_t> paths(path_cap);
   unsigned long long ntasks = 0, path_used = 0;
   C.defer_min_nv = defer_min_nv; C.defer_min_work = 0; C.defer_flag = defer_flag.data();
+  C.defer_ref_min_nv = defer_ref_min_nv; C.task_reference = defer_ref_min_nv != 0;
   C.comp_task0 = comp_task0.data(); C.comp_ncc = comp_ncc.data(); C.comp_nterm = comp_nterm.data();
   unsigned long long task_bytes = 0;
   C.task_bytes = &task_bytes;
@@ -277,7 +279,11 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
       const uint32_t t = tq[q], c = task_comp[t];
       GtsCompMem mem = GtsComponent<GtsWave1>::global_mem(C, c);
       GtsComponent<GtsWave1> prog(C, mem, c);
+      /* the harness runs the tasks of a component one after the other: they
+         share the component's ring (on the device every task carves its own) */
+      prog.qbase = comp_ring[2 * (size_t)c]; prog.qcap = comp_ring[2 * (size_t)c + 1];
       prog.walk_task(t);
+      comp_ring[2 * (size_t)c] = prog.qbase; comp_ring[2 * (size_t)c + 1] = prog.qcap;
     }
     tq_cnt[0] = 0;
     for (uint64_t d = 0; d < ndeferred; d++) {

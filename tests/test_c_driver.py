@@ -41,8 +41,16 @@ def test_c_driver_compiles_links_and_fails_loudly_without_gpu(tmp_path, golden_d
     assert "no CPU path" in r.stderr
 
 
+def test_c_driver_edge_and_vertex_accessors_on_a_handbuilt_graph(tmp_path):
+    # find_edge / get_vertex / get_vertex_id / alter_edge (ref gt_scaffolder_graph.h:127-146)
+    # on a graph built with add_vertex / add_edge: host only, no GPU needed
+    exe = build_driver(tmp_path)
+    r = subprocess.run([exe, "handbuilt"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "handbuilt ok" in r.stdout, r.stderr
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [(), ("stepwise",)])
+@pytest.mark.parametrize("mode", [(), ("stepwise",), ("api",)])
 def test_c_driver_reproduces_reference_dot_files(tmp_path, golden_dir, mode):
     exe = build_driver(tmp_path)
     r = run_driver(exe, tmp_path, golden_dir, *mode)
@@ -52,7 +60,9 @@ def test_c_driver_reproduces_reference_dot_files(tmp_path, golden_dir, mode):
         assert filecmp.cmp(out, "%s/gt_scaffolder_algorithms_test_%s_expected.dot" % (golden_dir, name),
                            shallow=False), name
     assert (tmp_path / "gt_scaffolder_new_write.scaf").stat().st_size > 0
-    if mode:
+    if mode == ("api",):
+        assert "api ok" in r.stdout, r.stdout + r.stderr
+    if mode == ("stepwise",):
         # count_contigs tests >= min_ctg_len, read_contigs > (ref parser.c:408, :481)
         assert "contigs counted 50, distances counted" in r.stdout, r.stdout
 

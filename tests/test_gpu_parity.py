@@ -100,8 +100,12 @@ def test_hub_vertices_take_the_wave_path():
 
 def test_walk_queue_retry():
     g = make_inputs(20000, 5)
-    eng, _ = run_pipeline(g, walk_queue_factor=1, fast_walks=0)
+    # a walk that overflows its ring takes a larger one from the pool; with a
+    # pool too small for that the whole call runs again with more room
+    eng, _ = run_pipeline(g, walk_queue_factor=1, fast_walks=0, walk_pool_entries=4096)
     assert eng.stat("walk_retries") >= 1
+    eng1, _ = run_pipeline(g, walk_queue_factor=1, fast_walks=0)
+    assert eng1.stat("walk_retries") == 0 and eng1.digest() == eng.digest()
 
 
 @pytest.mark.parametrize("seed", range(2))
@@ -708,3 +712,57 @@ def test_route_kernels_match_the_torch_packing():
     bad = dict(rec); bad["ctg"] = rec["ctg"].clone(); bad["ctg"][7] = n
     with pytest.raises(pkg.engine.EngineError, match="out of range"):
         eng.route_pack(bad, first, owner.to(torch.int8), world)
+
+
+def test_find_edge_and_alter_edge_match_a_relisted_record():
+    """ref gt_scaffolder_graph.c:174-235: alter_edge on the edge find_edge returns
+    is what a later record of the same (root, contig) with a larger std_dev does
+    (parser.c:357-366), so the oracle built from the records plus such records
+    must give the same graph and, through the whole pipeline, the same states"""
+    g = make_inputs(3000, 77, p_chimeric=0.05, unique_pairs=True)
+    eng = engine_from_inputs(g)
+    rng = np.random.default_rng(5)
+    picks = rng.choice(len(g["root"]), 40, replace=False)
+    extra = {k: [] for k in ("root", "ctg", "dist", "std_dev", "num_pairs", "flags")}
+    for k in picks:
+        r, c = int(g["root"][k]), int(g["ctg"][k])
+        eid = eng.find_edge(r, c)
+        assert eid is not None
+        nd, nsd, nnp = int(g["dist"][k]) + 37, float(g["std_dev"].max()) + 100.0 + k % 7, 3 + k % 5
+        fl = int(rng.integers(0, 4))
+        eng.alter_edge(eid, nd, nsd, nnp, fl & 1, fl >> 1 & 1)
+        for name, val in zip(extra, (r, c, nd, nsd, nnp, fl)):
+            extra[name].append(val)
+    r0 = int(g["root"][0])
+    assert eng.find_edge(r0, r0) is None     # (the generator draws no self loops)
+    g2 = dict(g)
+    for name in extra:
+        g2[name] = np.concatenate([g[name], np.array(extra[name], dtype=g[name].dtype)])
+    og = oracle_from_inputs(g2)
+    assert_same_graph(eng, og)
+    og.mark_repeats(); eng.mark_repeats()
+    og.filter(); eng.filter()
+    og.makescaffold(True); eng.makescaffold()
+    assert_same_states(eng, og, "makescaffold after alter_edge")
+
+
+def test_pool_wait_bound_leaves_a_graph_that_can_be_scaffolded_again():
+    """every wait inside k_components_pool is bounded; a wavefront that runs into
+    the bound leaves without entering what it waited for, the call returns
+    GTSG_EINTERNAL and the states are those before the call (as for GTSG_EWALK),
+    so the same call with the default bound then gives the oracle's result.
+    pool_wait_limit_us = 0 makes every contended lock a bound that was hit."""
+    g = make_inputs(30000, 8, p_chimeric=0.02)
+    og = oracle_from_inputs(g)
+    eng = engine_from_inputs(g)
+    og.mark_repeats(); eng.mark_repeats()
+    og.filter(); eng.filter()
+    eng.set_option("pool_wait_limit_us", 0)
+    with pytest.raises(pkg.engine.EngineError) as ei:
+        eng.makescaffold()
+    assert "(code -6)" in str(ei.value) and "states restored" in str(ei.value)
+    assert eng.stat("pool_gave_up_lock") > 0
+    assert_same_states(eng, og, "after the failed call")
+    eng.set_option("pool_wait_limit_us", 10_000_000)
+    og.makescaffold(True); eng.makescaffold()
+    assert_same_states(eng, og, "makescaffold after a failed call")

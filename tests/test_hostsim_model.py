@@ -150,7 +150,28 @@ def test_deferred_walks_give_the_same_scaffolds(seed):
     assert np.array_equal(og.edge_states(), hs.edge_states())
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(fast_walks=0), dict(defer_min_nv=2)])
+@pytest.mark.parametrize("seed", range(6))
+def test_reference_search_walks_as_tasks(seed):
+    # a component that meets a walk the linear-time walks cannot make (inversions:
+    # a contig walked in both directions) stops at that cc and hands the walks of
+    # the ccs it has not decided to tasks, which replay the reference's search
+    # themselves; forced here from 2 contigs on
+    kw = dict(p_chimeric=0.08, p_inversion=1.0, p_bubble=0.04, p_relist=0.05 * (seed % 2))
+    if seed >= 3:
+        kw.update(links_per_side=5, p_repeat=0.03, repeat_degree=43)
+    g = make_inputs(3000 if seed < 3 else 9000, 1700 + seed, **kw)
+    og = oracle_from_inputs(g)
+    hs = HostSimGraph(csr_from_oracle(og))
+    og.mark_repeats(); hs.mark_repeats(); og.filter(); hs.filter()
+    og.makescaffold(True)
+    assert hs.makescaffold(fast_walks=1, defer_ref_min_nv=2) == 0
+    assert hs.deferred_components > 0 and hs.walk_task_rounds >= 1 and hs.slow_walks > 0
+    assert np.array_equal(og.vertex_states(), hs.vertex_states())
+    assert np.array_equal(og.edge_states(), hs.edge_states())
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(fast_walks=0), dict(defer_min_nv=2), dict(defer_ref_min_nv=2),
+                                dict(fast_walks=0, defer_ref_min_nv=2)])
 def test_handmade_fixtures_through_the_component_programs(golden_dir, kw):
     """the hand-derived fixtures (tests/golden/handmade) through the engine's
     algorithm bodies on the host: plain, reference-search walks, deferred walks
