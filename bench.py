@@ -189,6 +189,50 @@ def cpu_baseline(pkg, n_sample, gen, seed):
                        % (n_sample, og.ne, dt)), og, g
 
 
+def cpu_baseline_full_size():
+    """The oracle on the WHOLE 10 M-contig / 100 M-edge configuration: a recording
+    (tests/golden/full_size_digest.json, made by tools/make_full_size_digest.py
+    in the build container -- the run takes 36 minutes, the bench must not), next
+    to the sample timed live on this host."""
+    path = os.path.join(ROOT, "tests", "golden", "full_size_digest.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    secs = {k: v for k, v in d["oracle_seconds"].items() if k != "generate"}   # build, mark_repeats + filter, makescaffold
+    total = float(sum(secs.values()))
+    return dict(value=d["n_edges"] / total, unit="edges/s", cores=1, kind="port", seconds=round(total, 1),
+                stages_s={k: round(v, 1) for k, v in secs.items()}, edges=d["n_edges"], contigs=d["n_contigs"],
+                host="build container (no GPU), one core", recorded=True,
+                source="tests/golden/full_size_digest.json (tools/make_full_size_digest.py: portable generator, "
+                       "seed %d; the GPU test test_full_size_against_oracle_digest compares the engine's "
+                       "states on the same inputs with this run's digests)" % d["seed"])
+
+
+def secondary_workload(pkg, eng, dev, torch, n_contigs, steps=2):
+    """The slow path next to the headline, outside its timed region: the same
+    generator with 10 % of the false links drawn as inversions and repeated
+    contig pairs kept -- components where a contig is walked in both directions
+    leave the linear-time walks for the reference's FIFO search."""
+    gen = dict(WORKLOADS["10M"]["gen"], p_inversion=0.1, unique_pairs=False)
+    g = pkg.synth.make_graph(n_contigs, seed=1234, device=dev, **gen)
+    g["num_pairs"] = g["num_pairs"].to(torch.int64)
+    torch.cuda.empty_cache()
+    run_step(eng, g)                                   # warm-up (workspace growth)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges = 0
+    for _ in range(steps):
+        edges += run_step(eng, g)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(workload="synthetic %d-contig scaffold graph, 10 %% of the false links inversions, repeated "
+                         "contig pairs kept" % n_contigs,
+                steps=steps, ms_per_step=dt / steps * 1e3, value=edges / dt, unit="edges/s",
+                edges=eng.ne, walks_reference=eng.stat("slow_walks"), walks_fast=eng.stat("fast_walks"),
+                walk_tasks=eng.stat("walk_tasks"), walk_task_rounds=eng.stat("walk_task_rounds"),
+                deferred_components=eng.stat("deferred_components"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +245,8 @@ def main():
                     help="contigs per GPU (default: the workload's own size)")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary (inversions) workload reported next to the headline")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option (gtsg_set_option), e.g. defer_min_contigs=256")
@@ -411,6 +457,9 @@ def main():
                                                   "why_marked_end", "why_two_directions",
                                                   "why_inexact_tie", "why_cycle",
                                                   "why_inexact_length_tie")},
+                       team={k[5:]: eng.stat(k) for k in
+                             ("team_components", "team_ccs", "team_batches", "team_sweep_steps", "team_ccs_with_tie",
+                              "team_us_clear", "team_us_sweep", "team_us_paths", "team_us_wave0_barriers")},
                        walk_tasks=eng.stat("walk_tasks"), walk_task_rounds=eng.stat("walk_task_rounds"),
                        walk_task_runs=eng.stat("walk_task_runs"),
                        deferred_components=eng.stat("deferred_components"),
@@ -420,7 +469,7 @@ def main():
                                 for i, b in enumerate(("2", "3", "4", "8", "16", "32", "64", "inf"))},
                        slowest_components=[
                            {k: eng.stat("top%d_%s" % (r, k)) for k in
-                            ("size", "edges", "terminals", "clean", "deferred", "why_not_deferred", "walks",
+                            ("size", "edges", "terminals", "ccs", "clean", "deferred", "why_not_deferred", "walks",
                              "ref_walks", "removecycles_us", "other_us", "walks_us", "ref_us", "ref_pops")}
                            for r in range(12)]),
                    hbm_resident=dict(graph_bytes=eng.stat("bytes_graph"),
@@ -436,7 +485,16 @@ def main():
                                                          for k, v in stage_s.items()}
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
             cb, og, gs = cpu_baseline(pkg, args.cpu_sample, WORKLOAD["gen"], 99)
+            if args.workload == "10M":
+                cb["full_size"] = cpu_baseline_full_size()
             out["cpu_baseline"] = cb
+        if (not args.no_secondary and world == 1 and mode == "shards" and args.workload == "10M"
+                and args.inversions is None and not args.duplicate_pairs):
+            # outside the timed region of the headline: its inputs are released first
+            g = None
+            torch.cuda.empty_cache()
+            eng.set_option("profile", 0)
+            out["secondary"] = [secondary_workload(pkg, eng, dev, torch, args.contigs)]
         if args.verify:
             from oracle.oracle_py import OracleGraph
             gn = pkg.synth.to_numpy(g)

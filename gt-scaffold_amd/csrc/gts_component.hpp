@@ -80,6 +80,11 @@ struct GtsCompView {
   /* linear-time walk (create_walk_fast) */
   int fast_walks;            /* 0: always run the reference's search */
   int batch_walks;           /* LDS-resident clean components: the walks of a cc side by side */
+  char *team_slab;           /* k_components_team: walk slots and path buffers of the workgroups */
+  unsigned long long *team_used;   /* bytes handed out */
+  unsigned long long *team_stat;   /* [8] statistics: ccs posted, batches, sweep steps, ccs with a tie,
+                                      ticks clearing slots / sweeping / extracting paths / wavefront 0 at the barriers */
+  uint64_t team_cap;
   int64_t *nd;               /* slot -> integer label pushed with the node */
   uint64_t *plen;            /* slot -> contig length of the tree path */
   uint8_t *tight;            /* slot -> number of tight in-arcs (saturating) */
@@ -124,12 +129,30 @@ struct GtsCompView {
   uint32_t *wbits;           /* nslots / 32 + ncomp + 1 words: select_walks' bitmap of component c
                                 starts at comp_off[c] / 32 + c */
   uint32_t *stat_fast, *stat_slow;  /* per component: walks by path taken */
+  uint32_t *stat_ncc;        /* per component: ccs of the last terminal search */
   unsigned long long *why;   /* [8] why walks left the linear path: mixed start,
                                 self arc, back at start, marked end, two
                                 directions, inexact tie, cycle, inexact length tie */
   uint64_t *tstat;           /* per component x5: ticks in removecycles, makescaffold
                                 outside walks, fast walks, reference walks; pops of
                                 the reference walks */
+};
+
+/* A component that runs from global memory with a whole workgroup ("team",
+   k_components_team): wavefront 0 runs the component program; when it comes to
+   the walks of a cc -- independent of each other, ref algorithms.c:809-832 -- it
+   posts the cc here, every wavefront of the workgroup sweeps batches of eight of
+   its terminals (walks_clean_batch_global) and leaves the best walk it has seen. */
+#define GTS_TEAM_WAVES_MAX 16
+struct GtsTeamCtl {
+  uint32_t kind;             /* 1: walks of the cc [tb, te); 0: done, the helpers leave */
+  uint32_t tb, te;
+  uint32_t slab_ok;
+  unsigned long long slab;   /* byte offset of the workgroup's slab */
+  unsigned long long len[GTS_TEAM_WAVES_MAX];   /* per wavefront: its longest walk, */
+  uint32_t j[GTS_TEAM_WAVES_MAX];               /* the first terminal (index) that attains it, */
+  uint32_t n[GTS_TEAM_WAVES_MAX];               /* its number of edges (the path is in the slab) */
+  uint32_t bad[GTS_TEAM_WAVES_MAX];             /* a walk of its batches met a tie */
 };
 
 /* Pointer type of the component's working set: generic pointers into the
@@ -292,7 +315,9 @@ GTS_HD uint32_t gts_walk_slot_bytes(uint32_t nv)
   return 2 * p4 + 2 * p2;
 }
 #define GTS_WALK_SLOTS_MAX 8u
+#ifndef GTS_WALK_LANES
 #define GTS_WALK_LANES 8u   /* lanes of a walk in a batch: 8 walks per wavefront */
+#endif
 /* LDS bytes a component asks for: its footprint plus, from `big_nv` contigs
    on, room for up to `big_slots` walk slots (as many as fit `limit`): the
    walks of a large component are the critical path of the launch, and a cc's
@@ -340,11 +365,15 @@ struct GtsComponent {
                            select_walks (task_reference = 0), makescaffold hands it to a task */
   bool needs_reference;
   bool deferred_late;   /* makescaffold stopped at a cc and published the rest as tasks */
+  /* k_components_team */
+  GtsTeamCtl *team;     /* null: no team */
+  char *team_base;      /* this workgroup's slab */
+  uint32_t team_wave, team_waves;
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -1866,6 +1895,250 @@ struct GtsComponent {
     return ok;
   }
 
+
+  /* ---- the walks of a cc on a team of wavefronts (global memory) ---------------
+     Slab of a workgroup: per wavefront GTS_WALK_SLOTS_MAX walk slots -- label
+     (f32), tree-path length (u64), edgemap, parent (u32) per contig and a bitmap
+     over the sweep positions -- and a buffer for the best path it has seen. */
+  static GTS_HD uint64_t team_slot_bytes(uint32_t nv)
+  {
+    const uint64_t a = 16, n = nv;
+    return ((n * 4 + a - 1) / a) * a * 3 + ((n * 8 + a - 1) / a) * a + ((((n + 31) / 32) * 4 + a - 1) / a) * a;
+  }
+  static GTS_HD uint64_t team_wave_bytes(uint32_t nv)
+  {
+    return GTS_WALK_SLOTS_MAX * team_slot_bytes(nv) + (((uint64_t)nv * 4 + 15) / 16) * 16;
+  }
+
+  /* walks_clean_batch for a component in global memory: the next labelled
+     vertex of a sweep comes from the slot's bitmap over the positions (a walk
+     costs its reachable set, not the component: create_walk_clean), eight words
+     a step */
+  template <uint32_t L>
+  GTS_HD void walks_clean_batch_global(uint32_t j0, uint32_t nb, char *slots, uint64_t &r_len,
+                                       uint32_t &r_t, bool &r_bad)
+  {
+    const uint32_t lane = W::lane(), g = lane / L, a = lane % L;
+    const uint32_t gsh = g * L;
+    const uint64_t gm = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
+    const uint64_t a16 = 16, p4 = (((uint64_t)nv * 4 + a16 - 1) / a16) * a16, p8 = (((uint64_t)nv * 8 + a16 - 1) / a16) * a16;
+    const uint32_t nw = (nv + 31) / 32;
+    bool active = g < nb;
+    char *sbase = slots + (uint64_t)(active ? g : 0u) * team_slot_bytes(nv);
+    float *dist = (float *)sbase;
+    uint64_t *plen = (uint64_t *)(sbase + p4);
+    uint32_t *emap = (uint32_t *)(sbase + p4 + p8);
+    uint32_t *par = (uint32_t *)(sbase + 2 * p4 + p8);
+    uint32_t *pbits = (uint32_t *)(sbase + 3 * p4 + p8);
+    const uint32_t start = active ? (uint32_t)M.term[j0 + g] : 0u;
+    const uint32_t sb0 = M.coff[start] - M.e0, se0 = M.coff[start + 1] - M.e0;
+    bool hs = false, ha = false;
+    for (uint32_t cur0 = sb0; W::ballot(active && cur0 < se0); cur0 += L) {
+      const uint32_t ce = cur0 + a;
+      const bool in = active && ce < se0;
+      const uint32_t fs = edge_bits(in ? ce : sb0);
+      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+      const bool sense = (fs & GTS_F_SENSE) != 0;
+      const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
+      hs |= ((bs >> gsh) & gm) != 0;
+      ha |= ((ba >> gsh) & gm) != 0;
+    }
+    bool bad = active && hs && ha;
+    if (bad || !(hs || ha)) active = false;
+    const bool forward = hs == ((M.gorient[start] & 3u) == 2);
+    const int32_t step = forward ? 1 : -1;
+    int32_t wcur = (int32_t)(M.tpos[start] >> 5);
+    bool have_u = active, is_start = true;
+    uint32_t u = start, cur = sb0, ub = sb0, ue = se0;
+    bool du = hs, us = false, ua = false;
+    int64_t ndu = 0;
+    uint64_t plu = (uint64_t)M.cseq[start], best_len = 0;
+    uint32_t pending = 0, best_t = GTS_NONE, steps = 0;
+    while (W::ballot(active)) {
+      ++steps;
+      /* (1) the next labelled position: eight words of the bitmap a step */
+      const bool scan = active && !have_u;
+      const int32_t wi = wcur + (int32_t)a * step;
+      const bool inr = scan && wi >= 0 && wi < (int32_t)nw;
+      const uint32_t word = inr ? pbits[wi] : 0u;
+      const uint64_t rb = (W::ballot(word != 0) >> gsh) & gm;
+      const uint32_t k = rb ? W::ctz(rb) : 0u;
+      const uint32_t wk = W::shfl(word, gsh + k);          /* the word of the group's lane k */
+      if (scan) {
+        if (rb) {
+          const uint32_t bit = forward ? W::ctz((uint64_t)wk) : 31u - W::clz32(wk);
+          wcur += (int32_t)k * step;
+          if (a == 0) W::and_bits(pbits + wcur, ~(1u << bit));
+          u = M.topo[(uint32_t)wcur * 32u + bit];
+          have_u = true; is_start = false; us = ua = false;
+          --pending;
+          ub = cur = M.coff[u] - M.e0; ue = M.coff[u + 1] - M.e0;
+          du = ((M.gorient[u] & 3u) == 2) == forward;
+          ndu = (int64_t)dist[u];
+          plu = plen[u];
+        } else {
+          wcur += (int32_t)L * step;
+          if (wcur < 0 || wcur >= (int32_t)nw) active = false;
+        }
+      }
+      /* (2) up to L arcs of the current vertex */
+      const bool proc = active && have_u;
+      const uint32_t ce = cur + a;
+      const bool in = proc && ce < ue;
+      const uint32_t cec = in ? ce : ub;
+      const uint32_t fs = edge_bits(cec);
+      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+      const bool sense = (fs & GTS_F_SENSE) != 0;
+      const bool arc = live && sense == du;
+      const uint32_t v = M.cend[cec];
+      const int64_t w = (int64_t)M.cdist[cec];
+      const float cand = (float)(ndu + w);
+      const float old = dist[v];
+      const bool imp = arc && (old == GTS_DIST_UNSET || old > cand);
+      const bool tie = arc && !imp && old == cand;
+      const bool fresh = imp && old == GTS_DIST_UNSET;
+      /* the node of a child of the start carries the distance itself, not its
+         float image (create_walk_clean: nd[v] = w): the same below 2^24 */
+      const bool wide = arc && is_start && !(w > -16777216 && w < 16777216);
+      if (imp) {
+        dist[v] = cand;
+        emap[v] = ce;
+        par[v] = u;
+        plen[v] = plu + (uint64_t)M.cseq[v];
+      }
+      if (fresh) { const uint32_t tp = M.tpos[v]; W::or_bits(pbits + (tp >> 5), 1u << (tp & 31)); }
+      const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
+      const uint64_t fm = W::ballot(fresh), tm = W::ballot(tie || wide);
+      us |= ((bs >> gsh) & gm) != 0;
+      ua |= ((ba >> gsh) & gm) != 0;
+      pending += W::popc((fm >> gsh) & gm);
+      if ((tm >> gsh) & gm) bad = true;
+      if (proc) {
+        cur += L;
+        if (cur >= ue) {
+          if (!is_start && !(us && ua)) {
+            if (plu > best_len) { best_len = plu; best_t = u; }
+            else if (plu == best_len && best_t != GTS_NONE) bad = true;
+          }
+          have_u = false;
+          if (pending == 0) active = false;
+        }
+      }
+      if (bad) active = false;
+      W::fence();
+    }
+    if (lane == 0) W::add64((uint64_t *)C.team_stat + 2, steps);
+    r_len = best_len; r_t = best_t; r_bad = bad;
+  }
+
+  /* this wavefront's share of the walks of the cc [tb, te): batches
+     team_wave, team_wave + team_waves, ...; result in the team's control block */
+  /* few terminals: more lanes per walk (the lists of a hub vertex and the
+     bitmap are swept L entries a step) */
+  GTS_HD void team_share(uint32_t tb, uint32_t te)
+  {
+    if (te - tb <= 2) team_share_t<32>(tb, te);
+    else if (te - tb <= 4) team_share_t<16>(tb, te);
+    else team_share_t<8>(tb, te);
+  }
+  template <uint32_t L>
+  GTS_HD void team_share_t(uint32_t tb, uint32_t te)
+  {
+    const uint32_t lane = W::lane();
+    constexpr uint32_t G = W::WIDTH / L;
+    const uint64_t sbytes = team_slot_bytes(nv);
+    char *wbase = team_base + (uint64_t)team_wave * team_wave_bytes(nv);
+    uint32_t *path = (uint32_t *)(wbase + GTS_WALK_SLOTS_MAX * sbytes);
+    const uint64_t a16 = 16, p4 = (((uint64_t)nv * 4 + a16 - 1) / a16) * a16, p8 = (((uint64_t)nv * 8 + a16 - 1) / a16) * a16;
+    const uint32_t nw = (nv + 31) / 32;
+    uint64_t best_len = 0;
+    uint32_t best_j = GTS_NONE, best_n = 0;
+    bool bad = false;
+    for (uint32_t b = team_wave; b * G < te - tb && !bad; b += team_waves) {
+      const uint32_t j0 = tb + b * G, nb = te - j0 < G ? te - j0 : G;
+      const uint64_t tc0 = W::clock();
+      for (uint32_t k = 0; k < nb; ++k) {
+        float *dist = (float *)(wbase + k * sbytes);
+        uint32_t *pb = (uint32_t *)(wbase + k * sbytes + 3 * p4 + p8);
+        for (uint32_t s = lane; s < nv; s += W::WIDTH) dist[s] = GTS_DIST_UNSET;
+        for (uint32_t s = lane; s < nw; s += W::WIDTH) pb[s] = 0;
+      }
+      W::fence();
+      const uint64_t tc1 = W::clock();
+      uint64_t r_len;
+      uint32_t r_t;
+      bool r_bad;
+      walks_clean_batch_global<L>(j0, nb, wbase, r_len, r_t, r_bad);
+      const uint64_t tc2 = W::clock();
+      if (lane == 0) {
+        W::add64((uint64_t *)C.team_stat + 1, 1); W::add64((uint64_t *)C.team_stat + 4, tc1 - tc0);
+        W::add64((uint64_t *)C.team_stat + 5, tc2 - tc1);
+      }
+      if (W::ballot(r_bad)) { bad = true; break; }
+      uint32_t wg = GTS_NONE;
+      for (uint32_t k = 0; k < nb; ++k) {
+        const uint64_t len = (uint64_t)W::bcast((uint32_t)r_len, k * L) |
+                             (uint64_t)W::bcast((uint32_t)(r_len >> 32), k * L) << 32;
+        if (len > best_len) { best_len = len; wg = k; }
+      }
+      if (wg != GTS_NONE) {
+        const uint32_t *emap = (const uint32_t *)(wbase + wg * sbytes + p4 + p8);
+        const uint32_t *par = (const uint32_t *)(wbase + wg * sbytes + 2 * p4 + p8);
+        const uint32_t start = W::uni((uint32_t)M.term[j0 + wg]);
+        uint32_t cv = W::bcast(r_t, wg * L), n = 0;
+        while (cv != start) {
+          const uint32_t re = W::uni(emap[cv]);
+          if (lane == 0) path[n] = re;
+          ++n;
+          cv = W::uni(par[cv]);
+        }
+        best_j = j0 + wg; best_n = n;
+      }
+      if (lane == 0) W::add64((uint64_t *)C.team_stat + 6, W::clock() - tc2);
+      nfast += nb;
+    }
+    if (lane == 0) {
+      team->len[team_wave] = best_len; team->j[team_wave] = best_j; team->n[team_wave] = best_n;
+      team->bad[team_wave] = bad ? 1u : 0u;
+    }
+    W::fence();
+  }
+
+  /* wavefront 0: posts the cc, takes its share, picks the first strictly
+     longest walk in terminal order (algorithms.c:826-832).  False if a walk
+     met a tie: the caller makes the walks of this cc one by one. */
+  GTS_HD bool cc_walks_team(uint32_t tb, uint32_t te, uint64_t &cc_len, uint32_t &cc_n)
+  {
+    const uint32_t lane = W::lane();
+    if (lane == 0) { team->kind = 1; team->tb = tb; team->te = te; }
+    const uint64_t tb0 = W::clock();
+    W::team_barrier();
+    const uint64_t tb1 = W::clock();
+    team_share(tb, te);
+    const uint64_t tb2 = W::clock();
+    W::team_barrier();
+    if (lane == 0) { W::add64((uint64_t *)C.team_stat, 1); W::add64((uint64_t *)C.team_stat + 7, (tb1 - tb0) + (W::clock() - tb2)); }
+    uint64_t best = 0;
+    uint32_t bj = GTS_NONE, bw = 0;
+    bool bad = false;
+    for (uint32_t w = 0; w < team_waves; ++w) {
+      bad |= team->bad[w] != 0;
+      const uint64_t len = team->len[w];
+      const uint32_t j = team->j[w];
+      if (j != GTS_NONE && (len > best || (len == best && j < bj))) { best = len; bj = j; bw = w; }
+    }
+    if (bad) { if (lane == 0) W::add64((uint64_t *)C.team_stat + 3, 1); return false; }
+    if (bj != GTS_NONE && best > cc_len) {
+      const uint32_t *path = (const uint32_t *)(team_base + (uint64_t)bw * team_wave_bytes(nv) +
+                                                GTS_WALK_SLOTS_MAX * team_slot_bytes(nv));
+      const uint32_t n = team->n[bw];
+      for (uint32_t k = lane; k < n; k += W::WIDTH) M.cc_best[k] = path[k];
+      cc_len = best; cc_n = n;
+      W::fence();
+    }
+    return true;
+  }
+
   GTS_HD bool create_walk(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     /* (the reference's test for a start without any edge, algorithms.c:655,
@@ -1930,6 +2203,14 @@ struct GtsComponent {
             if (clean && C.fast_walks && C.batch_walks && M.wslots >= 2) {
               const uint64_t tw0 = W::clock();
               batched = cc_walks_batched<GTS_WALK_LANES>(tb, te, cc_len, cc_n);
+              tfast += W::clock() - tw0;
+              if (!batched) { cc_len = 0; cc_n = 0; }
+            }
+          }
+          if constexpr (W::TEAM) {
+            if (clean && C.fast_walks && team) {
+              const uint64_t tw0 = W::clock();
+              batched = cc_walks_team(tb, te, cc_len, cc_n);
               tfast += W::clock() - tw0;
               if (!batched) { cc_len = 0; cc_n = 0; }
             }
@@ -2281,7 +2562,7 @@ struct GtsComponent {
       C.G.vstate[C.slot_v[s0 + s]] = st;
     }
     if (lane == 0) {
-      C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow;
+      C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow; C.stat_ncc[c] = ncc;
       C.stat_clean[c] = (was_clean ? 1u : 0u) | (deferred ? 2u : 0u) | (nodefer << 2) | (nterm << 8);
       C.tstat[5 * (uint64_t)c] = t1 - t0;
       C.tstat[5 * (uint64_t)c + 1] = t2 - t1 - tfast - tslow;
@@ -2296,6 +2577,8 @@ struct GtsComponent {
 /* host / test wave policy: one lane */
 struct GtsWave1 {
   static const uint32_t WIDTH = 1;
+  static const bool TEAM = false;
+  static GTS_HD void and_bits(uint32_t *p, uint32_t m) { *p &= m; }
   static GTS_HD uint32_t lane() { return 0; }
   static GTS_HD uint64_t ballot(bool p) { return p ? 1u : 0u; }
   static GTS_HD uint32_t popc(uint64_t m) { return (uint32_t)(m & 1u); }

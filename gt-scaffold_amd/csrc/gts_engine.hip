@@ -60,6 +60,8 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_POOL_WAVES 16u /* wavefronts of a k_components_pool workgroup (one per CU) */
 #define GTS_S_POOLCUR 392  /* u64: claim counter of k_components_pool */
 #define GTS_S_POOLSTAT 400 /* 10 x u64: clocks, give-up and overrun counts of k_components_pool */
+#define GTS_S_TEAMUSED 424 /* u64: bytes of the team slab handed out */
+#define GTS_S_TEAMSTAT 432 /* 8 x u64: statistics of k_components_team */
 
 static const char *klass_event(int makescaffold, uint32_t bytes)
 {
@@ -152,6 +154,10 @@ struct GtsgEngine {
   int64_t defer_global_components = 0;
   int64_t global_task_pool_mb = 2048;   /* scratch slabs of the walks deferred from global-memory components */
   char *gtask_pool = nullptr;
+  /* components that run from global memory get a workgroup each (k_components_team)
+     when there are few of them: the walks of a cc over its wavefronts */
+  int64_t team_components = 1, team_max_components = 512, team_pool_mb = 4096;
+  char *team_pool = nullptr;
   int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
   /* profiling */
   struct Pending { const char *name; hipEvent_t a, b; };
@@ -434,18 +440,32 @@ __global__ void k_row_offsets(const uint32_t *sorted_start, uint32_t *row,
   for (uint32_t v = lo; v <= hi; ++v) row[v] = (uint32_t)i;
 }
 
+#define GTS_GATHER_UNROLL 4
 __global__ void k_gather_csr(const uint32_t *perm, const GtsEdgeRec *rec,
                              uint32_t *eend, int64_t *dist, int64_t *npairs,
                              float *sd, uint8_t *flags, uint8_t *state,
                              uint32_t *pos_of_eid, uint32_t m)
 {
-  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= m) return;
-  const uint32_t id = perm[p];
-  const GtsEdgeRec r = rec[id];
-  eend[p] = r.end; dist[p] = r.dist; npairs[p] = r.npairs; sd[p] = r.sd;
-  flags[p] = (uint8_t)r.flags; state[p] = GIS_UNVISITED;
-  pos_of_eid[id] = (uint32_t)p;
+  /* four edges a thread, the four random 32-byte records in flight together:
+     one dependent gather per thread leaves the memory system idle (1.4 TB/s) */
+  const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x) * GTS_GATHER_UNROLL + threadIdx.x;
+  uint32_t id[GTS_GATHER_UNROLL];
+  GtsEdgeRec r[GTS_GATHER_UNROLL];
+#pragma unroll
+  for (int k = 0; k < GTS_GATHER_UNROLL; ++k) {
+    const uint64_t p = base + (uint64_t)k * blockDim.x;
+    id[k] = p < m ? perm[p] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < GTS_GATHER_UNROLL; ++k) r[k] = rec[id[k]];
+#pragma unroll
+  for (int k = 0; k < GTS_GATHER_UNROLL; ++k) {
+    const uint64_t p = base + (uint64_t)k * blockDim.x;
+    if (p >= m) continue;
+    eend[p] = r[k].end; dist[p] = r[k].dist; npairs[p] = r[k].npairs; sd[p] = r[k].sd;
+    flags[p] = (uint8_t)r[k].flags; state[p] = GIS_UNVISITED;
+    pos_of_eid[id[k]] = (uint32_t)p;
+  }
 }
 __global__ void k_twins(const uint32_t *eid, const uint32_t *pos_of_eid,
                         uint32_t *twin, uint32_t m)
@@ -952,6 +972,8 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
 /* gfx950 wave policy of gts_component.hpp */
 struct GtsWave64 {
   static const uint32_t WIDTH = 64;
+  static const bool TEAM = false;
+  static __device__ __forceinline__ void and_bits(uint32_t *p, uint32_t m) { atomicAnd(p, m); }
   static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
   static __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
   static __device__ __forceinline__ uint32_t popc(uint64_t m) { return (uint32_t)__popcll(m); }
@@ -1034,6 +1056,74 @@ k_components(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t coun
   const GtsCompMem M = GtsComponent<GtsWave64>::global_mem(C, c);
   GtsComponent<GtsWave64> prog(C, M, c);
   prog.run(mode);
+}
+
+/* Global-memory variant with a team: a workgroup of GTS_TEAM_WAVES wavefronts
+   per component.  Wavefront 0 runs the component program; the others wait for
+   the ccs it posts (GtsTeamCtl) and sweep their share of the cc's walks.  Every
+   wavefront meets every barrier: two per posted cc, one for the end. */
+#define GTS_TEAM_WAVES 8u
+struct GtsWave64Team : GtsWave64 {
+  static const bool TEAM = true;
+  static __device__ __forceinline__ void team_barrier() { __syncthreads(); }
+};
+__global__ void __launch_bounds__(GTS_TEAM_WAVES * GTS_WAVE)
+k_components_team(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
+                  uint32_t lds_bytes)
+{
+  __shared__ GtsTeamCtl ctl;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x >= count) return;
+  const uint32_t c = order[first + blockIdx.x];
+  const uint32_t wv = threadIdx.x / GTS_WAVE;
+  C.defer_min_nv = 0; C.defer_ref_min_nv = 0;
+  GtsCompMem M = GtsComponent<GtsWave64Team>::global_mem(C, c);
+  {
+    /* the vertex-indexed arrays the traversals chase -- states, strands, the
+       queue, degrees, the sweep order -- move to the workgroup's LDS as far as
+       they fit (generic pointers: the program is the global-memory one); the
+       lists stay in global memory (L2) */
+    const uint32_t nv = M.nv, nv4 = ((nv * 4u + 15u) / 16u) * 16u, nv1 = ((nv + 15u) / 16u) * 16u;
+    uint32_t off = 0;
+    if (off + nv1 <= lds_bytes) {
+      uint8_t *p = (uint8_t *)(smem + off); off += nv1;
+      for (uint32_t s = threadIdx.x; s < nv; s += blockDim.x) p[s] = M.vst[s];
+      M.vst = p;
+    }
+    if (off + nv1 <= lds_bytes) { M.gorient = (uint8_t *)(smem + off); off += nv1; }
+    if (off + nv4 <= lds_bytes) { M.queue = (uint32_t *)(smem + off); off += nv4; }
+    if (off + nv4 <= lds_bytes) { M.st_v = (uint32_t *)(smem + off); off += nv4; }
+    if (off + nv4 <= lds_bytes) { M.topo = (uint32_t *)(smem + off); off += nv4; }
+    if (off + nv4 <= lds_bytes) { M.tpos = (uint32_t *)(smem + off); off += nv4; }
+  }
+  if (threadIdx.x == 0) {
+    const uint64_t need = (uint64_t)GTS_TEAM_WAVES * GtsComponent<GtsWave64Team>::team_wave_bytes(M.nv);
+    const unsigned long long off = atomicAdd(C.team_used, (unsigned long long)need);
+    ctl.slab = off; ctl.slab_ok = off + need <= C.team_cap ? 1u : 0u;
+    ctl.kind = 0;
+  }
+  __syncthreads();
+  const bool ok = ctl.slab_ok != 0;
+  GtsComponent<GtsWave64Team> prog(C, M, c);
+  if (ok) {
+    prog.team = &ctl; prog.team_base = C.team_slab + ctl.slab;
+    prog.team_wave = wv; prog.team_waves = GTS_TEAM_WAVES;
+  }
+  if (wv == 0) {
+    prog.run(mode);
+    if (ok) {
+      if (threadIdx.x == 0) ctl.kind = 0;
+      __syncthreads();
+    }
+  } else if (ok) {
+    prog.clean = true;     /* only clean components post walks */
+    for (;;) {
+      __syncthreads();
+      if (ctl.kind == 0) break;
+      prog.team_share(ctl.tb, ctl.te);
+      __syncthreads();
+    }
+  }
 }
 
 /* LDS-resident variant: the launcher guarantees gts_comp_lds_bytes(nv, ne) <=
@@ -1162,9 +1252,20 @@ __device__ __forceinline__ gts_pool_bits pool_bits_load(const volatile uint32_t 
 {
   return (gts_pool_bits)used[0] | (gts_pool_bits)used[1] << 32 | (gts_pool_bits)used[2] << 64;
 }
-__device__ __forceinline__ void pool_bits_store(volatile uint32_t *used, gts_pool_bits b)
+/* pages are taken under the lock and given back without it: the bits of a run
+   are set / cleared with LDS atomics, so a free never collides with the search
+   of the wavefront that holds the lock (it may miss pages freed meanwhile) */
+__device__ __forceinline__ void pool_bits_set(uint32_t *used, gts_pool_bits m)
 {
-  used[0] = (uint32_t)b; used[1] = (uint32_t)(b >> 32); used[2] = (uint32_t)(b >> 64);
+  if ((uint32_t)m) atomicOr(&used[0], (uint32_t)m);
+  if ((uint32_t)(m >> 32)) atomicOr(&used[1], (uint32_t)(m >> 32));
+  if ((uint32_t)(m >> 64)) atomicOr(&used[2], (uint32_t)(m >> 64));
+}
+__device__ __forceinline__ void pool_bits_clear(uint32_t *used, gts_pool_bits m)
+{
+  if ((uint32_t)m) atomicAnd(&used[0], ~(uint32_t)m);
+  if ((uint32_t)(m >> 32)) atomicAnd(&used[1], ~(uint32_t)(m >> 32));
+  if ((uint32_t)(m >> 64)) atomicAnd(&used[2], ~(uint32_t)(m >> 64));
 }
 __device__ __forceinline__ gts_pool_bits pool_run_mask(uint32_t pos, uint32_t n)
 {
@@ -1289,7 +1390,7 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
           const gts_pool_bits bits = pool_bits_load(v->used);
           pos = pool_find(bits, npages, front, floor, GTS_POOL_PAGES);
           if (pos != GTS_NONE) {
-            pool_bits_store(v->used, bits | pool_run_mask(pos, npages));
+            pool_bits_set(ctl->used, pool_run_mask(pos, npages));
             if (front) { v->front_busy = 0; v->wait_pages = 0; }
           } else if (front && !waiting) {
             v->wait_pages = npages; waiting = true;
@@ -1339,11 +1440,8 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane == 0) {
       if (canary && *canary != 0x5CAFF01Du) atomicAdd(pstat + 9, 1ull);
-      if (pool_lock(ctl, pstat, wait_limit)) {     /* (else the pages stay taken: the launch is lost anyway) */
-        volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
-        pool_bits_store(v->used, pool_bits_load(v->used) & ~pool_run_mask(pos, npages));
-        pool_unlock(ctl);
-      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      pool_bits_clear(ctl->used, pool_run_mask(pos, npages));
     }
   }
   if (lane == 0) {
@@ -1633,7 +1731,7 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
   if (!rc && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
   const void *big_lds[] = {(const void *)k_walk_tasks_mixed, (const void *)k_walk_tasks,
                            (const void *)k_components_lds,
-                           (const void *)k_components_pool};
+                           (const void *)k_components_pool, (const void *)k_components_team};
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
@@ -1669,7 +1767,7 @@ void gtsg_destroy(GtsgEngine *e)
   collect_times(e);
   free_graph(e, true);
   void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->vtime, e->pool, e->d_scalars,
-                  e->gtask_pool};
+                  e->gtask_pool, e->team_pool};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto ev : e->free_events) hipEventDestroy(ev);
   for (int k = 0; k < GTS_NSTREAMS; ++k) if (e->side[k]) hipStreamDestroy(e->side[k]);
@@ -1707,6 +1805,9 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "walk_path_entries") && value >= 1) e->walk_path_entries = value;
   else if (!strcmp(name, "global_task_pool_mb") && value >= 0) e->global_task_pool_mb = value;
   else if (!strcmp(name, "defer_global_components")) e->defer_global_components = value != 0;
+  else if (!strcmp(name, "team_components")) e->team_components = value != 0;
+  else if (!strcmp(name, "team_max_components") && value >= 0) e->team_max_components = value;
+  else if (!strcmp(name, "team_pool_mb") && value >= 0) e->team_pool_mb = value;
   else if (!strcmp(name, "profile")) e->profile = (int)value;
   else return fail(e, GTSG_EINVAL, "unknown option %s", name);
   return 0;
@@ -1878,7 +1979,7 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
       return fail(e, GTSG_EHIP, "CSR sort ended in the wrong buffer");
     LAUNCH("build_row_offsets", k_row_offsets, nblk((uint64_t)m + 1), GTS_BLOCK, e->estart,
            e->row, n, m);
-    LAUNCH("build_gather_csr", k_gather_csr, nblk(m), GTS_BLOCK, e->eid, rec, e->eend,
+    LAUNCH("build_gather_csr", k_gather_csr, nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK, e->eid, rec, e->eend,
            e->dist, e->npairs, e->sd, e->flags, e->state, e->pos_of_eid, m);
     LAUNCH("build_twins", k_twins, nblk(m), GTS_BLOCK, e->eid, e->pos_of_eid, e->twin, m);
   } else
@@ -2067,10 +2168,19 @@ __global__ void k_label_union(const uint32_t *root, const uint32_t *ctg,
     if (atomicCAS(&parent[x], x, y) == x) break;
   }
 }
+/* every entry its root.  The climb only reads: the path halving of uf_find
+   stores grandparents, and such a store landing after another thread's final
+   store would leave that entry pointing at an inner vertex (seen as contigs
+   without an owner in the plan of the partition).  What the other threads of
+   this kernel store are roots, so any mix of old and new entries leads to the
+   root. */
 __global__ void k_label_flatten(uint32_t *parent, uint32_t n)
 {
   uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < n) parent[v] = uf_find(parent, (uint32_t)v);
+  if (v >= n) return;
+  uint32_t r = (uint32_t)v, p = parent[r];
+  while (p != r) { r = p; p = parent[r]; }
+  parent[v] = r;
 }
 /* ---- routing of records to the shard that owns their component (multi-GPU) ----
    A record travels as four 64-bit words (gt-scaffold_amd/dist.py, pack_records):
@@ -2111,11 +2221,13 @@ __global__ void k_route_rows(const uint32_t *perm, const uint32_t *root, const u
    the shard's local numbers on the way */
 __global__ void k_route_unpack(const uint64_t *rows, const uint32_t *loc_of, uint32_t *root,
                                uint32_t *ctg, int64_t *dist, float *sd, int64_t *np,
-                               uint8_t *flags, uint64_t *kidx, uint64_t nrec)
+                               uint8_t *flags, uint64_t *kidx, uint64_t nrec, uint32_t *unsorted)
 {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrec) return;
   const ulonglong2 lo = ((const ulonglong2 *)rows)[2 * i], hi = ((const ulonglong2 *)rows)[2 * i + 1];
+  /* rows dealt in file-order chunks arrive in file order; say so if they did not */
+  if (i && (rows[4 * (i - 1) + 3] & 0xFFFFFFFFull) > (hi.y & 0xFFFFFFFFull)) *unsorted = 1;
   const uint32_t a = (uint32_t)lo.x & 0x7FFFFFFFu, b = (uint32_t)(lo.x >> 32) & 0x7FFFFFFFu;
   root[i] = loc_of ? loc_of[a] : a;
   ctg[i] = loc_of ? loc_of[b] : b;
@@ -2166,17 +2278,29 @@ int gtsg_route_pack(GtsgEngine *e, uint64_t nrec, const uint32_t *root, const ui
   return 0;
 }
 
-int gtsg_route_unpack(GtsgEngine *e, uint64_t nrec, const uint64_t *rows, const uint32_t *loc_of,
-                      uint32_t *root, uint32_t *ctg, int64_t *dist, float *std_dev,
-                      int64_t *num_pairs, uint8_t *flags, uint64_t *index)
+int gtsg_route_unpack_ex(GtsgEngine *e, uint64_t nrec, const uint64_t *rows, const uint32_t *loc_of,
+                         uint32_t *root, uint32_t *ctg, int64_t *dist, float *std_dev,
+                         int64_t *num_pairs, uint8_t *flags, uint64_t *index, int *out_of_order)
 {
   if (!e || (nrec && (!rows || !root || !ctg || !dist || !std_dev || !num_pairs || !flags || !index)))
     return GTSG_EINVAL;
   HIPCHK(hipSetDevice(e->device));
+  if (out_of_order) *out_of_order = 0;
+  HIPCHK(hipMemsetAsync(e->d_scalars + 6, 0, 4, e->st));
   if (nrec)
     LAUNCH("route_unpack", k_route_unpack, nblk(nrec), GTS_BLOCK, rows, loc_of, root, ctg, dist, std_dev,
-           num_pairs, flags, index, nrec);
-  return sync_stream(e);
+           num_pairs, flags, index, nrec, e->d_scalars + 6);
+  uint32_t uns = 0;
+  int rc;
+  if ((rc = read_u32(e, e->d_scalars + 6, &uns))) return rc;
+  if (out_of_order) *out_of_order = uns ? 1 : 0;
+  return 0;
+}
+int gtsg_route_unpack(GtsgEngine *e, uint64_t nrec, const uint64_t *rows, const uint32_t *loc_of,
+                      uint32_t *root, uint32_t *ctg, int64_t *dist, float *std_dev,
+                      int64_t *num_pairs, uint8_t *flags, uint64_t *index)
+{
+  return gtsg_route_unpack_ex(e, nrec, rows, loc_of, root, ctg, dist, std_dev, num_pairs, flags, index, nullptr);
 }
 
 int gtsg_label_components(GtsgEngine *e, uint64_t n, uint64_t nrec, const uint32_t *root,
@@ -2210,6 +2334,124 @@ int gtsg_label_components(GtsgEngine *e, uint64_t n, uint64_t nrec, const uint32
                        (unsigned long long)n);
   if (!on_device)
     HIPCHK(hipMemcpyAsync(labels, d_lab, n * 4, hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+
+/* ---- plan of the component partition (multi-GPU, dist.py step 2) on the device ----
+   weights: records per component of THIS shard (a record counts for the
+   component of its first non-repeat contig); after the shards have summed them
+   (all_reduce), deal: the components -- their labels are their smallest contigs
+   -- go to the ranks largest first, ties by label, in serpentine order. */
+__global__ void k_plan_count(const uint32_t *root, const uint32_t *ctg, const uint8_t *skip,
+                             uint32_t *cnt, uint64_t nrec, uint32_t n, uint32_t *bad)
+{
+  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t anchor = GTS_NONE;
+  if (k < nrec) {
+    const uint32_t a = root[k], b = ctg[k];
+    if (a >= n || b >= n) *bad = 1;
+    else anchor = !skip[a] ? a : !skip[b] ? b : GTS_NONE;
+  }
+  /* a root's records are neighbours in the file: one atomic per run of equal
+     anchors inside the wavefront instead of one per record */
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t prev = (uint32_t)__shfl_up((int)anchor, 1);
+  const uint64_t heads = __builtin_amdgcn_ballot_w64(lane == 0 || prev != anchor);
+  if ((heads >> lane) & 1ull) {
+    const uint64_t later = lane == 63 ? 0ull : heads >> (lane + 1);
+    const uint32_t run = later ? (uint32_t)__ffsll((long long)later) : 64u - lane;
+    if (anchor != GTS_NONE) atomicAdd(&cnt[anchor], run);
+  }
+}
+__global__ void k_plan_fold(const uint32_t *cnt, const uint32_t *labels, int32_t *w, uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n && cnt[v]) atomicAdd(&w[labels[v]], (int32_t)cnt[v]);
+}
+__global__ void k_plan_keys(const uint32_t *labels, const uint8_t *skip, const int32_t *w,
+                            uint32_t *key, uint32_t *val, uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const bool is_root = labels[v] == (uint32_t)v && !skip[v];
+  key[v] = is_root ? 0xFFFFFFFEu - (uint32_t)w[v] : 0xFFFFFFFFu;   /* ascending = heaviest first, then by id */
+  val[v] = (uint32_t)v;
+}
+__device__ __forceinline__ uint32_t plan_rank(uint64_t pos, uint32_t world)
+{
+  const uint64_t lap = pos / world;
+  const uint32_t col = (uint32_t)(pos % world);
+  return (lap & 1ull) ? world - 1u - col : col;
+}
+__global__ void k_plan_scatter(const uint32_t *key, const uint32_t *val, int8_t *owner_of_root,
+                               unsigned long long *load, uint32_t world, uint32_t n)
+{
+  __shared__ unsigned long long s_load[128];
+  if (threadIdx.x < 128) s_load[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n && key[p] != 0xFFFFFFFFu) {
+    const uint32_t r = plan_rank(p, world);
+    owner_of_root[val[p]] = (int8_t)r;
+    atomicAdd(&s_load[r], (unsigned long long)(0xFFFFFFFEu - key[p]));
+  }
+  __syncthreads();
+  if (threadIdx.x < world && s_load[threadIdx.x]) atomicAdd(&load[threadIdx.x], s_load[threadIdx.x]);
+}
+__global__ void k_plan_owner(const uint32_t *labels, const uint8_t *skip, const int8_t *owner_of_root,
+                             int8_t *owner, uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) owner[v] = skip[v] ? (int8_t)-1 : owner_of_root[labels[v]];
+}
+
+int gtsg_plan_weights(GtsgEngine *e, uint64_t n, uint64_t nrec, const uint32_t *root,
+                      const uint32_t *ctg, const uint8_t *skip, const uint32_t *labels,
+                      int32_t *weights)
+{
+  if (!e || !skip || !labels || !weights || (nrec && (!root || !ctg))) return GTSG_EINVAL;
+  if (n >= (1ull << 31) || nrec >= (1ull << 31)) return fail(e, GTSG_ELIMIT, "too many contigs or records");
+  HIPCHK(hipSetDevice(e->device));
+  if (!n) return 0;
+  int rc;
+  if ((rc = pool_reserve(e, n * 4 + (1u << 20)))) return rc;
+  PALLOC(cnt, uint32_t, n);
+  HIPCHK(hipMemsetAsync(cnt, 0, n * 4, e->st));
+  HIPCHK(hipMemsetAsync(weights, 0, n * 4, e->st));
+  HIPCHK(hipMemsetAsync(e->d_scalars + 6, 0, 4, e->st));
+  if (nrec)
+    LAUNCH("plan_count", k_plan_count, nblk(nrec), GTS_BLOCK, root, ctg, skip, cnt, nrec, (uint32_t)n,
+           e->d_scalars + 6);
+  LAUNCH("plan_fold", k_plan_fold, nblk(n), GTS_BLOCK, cnt, labels, weights, (uint32_t)n);
+  uint32_t bad = 0;
+  if ((rc = read_u32(e, e->d_scalars + 6, &bad))) return rc;
+  if (bad) return fail(e, GTSG_EINVAL, "contig id out of range in the records");
+  return 0;
+}
+
+int gtsg_plan_deal(GtsgEngine *e, uint64_t n, const uint8_t *skip, const uint32_t *labels,
+                   const int32_t *weights, uint32_t world, int8_t *owner, int64_t *load)
+{
+  if (!e || !skip || !labels || !weights || !owner || !load || world < 1 || world > 127) return GTSG_EINVAL;
+  if (n >= GTS_ONESWEEP_MAX_N) return fail(e, GTSG_ELIMIT, "too many contigs for one plan");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipMemsetAsync(load, 0, (size_t)world * 8, e->st));
+  if (!n) return sync_stream(e);
+  int rc;
+  if ((rc = pool_reserve(e, n * 17 + gts_sort_tmp_elems(n) * 4 + (1u << 20)))) return rc;
+  PALLOC(k0, uint32_t, n); PALLOC(k1, uint32_t, n); PALLOC(v0, uint32_t, n); PALLOC(v1, uint32_t, n);
+  PALLOC(oor, int8_t, n);
+  PALLOC(stmp, uint32_t, gts_sort_tmp_elems(n));
+  LAUNCH("plan_keys", k_plan_keys, nblk(n), GTS_BLOCK, labels, skip, weights, k0, v0, (uint32_t)n);
+  int shifts[4] = {0, 8, 16, 24};
+  int where;
+  { ProfScope ps(e, "plan_sort");
+    where = gts_radix_sort<uint32_t>(k0, v0, k1, v1, n, shifts, 4, stmp, e->st); }
+  if (where < 0) return fail(e, GTSG_ELIMIT, "too many contigs for one plan");
+  HIPCHK(hipMemsetAsync(oor, 0xFF, n, e->st));
+  LAUNCH("plan_scatter", k_plan_scatter, nblk(n), GTS_BLOCK, where ? k1 : k0, where ? v1 : v0, oor,
+         (unsigned long long *)load, world, (uint32_t)n);
+  LAUNCH("plan_owner", k_plan_owner, nblk(n), GTS_BLOCK, labels, skip, oor, owner, (uint32_t)n);
   return sync_stream(e);
 }
 
@@ -2324,7 +2566,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cerr, uint32_t, ncomp);
     PALLOC(s_nd, int64_t, nslots); PALLOC(s_plen, uint64_t, nslots); PALLOC(s_tight, uint8_t, nslots);
     PALLOC(stat_fast, uint32_t, ncomp); PALLOC(stat_slow, uint32_t, ncomp);
-    PALLOC(stat_clean, uint32_t, ncomp);
+    PALLOC(stat_clean, uint32_t, ncomp); PALLOC(stat_ncc, uint32_t, ncomp);
     PALLOC(comp_klass, uint8_t, (size_t)ncomp + 1); PALLOC(defer_flag, uint8_t, (size_t)ncomp + 1);
     PALLOC(comp_task0, uint32_t, ncomp); PALLOC(comp_ncc, uint32_t, ncomp); PALLOC(comp_nterm, uint32_t, ncomp);
     const uint64_t task_cap = nslots, path_cap = (uint64_t)path_entries;
@@ -2366,9 +2608,10 @@ static int run_components(GtsgEngine *e, int mode)
       order = where ? ov1 : ov0;
       order_key = where ? ok1 : ok0;
     }
-    uint32_t kcount[GTS_NKLASS + 1];
+    uint32_t kcount[GTS_NKLASS + 1], kslots_h[GTS_NKLASS + 1];
     uint64_t kbytes[GTS_NKLASS + 1];
     HIPCHK(hipMemcpyAsync(kcount, klass_count, sizeof kcount, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(kslots_h, e->d_scalars + GTS_S_KSLOTS, sizeof kslots_h, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(kbytes, e->d_scalars + GTS_S_KBYTES, sizeof kbytes, hipMemcpyDeviceToHost, e->st));
     /* largest component: sizes the scratch slabs of walks deferred from global memory */
     uint32_t maxcomp = 0;
@@ -2390,8 +2633,11 @@ static int run_components(GtsgEngine *e, int mode)
     C.distmap = s_distmap; C.ccoff = s_ccoff; C.wq_edge = wq_edge; C.wq_used = wq_used;
     C.wq_pool = wq_pool; C.wq_factor = (uint64_t)factor;
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
-    C.fast_walks = (int)e->fast_walks; C.batch_walks = (int)e->batch_walks; C.nd = s_nd; C.plen = s_plen; C.tight = s_tight;
+    C.fast_walks = (int)e->fast_walks; C.batch_walks = (int)e->batch_walks; C.nd = s_nd;
+    C.team_slab = nullptr; C.team_used = nullptr; C.team_cap = 0; C.team_stat = nullptr;
+    bool team_ran = false; C.plen = s_plen; C.tight = s_tight;
     C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat; C.stat_clean = stat_clean;
+    C.stat_ncc = stat_ncc;
     C.gorient = s_gorient; C.topo = s_topo; C.tpos = s_tpos;
     C.defer_min_nv = mode == GTS_MODE_MAKESCAFFOLD && e->lds_components ? (uint32_t)e->defer_min_contigs : 0u;
     C.defer_min_work = (uint64_t)e->defer_min_work;
@@ -2428,8 +2674,29 @@ static int run_components(GtsgEngine *e, int mode)
       if (e->profile) { span_a = get_event(e); span_b = get_event(e); hipEventRecord(span_a, e->st); }
       HIPCHK(hipEventRecord(e->ev_fork, e->st));
       if (kcount[nk]) {
-        LAUNCH(kname, k_components, kcount[nk], GTS_WAVE, C, order, first, kcount[nk], mode,
-               (int)e->defer_global_components);
+        /* few of them (the components too large for LDS): a workgroup each, the
+           walks of a cc over its wavefronts (k_components_team) */
+        const uint64_t team_bytes = (uint64_t)GTS_TEAM_WAVES * (172ull * kslots_h[nk] + 1024ull * kcount[nk]);
+        const bool team = mode == GTS_MODE_MAKESCAFFOLD && e->team_components && e->fast_walks &&
+                          !e->defer_global_components && kcount[nk] <= (uint32_t)e->team_max_components &&
+                          team_bytes <= ((uint64_t)e->team_pool_mb << 20);
+        if (team) {
+          if ((rc = dev_alloc(e, &e->team_pool, (size_t)team_bytes))) return rc;
+          C.team_slab = e->team_pool; C.team_cap = team_bytes;
+          C.team_used = (unsigned long long *)(e->d_scalars + GTS_S_TEAMUSED);
+          HIPCHK(hipMemsetAsync(C.team_used, 0, 8, e->st));
+          C.team_stat = (unsigned long long *)(e->d_scalars + GTS_S_TEAMSTAT);
+          HIPCHK(hipMemsetAsync(C.team_stat, 0, 64, e->st));
+          team_ran = true;
+          uint64_t lds = 18ull * maxcomp + 128;
+          if (lds > 159744u - 1024u) lds = 159744u - 1024u;
+          { ProfScope ps(e, kname);
+            k_components_team<<<kcount[nk], GTS_TEAM_WAVES * GTS_WAVE, (size_t)lds, e->st>>>(
+                C, order, first, kcount[nk], mode, (uint32_t)lds); }
+        } else
+          LAUNCH(kname, k_components, kcount[nk], GTS_WAVE, C, order, first, kcount[nk], mode,
+                 (int)e->defer_global_components);
+        e->stats["team_components"] = team ? (int64_t)kcount[nk] : 0;
         first += kcount[nk];
       }
       uint32_t pooled = 0;
@@ -2606,6 +2873,8 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 64, hipMemcpyDeviceToHost, e->st));
     uint64_t pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 80, hipMemcpyDeviceToHost, e->st));
+    uint64_t tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (team_ran) HIPCHK(hipMemcpyAsync(tst, e->d_scalars + GTS_S_TEAMSTAT, 64, hipMemcpyDeviceToHost, e->st));
     uint32_t res[4] = {0, 0, 0, 0};
     uint64_t wstat[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 16, hipMemcpyDeviceToHost, e->st));
@@ -2629,6 +2898,11 @@ static int run_components(GtsgEngine *e, int mode)
                   "pages %llu); states restored", (unsigned long long)pst[6], (unsigned long long)pst[7],
                   (unsigned long long)pst[8]);
     }
+    if (team_ran) {
+      static const char *tn[8] = {"team_ccs", "team_batches", "team_sweep_steps", "team_ccs_with_tie",
+                                  "team_us_clear", "team_us_sweep", "team_us_paths", "team_us_wave0_barriers"};
+      for (int k = 0; k < 8; ++k) e->stats[tn[k]] = (int64_t)(k < 4 ? tst[k] : tst[k] / 100);
+    }
     if (pool_ran) {   /* 100 MHz ticks -> microseconds */
       e->stats["pool_us_sum_run"] = (int64_t)(pst[0] / 100);
       e->stats["pool_us_sum_wait_pages"] = (int64_t)(pst[1] / 100);
@@ -2645,7 +2919,8 @@ static int run_components(GtsgEngine *e, int mode)
     }
     if (e->profile >= 2) {   /* the three components that took longest */
       std::vector<uint64_t> ht(5 * (size_t)ncomp);
-      std::vector<uint32_t> hs(ncomp), hf(ncomp), hc(ncomp), ho((size_t)ncomp + 1), hco((size_t)nslots + 1);
+      std::vector<uint32_t> hs(ncomp), hf(ncomp), hc(ncomp), ho((size_t)ncomp + 1), hco((size_t)nslots + 1), hn(ncomp);
+      HIPCHK(hipMemcpy(hn.data(), stat_ncc, (size_t)ncomp * 4, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(ht.data(), tstat, ht.size() * 8, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(hs.data(), stat_slow, (size_t)ncomp * 4, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(hf.data(), stat_fast, (size_t)ncomp * 4, hipMemcpyDeviceToHost));
@@ -2704,6 +2979,7 @@ static int run_components(GtsgEngine *e, int mode)
         e->stats[pre + "size"] = ho[best + 1] - ho[best];
         e->stats[pre + "edges"] = hco[ho[best + 1]] - hco[ho[best]];
         e->stats[pre + "terminals"] = hc[best] >> 8;
+        e->stats[pre + "ccs"] = hn[best];
         e->stats[pre + "clean"] = hc[best] & 1;
         e->stats[pre + "deferred"] = hc[best] >> 1 & 1;
         e->stats[pre + "why_not_deferred"] = hc[best] >> 2 & 3;

@@ -143,17 +143,28 @@ def unpack_records(rows):
 def component_labels(comm, n, root, ctg, skip, label_fn, device):
     """Step 1.  root / ctg: this shard's records, skip: bool[n] (repeat
     contigs).  Returns labels[n] (int32): smallest contig of the component,
-    identical on every rank."""
-    labels = torch.arange(n, dtype=torch.int32, device=device)
+    identical on every rank.
+    A round: join the contigs of the local records (label_fn runs its union-find
+    to the end), then the element-wise MIN over the shards.  The fixpoint is
+    reached when a round changes nothing on any shard; the "changed" flag rides
+    in one extra element of the reduced tensor (-1 = changed: MIN), so a round is
+    one collective and one look at the host.  One shard: the first round's
+    labels are final."""
+    buf = torch.empty(n + 1, dtype=torch.int32, device=device)
+    labels = buf[:n]
+    torch.arange(n, dtype=torch.int32, device=device, out=labels)
     rounds = 0
     while True:
-        prev = labels.clone()
-        labels = label_fn(labels, root, ctg, skip)
-        comm.all_reduce(labels, "min")
-        changed = (labels != prev).any().to(torch.int32).reshape(1)
-        comm.all_reduce(changed, "max")
+        prev = labels.clone() if comm.world > 1 else None
+        out = label_fn(labels, root, ctg, skip)
+        if out.data_ptr() != labels.data_ptr():
+            labels.copy_(out)
         rounds += 1
-        if not int(changed.item()):
+        if comm.world == 1:
+            return labels, rounds
+        buf[n] = -(labels != prev).any().to(torch.int32)
+        comm.all_reduce(buf, "min")
+        if int(buf[n].item()) == 0:
             return labels, rounds
 
 
@@ -181,6 +192,16 @@ def plan_owners(comm, n, labels, skip, root, ctg):
     return owner, load
 
 
+def plan_owners_engine(comm, eng, labels, skip8, root32, ctg32):
+    """Step 2 with the engine's kernels (gtsg_plan_weights / gtsg_plan_deal):
+    nothing of the plan is computed in torch ops and nothing is read back on the
+    way -- count, ONE all_reduce of the weights (int32 per contig), sort + deal.
+    Returns (owner int8 [n], load int64 [world])."""
+    w = eng.plan_weights(root32, ctg32, skip8, labels)
+    comm.all_reduce(w, "sum")
+    return eng.plan_deal(skip8, labels, w, comm.world)
+
+
 def route_records_engine(comm, eng, owner, rec, loc_of):
     """Step 3 with the engine's HIP kernels (gtsg_route_pack / _unpack): the
     destination of every record, one stable 8-bit sort pass by destination and
@@ -192,12 +213,11 @@ def route_records_engine(comm, eng, owner, rec, loc_of):
     r = dict(root=rec["root"].to(torch.int32).contiguous(), ctg=rec["ctg"].to(torch.int32).contiguous(),
              dist=rec["dist"].to(torch.int64).contiguous(), std_dev=rec["std_dev"].to(torch.float32).contiguous(),
              num_pairs=rec["num_pairs"].to(torch.int64).contiguous(), flags=rec["flags"].to(torch.uint8).contiguous())
-    rows, counts = eng.route_pack(r, first, owner.to(torch.int8), comm.world)
+    rows, counts = eng.route_pack(r, first, owner if owner.dtype == torch.int8 else owner.to(torch.int8), comm.world)
     rows = comm.exchange_rows(rows, counts)
     out = eng.route_unpack(rows.contiguous(), loc_of)
-    kk = out["k"]
-    if kk.numel() > 1 and not bool((kk[1:] >= kk[:-1]).all()):   # chunks dealt in file order arrive sorted
-        o = torch.argsort(kk, stable=True)
+    if out.pop("out_of_order"):            # chunks dealt in file order arrive sorted: the kernel looks
+        o = torch.argsort(out["k"], stable=True)
         out = {name: t[o] for name, t in out.items()}
     return out
 
@@ -266,10 +286,22 @@ def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None, timers=None):
     dev = contigs["seq_len"].device
     n = contigs["seq_len"].numel()
     skip = (contigs["astat"] <= cuts["astat_cutoff"]) | (contigs["copy_num"] < cuts["copy_num_cutoff"])
-    root, ctg = rec["root"].to(torch.int64), rec["ctg"].to(torch.int64)
-    labels, rounds = component_labels(comm, n, root, ctg, skip, label_fn or engine_label_fn(eng), dev)
-    lap("label")
-    owner, load = plan_owners(comm, n, labels, skip, root, ctg)
+    on_engine = dev.type == "cuda" and label_fn is None and hasattr(eng, "plan_weights")
+    if on_engine:
+        # ids stay 32 bit on the device; the engine's kernels take them as they are
+        root = rec["root"] if rec["root"].dtype == torch.int32 else rec["root"].to(torch.int32)
+        ctg = rec["ctg"] if rec["ctg"].dtype == torch.int32 else rec["ctg"].to(torch.int32)
+        skip8 = skip.to(torch.uint8)
+        labels, rounds = component_labels(comm, n, root.contiguous(), ctg.contiguous(), skip8,
+                                          lambda lab, r, c, s: (eng.label_components(lab.numel(), r, c, s, lab), lab)[1],
+                                          dev)
+        lap("label")
+        owner, load = plan_owners_engine(comm, eng, labels, skip8, root, ctg)
+    else:
+        root, ctg = rec["root"].to(torch.int64), rec["ctg"].to(torch.int64)
+        labels, rounds = component_labels(comm, n, root, ctg, skip, label_fn or engine_label_fn(eng), dev)
+        lap("label")
+        owner, load = plan_owners(comm, n, labels, skip, root, ctg)
     lap("plan")
     # local numbering: owned + repeat contigs, in id order
     member = (owner == comm.rank) | skip
@@ -298,9 +330,10 @@ def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None, timers=None):
     rep_loc = loc_of[torch.nonzero(skip).flatten()].to(torch.int64)
     if local.numel():
         eng.filter_begin(cuts["pcutoff"], cuts["cncutoff"], cuts["ocutoff"])
-        lasthit = torch.empty(2 * local.numel(), dtype=torch.int32, device=dev)
-        eng.filter_get_lasthit(lasthit)
-    if rep_loc.numel():
+        if comm.world > 1:
+            lasthit = torch.empty(2 * local.numel(), dtype=torch.int32, device=dev)
+            eng.filter_get_lasthit(lasthit)
+    if rep_loc.numel() and comm.world > 1:     # (one shard has nobody to agree with)
         tab = lasthit.view(-1, 2)[rep_loc].contiguous()
         comm.all_reduce(tab, "max")
         lasthit.view(-1, 2)[rep_loc] = tab

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgtscaffold_hip.so")
+# (GTS_ENGINE_LIB: another build of the same library, for A/B measurements)
+LIB_PATH = os.environ.get("GTS_ENGINE_LIB") or os.path.join(_HERE, "csrc", "libgtscaffold_hip.so")
 _LIB = None
 
 SYMBOLS = [
@@ -24,7 +25,7 @@ SYMBOLS = [
     "gtsg_deparser_create", "gtsg_deparser_destroy", "gtsg_deparser_last_error", "gtsg_deparser_set_names",
     "gtsg_deparser_parse", "gtsg_deparser_records", "gtsg_deparser_download", "gtsg_deparser_parse_astat",
     "gtsg_deparser_trim", "gtsg_sort_names", "gtsg_fasta_records", "gtsg_deparser_accumulate",
-    "gtsg_find_edge", "gtsg_alter_edge",
+    "gtsg_find_edge", "gtsg_alter_edge", "gtsg_plan_weights", "gtsg_plan_deal", "gtsg_route_unpack_ex",
 ]
 
 
@@ -85,6 +86,9 @@ def lib():
         L.gtsg_route_pack.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, u64, u64, vp, C.c_uint32, vp,
                                       C.POINTER(u64)]
         L.gtsg_route_unpack.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.gtsg_route_unpack_ex.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(ci)]
+        L.gtsg_plan_weights.argtypes = [vp, u64, u64, vp, vp, vp, vp, vp]
+        L.gtsg_plan_deal.argtypes = [vp, u64, vp, vp, vp, C.c_uint32, vp, vp]
         L.gtsg_removecycles.argtypes = [vp]
         L.gtsg_makescaffold.argtypes = [vp]
         L.gtsg_num_vertices.argtypes = [vp]
@@ -399,6 +403,35 @@ class Engine:
         self._chk(self._L.gtsg_label_components(self._h, int(n), len(root), a[0][0], a[1][0], a[2][0],
                                                 a[3][0], self._same_side([x[1] for x in a])))
 
+    def plan_weights(self, root, ctg, skip8, labels):
+        """records of this shard per component label (device tensors: root / ctg /
+        labels int32, skip8 uint8) -> int32 [n] on the device (gtsg_plan_weights)"""
+        import torch
+        n = labels.numel()
+        w = torch.empty(n, dtype=torch.int32, device=labels.device)
+        a = [_ptr(root, np.uint32), _ptr(ctg, np.uint32), _ptr(skip8, np.uint8), _ptr(labels, np.uint32),
+             _ptr(w, np.int32)]
+        if not all(x[1] for x in a):
+            raise TypeError("plan_weights takes device tensors")
+        self._sync_producer(a)
+        self._chk(self._L.gtsg_plan_weights(self._h, n, root.numel(), *[x[0] for x in a]))
+        return w
+
+    def plan_deal(self, skip8, labels, weights, world):
+        """components to ranks, heaviest first in serpentine order (gtsg_plan_deal):
+        returns (owner int8 [n], -1 for skipped contigs; load int64 [world])"""
+        import torch
+        n = labels.numel()
+        owner = torch.empty(n, dtype=torch.int8, device=labels.device)
+        load = torch.empty(world, dtype=torch.int64, device=labels.device)
+        a = [_ptr(skip8, np.uint8), _ptr(labels, np.uint32), _ptr(weights, np.int32)]
+        b = [_ptr(owner, np.int8), _ptr(load, np.int64)]
+        if not all(x[1] for x in a):
+            raise TypeError("plan_deal takes device tensors")
+        self._sync_producer(a)
+        self._chk(self._L.gtsg_plan_deal(self._h, n, a[0][0], a[1][0], a[2][0], int(world), b[0][0], b[1][0]))
+        return owner, load
+
     def route_pack(self, rec, first_index, owner8, world):
         """rec: device tensors root / ctg (int32), dist, num_pairs (int64), std_dev
         (float32), flags (uint8); owner8: int8 per contig (negative = shared).
@@ -431,9 +464,11 @@ class Engine:
         pr, dr, kr = _ptr(rows, np.int64)
         pl = _ptr(loc_of, np.uint32)[0] if loc_of is not None else None
         self._sync_producer([(pr, dr)])
-        self._chk(self._L.gtsg_route_unpack(self._h, n, pr, pl, *[C.c_void_p(out[k].data_ptr()) for k in
-                                                                   ("root", "ctg", "dist", "std_dev",
-                                                                    "num_pairs", "flags", "k")]))
+        ooo = C.c_int(0)
+        self._chk(self._L.gtsg_route_unpack_ex(self._h, n, pr, pl, *[C.c_void_p(out[k].data_ptr()) for k in
+                                                                      ("root", "ctg", "dist", "std_dev",
+                                                                       "num_pairs", "flags", "k")], C.byref(ooo)))
+        out["out_of_order"] = bool(ooo.value)
         return out
 
     # ---- results ----

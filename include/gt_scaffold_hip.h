@@ -122,6 +122,20 @@ int gtsg_filter_end(GtsgEngine *e);
 int gtsg_label_components(GtsgEngine *e, uint64_t n, uint64_t n_records,
                           const uint32_t *root, const uint32_t *ctg,
                           const uint8_t *skip, uint32_t *labels, int on_device);
+/* Step 2 of that partition, on the device (all pointers are device pointers).
+   gtsg_plan_weights: weights[c] = records of THIS shard that belong to the
+   component with label c (a record counts for its first contig that is not
+   skipped; labels from gtsg_label_components after the shards agreed).  The
+   caller sums the weights over the shards (all_reduce), then
+   gtsg_plan_deal: the components go to the ranks heaviest first (ties: smaller
+   label first) in serpentine order 0..world-1, world-1..0, ...; owner[v] = the
+   rank of v's component, -1 for skipped (repeat) contigs, which every shard
+   holds; load[r] = records of rank r's components. */
+int gtsg_plan_weights(GtsgEngine *e, uint64_t n, uint64_t nrec, const uint32_t *root,
+                      const uint32_t *ctg, const uint8_t *skip, const uint32_t *labels,
+                      int32_t *weights);
+int gtsg_plan_deal(GtsgEngine *e, uint64_t n, const uint8_t *skip, const uint32_t *labels,
+                   const int32_t *weights, uint32_t world, int8_t *owner, int64_t *load);
 
 /* Component-partition step, routing: the records of this shard, packed into
    four 64-bit words each and grouped by the rank that owns their component
@@ -142,6 +156,13 @@ int gtsg_route_unpack(GtsgEngine *e, uint64_t n_rows, const uint64_t *rows,
                       const uint32_t *loc_of, uint32_t *root, uint32_t *ctg,
                       int64_t *dist, float *std_dev, int64_t *num_pairs,
                       uint8_t *flags, uint64_t *index);
+/* the same; *out_of_order = 1 if the rows' record indices are not ascending
+   (rows dealt in file-order chunks arrive in file order: the caller sorts only
+   when told to) */
+int gtsg_route_unpack_ex(GtsgEngine *e, uint64_t n_rows, const uint64_t *rows,
+                         const uint32_t *loc_of, uint32_t *root, uint32_t *ctg,
+                         int64_t *dist, float *std_dev, int64_t *num_pairs,
+                         uint8_t *flags, uint64_t *index, int *out_of_order);
 
 /* ref gt_scaffolder_removecycles, algorithms.c:495-578 */
 int gtsg_removecycles(GtsgEngine *e);

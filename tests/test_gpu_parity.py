@@ -521,6 +521,137 @@ def test_full_size_properties():
     assert eng.digest() == pkg.engine.state_digest_host(og.vertex_states(), og.edge_states())
 
 
+_FULL = {}
+
+
+def full_size_inputs():
+    """the portable 10 M-contig workload of tests/golden/full_size_digest.json,
+    drawn once per test session (53 s on a host core)"""
+    import json
+    import os
+    import sys
+    import bench
+    from helpers import ROOT
+    if not _FULL:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import make_full_size_digest as tool
+        want = json.load(open(os.path.join(ROOT, "tests", "golden", "full_size_digest.json")))
+        assert want["gen"] == bench.WORKLOADS["10M"]["gen"] and want["cuts"] == bench.CUTS
+        g = tool.generate(pkg, want["n_contigs"], want["seed"], want["gen"])
+        assert len(g["root"]) == want["n_records"]
+        assert tool.input_checksum(g) == want["input_sha256"], "this host draws other inputs than the build container"
+        _FULL.update(want=want, g=g)
+    return _FULL["want"], _FULL["g"]
+
+
+def test_full_size_sharded_pipeline_against_oracle_digest():
+    """BASELINE configs[3] at full size, rehearsed on one GPU: the 10 M-contig /
+    100 M-edge graph of the oracle fixture split over TWO engines (threads) by
+    file chunk -- label, plan and route on the device, the filter's latest-hit
+    exchange, makescaffold per shard -- and the merged vertex / edge states
+    digested like the unsharded graph's: the oracle's digests of
+    tests/golden/full_size_digest.json."""
+    import threading
+    import torch
+    dist_mod = pkg.dist
+    want, g = full_size_inputs()
+    n, m = len(g["seq_len"]), len(g["root"])
+    world, dev = 2, "cuda:0"
+    # edge ids of the whole graph: (start, end) in id order from an unsharded build
+    eng0 = pkg.engine.Engine(0)
+    eng0.set_contigs(g["seq_len"].astype(np.int64), g["astat"], g["copy_num"])
+    eng0.build_from_records(g["root"], g["ctg"], g["dist"], g["std_dev"], g["num_pairs"].astype(np.int64),
+                            g["flags"])
+    e0 = eng0.edges()
+    eng0.close()
+    ne = len(e0["start"])
+    assert ne == want["n_edges"]
+    key = torch.from_numpy(e0["start"].astype(np.int64)).to(dev) * n + torch.from_numpy(e0["end"].astype(np.int64)).to(dev)
+    del e0
+    skey, perm = torch.sort(key)
+    del key
+    cuts = want["cuts"]
+    contigs = dict(seq_len=torch.from_numpy(g["seq_len"].astype(np.int64)).to(dev),
+                   astat=torch.from_numpy(g["astat"]).to(dev), copy_num=torch.from_numpy(g["copy_num"]).to(dev))
+    shared = dist_mod.ThreadComm.Shared(world)
+    vs = torch.zeros(n, dtype=torch.uint8, device=dev)
+    es = torch.full((ne,), 255, dtype=torch.uint8, device=dev)
+    errs, lock, info = [], threading.Lock(), {}
+
+    def run(r):
+        try:
+            eng = pkg.engine.Engine(0)
+            lo, hi = m * r // world, m * (r + 1) // world
+            rec = {k: torch.from_numpy(np.ascontiguousarray(g[k][lo:hi]).astype(
+                {"root": np.int32, "ctg": np.int32, "num_pairs": np.int64}.get(k, g[k].dtype))).to(dev)
+                for k in ("root", "ctg", "dist", "std_dev", "num_pairs", "flags")}
+            rec["k"] = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+            owner, rounds, load, local = dist_mod.scaffold_sharded(dist_mod.ThreadComm(shared, r), eng,
+                                                                   contigs, rec, cuts)
+            v = torch.from_numpy(eng.vertex_states()).to(dev)
+            e = eng.edges()
+            st = torch.from_numpy(eng.edge_states()).to(dev)
+            a = local[torch.from_numpy(e["start"].astype(np.int64)).to(dev)]
+            b = local[torch.from_numpy(e["end"].astype(np.int64)).to(dev)]
+            pos = torch.searchsorted(skey, a * n + b)
+            with lock:
+                assert bool((skey[pos] == a * n + b).all())      # every shard edge is an edge of the graph
+                eid = perm[pos]
+                assert bool((es[eid] == 255).all())              # ... that lives on one rank only
+                es[eid] = st
+                own = owner[local] == r
+                vs[local[own]] = v[own]
+                rep = owner[local] < 0                           # repeat contigs: the same state everywhere
+                if r == 0:
+                    vs[local[rep]] = v[rep]
+                else:
+                    assert bool((vs[local[rep]] == v[rep]).all())
+                info[r] = (rounds, load.cpu().tolist(), int(local.numel()), len(e["start"]))
+            eng.close()
+        except BaseException as ex:   # noqa: B902
+            errs.append(ex)
+            shared.barrier.abort()
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert bool((es != 255).all())                               # every edge of the graph is on some rank
+    assert info[0][3] + info[1][3] == ne
+    # the plan balances the records: the heavier rank holds less than 51 %
+    assert max(info[0][1]) <= 0.51 * sum(info[0][1])
+    dig = pkg.engine.state_digest_host(vs.cpu().numpy(), es.cpu().numpy())
+    assert dig == (want["after_makescaffold"]["vertex_digest"], want["after_makescaffold"]["edge_digest"])
+
+
+def test_plan_kernels_match_the_torch_plan():
+    """gtsg_plan_weights / gtsg_plan_deal (the component plan of the partition
+    step without a torch op or a look at the host in between) against
+    dist.plan_owners, three ranks"""
+    import torch
+    dist_mod = pkg.dist
+    dev = "cuda:0"
+    g = make_inputs(20000, 43, p_repeat=0.05, p_chimeric=0.05)
+    n = len(g["seq_len"])
+    eng = pkg.engine.Engine(0)
+    comm = dist_mod.ThreadComm(dist_mod.ThreadComm.Shared(1), 0)
+    comm.world = 3            # one process plays the only shard of a three-rank plan
+    comm.all_reduce = lambda t, op: t
+    skip = torch.from_numpy((g["astat"] <= 20.0) | (g["copy_num"] < 0.3)).to(dev)
+    root = torch.from_numpy(g["root"].astype(np.int32)).to(dev)
+    ctg = torch.from_numpy(g["ctg"].astype(np.int32)).to(dev)
+    labels = torch.arange(n, dtype=torch.int32, device=dev)
+    eng.label_components(n, root, ctg, skip.to(torch.uint8), labels)
+    assert torch.equal(labels[labels.long()], labels)      # every label is a root (the smallest contig)
+    owner_t, load_t = dist_mod.plan_owners(comm, n, labels, skip, root.to(torch.int64), ctg.to(torch.int64))
+    owner_e, load_e = dist_mod.plan_owners_engine(comm, eng, labels, skip.to(torch.uint8), root, ctg)
+    assert owner_e.dtype == torch.int8
+    assert torch.equal(owner_e.to(torch.int64), owner_t)
+    assert torch.equal(load_e, load_t)
+    assert int((owner_e[~skip] < 0).sum()) == 0 and int((owner_e[skip] >= 0).sum()) == 0
+
+
 def test_full_size_against_oracle_digest():
     """BASELINE configs[2] against the oracle at FULL size: the 10 M-contig /
     100 M-edge workload is regenerated on this host with the generator's
@@ -529,24 +660,11 @@ def test_full_size_against_oracle_digest():
     tools/make_full_size_digest.py, where the CPU oracle ran on the whole graph
     for ~45 min) and the engine's state digests are compared with the oracle's
     after the filter and after makescaffold."""
-    import json
-    import os
-    import sys
-    import torch
-    import bench
-    from helpers import ROOT
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import make_full_size_digest as tool
-    want = json.load(open(os.path.join(ROOT, "tests", "golden", "full_size_digest.json")))
-    assert want["gen"] == bench.WORKLOADS["10M"]["gen"] and want["cuts"] == bench.CUTS
-    g = tool.generate(pkg, want["n_contigs"], want["seed"], want["gen"])
-    assert len(g["root"]) == want["n_records"]
-    assert tool.input_checksum(g) == want["input_sha256"], "this host draws other inputs than the build container"
+    want, g = full_size_inputs()
     eng = pkg.engine.Engine(0)
     eng.set_contigs(g["seq_len"].astype(np.int64), g["astat"], g["copy_num"])
     eng.build_from_records(g["root"], g["ctg"], g["dist"], g["std_dev"], g["num_pairs"].astype(np.int64),
                            g["flags"])
-    del g
     assert eng.ne == want["n_edges"]
     C = want["cuts"]
     eng.mark_repeats(True, C["copy_num_cutoff"], C["astat_cutoff"])
@@ -702,6 +820,7 @@ def test_route_kernels_match_the_torch_packing():
     assert torch.equal(rows, d.pack_records(rec)[order])
     assert counts == torch.bincount(dest, minlength=world).tolist()
     back = eng.route_unpack(rows)
+    assert back["out_of_order"] == bool((back["k"][1:] < back["k"][:-1]).any())
     for name in ("root", "ctg", "dist", "num_pairs", "flags", "k"):
         assert torch.equal(back[name].long(), rec[name][order].long()), name
     assert torch.equal(back["std_dev"].view(torch.int32), rec["std_dev"][order].view(torch.int32))
@@ -766,3 +885,24 @@ def test_pool_wait_bound_leaves_a_graph_that_can_be_scaffolded_again():
     eng.set_option("pool_wait_limit_us", 10_000_000)
     og.makescaffold(True); eng.makescaffold()
     assert_same_states(eng, og, "makescaffold after a failed call")
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_team_kernel_for_global_memory_components(case):
+    """components that run from global memory get a workgroup each when there
+    are few of them (k_components_team): wavefront 0 runs the program, the walks
+    of a cc are swept eight to a wavefront by all of them.  Forced here for every
+    component (LDS off, no limit on their number); ties and inversions fall back
+    to the walks made one by one"""
+    kw = [dict(n=30000, seed=8, p_chimeric=0.02),
+          dict(n=8000, seed=1201, p_chimeric=0.08, p_inversion=0.0, p_bubble=0.05, links_per_side=4,
+               unique_pairs=True),
+          dict(n=3000, seed=21, dist_range_small=True, contig_median=300),
+          dict(n=6000, seed=61, p_chimeric=0.05)][case]
+    kw = dict(kw)
+    g = make_inputs(kw.pop("n"), kw.pop("seed"), **kw)
+    eng, _ = run_pipeline(g, lds_components=0, team_max_components=1 << 30)
+    assert eng.stat("team_components") == eng.stat("components") > 0
+    eng0, _ = run_pipeline(g, lds_components=0, team_components=0)
+    assert eng0.stat("team_components") == 0
+    assert eng.digest() == eng0.digest()
