@@ -457,6 +457,9 @@ def main():
                                                   "why_marked_end", "why_two_directions",
                                                   "why_inexact_tie", "why_cycle",
                                                   "why_inexact_length_tie")},
+                       small={k[6:]: eng.stat(k) for k in
+                              ("small_all_live_components", "small_other_components",
+                               "small_all_live_removecycles_us", "small_other_removecycles_us")},
                        team={k[5:]: eng.stat(k) for k in
                              ("team_components", "team_ccs", "team_batches", "team_sweep_steps", "team_ccs_with_tie",
                               "team_us_clear", "team_us_sweep", "team_us_paths", "team_us_wave0_barriers")},
@@ -467,6 +470,10 @@ def main():
                                                  wave_us=eng.stat("size_band%d_us" % i),
                                                  walk_us=eng.stat("size_band%d_walk_us" % i))
                                 for i, b in enumerate(("2", "3", "4", "8", "16", "32", "64", "inf"))},
+                       last_to_finish=[
+                           {k: eng.stat("last%d_%s" % (r, k)) for k in
+                            ("size", "terminals", "clean", "start_us", "end_us", "removecycles_us", "walks_us")}
+                           for r in range(8)],
                        slowest_components=[
                            {k: eng.stat("top%d_%s" % (r, k)) for k in
                             ("size", "edges", "terminals", "ccs", "clean", "deferred", "why_not_deferred", "walks",

@@ -82,6 +82,9 @@ struct GtsCompView {
   int batch_walks;           /* LDS-resident clean components: the walks of a cc side by side */
   char *team_slab;           /* k_components_team: walk slots and path buffers of the workgroups */
   unsigned long long *team_used;   /* bytes handed out */
+  uint64_t *tspan;           /* per component x2 (or null): clock at the start and the end of its program */
+  unsigned long long *small_stat;  /* [4] statistics: components of at most 64 contigs whose compact edges are
+                                      all live / all components of that size, and their cycle-removal ticks */
   unsigned long long *team_stat;   /* [8] statistics: ccs posted, batches, sweep steps, ccs with a tie,
                                       ticks clearing slots / sweeping / extracting paths / wavefront 0 at the barriers */
   uint64_t team_cap;
@@ -365,6 +368,7 @@ struct GtsComponent {
                            select_walks (task_reference = 0), makescaffold hands it to a task */
   bool needs_reference;
   bool deferred_late;   /* makescaffold stopped at a cc and published the rest as tasks */
+  bool was_all_live;    /* statistics */
   /* k_components_team */
   GtsTeamCtl *team;     /* null: no team */
   char *team_base;      /* this workgroup's slab */
@@ -373,7 +377,7 @@ struct GtsComponent {
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -622,6 +626,7 @@ struct GtsComponent {
       const uint32_t ce = base + lane;
       all_live = W::ballot(ce < M.ne && gts_edge_is_marked(M.cstate[ce])) == 0;
     }
+    was_all_live = all_live;
     bool oriented = false, first = true;
     if (!all_live) oriented = C.fast_walks && nv > 1 && orient();
     bool found = true;
@@ -2548,6 +2553,10 @@ struct GtsComponent {
     removecycles(mode == GTS_MODE_MAKESCAFFOLD);
     reuse_cc = clean;   /* the terminal search of the last pass is makescaffold's */
     const uint64_t t1 = W::clock();
+    if (C.small_stat && nv <= 64 && lane == 0) {
+      W::add64((uint64_t *)C.small_stat + (was_all_live && clean ? 0 : 1), 1);
+      W::add64((uint64_t *)C.small_stat + (was_all_live && clean ? 2 : 3), t1 - t0);
+    }
     const bool was_clean = clean;
     bool deferred = false;
     if (mode == GTS_MODE_MAKESCAFFOLD) {
@@ -2569,6 +2578,7 @@ struct GtsComponent {
       C.tstat[5 * (uint64_t)c + 2] = tfast;
       C.tstat[5 * (uint64_t)c + 3] = tslow;
       C.tstat[5 * (uint64_t)c + 4] = npops;
+      if (C.tspan) { C.tspan[2 * (uint64_t)c] = t0; C.tspan[2 * (uint64_t)c + 1] = W::clock(); }
     }
     W::fence();
   }

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -62,6 +63,7 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_S_POOLSTAT 400 /* 10 x u64: clocks, give-up and overrun counts of k_components_pool */
 #define GTS_S_TEAMUSED 424 /* u64: bytes of the team slab handed out */
 #define GTS_S_TEAMSTAT 432 /* 8 x u64: statistics of k_components_team */
+#define GTS_S_SMALLSTAT 448 /* 4 x u64: small components by "all edges live" */
 
 static const char *klass_event(int makescaffold, uint32_t bytes)
 {
@@ -138,6 +140,7 @@ struct GtsgEngine {
   int64_t task_reference_walks = 1;
   int64_t pool_components = 1;        /* all LDS components in one launch (k_components_pool) */
   int64_t pool_waves = GTS_POOL_WAVES; /* wavefronts per workgroup of that launch */
+  int64_t gather_unroll = 4;           /* edges a thread of the gather-shaped build kernels (1: A/B measurements) */
   int64_t lds_poison = -1;             /* test aid: fill a component's pages with this byte before staging */
   int64_t pool_wait_limit_us = 10000000; /* bound of every wait inside that launch (0: test aid, a wait gives up at once) */
   int n_cus = 256;
@@ -158,6 +161,9 @@ struct GtsgEngine {
      when there are few of them: the walks of a cc over its wavefronts */
   int64_t team_components = 1, team_max_components = 512, team_pool_mb = 4096;
   char *team_pool = nullptr;
+  char *text_buf = nullptr;   /* .dot text of a chunk of edges (gtsg_format_dot_edges) */
+  char *text_host = nullptr;  /* its page-locked host copy (gtsg_format_dot_edges_pinned) */
+  size_t text_host_cap = 0;
   int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
   /* profiling */
   struct Pending { const char *name; hipEvent_t a, b; };
@@ -370,12 +376,16 @@ __global__ void k_pair_segments(const uint64_t *keys, const uint32_t *recs,
   const uint32_t k0 = recs[i];
   const bool selfloop = (uint32_t)(key >> 32 & 0x7FFFFFFFu) == (uint32_t)key;
   uint32_t fw = k0, bw = k0;
+  /* (the usual pair has two records, one from each contig: both deviations are
+     fetched together, not one after the other) */
+  const uint32_t k1 = recs[i + 1];
+  const float s1 = sd[k1];
   float fsd = sd[k0], bsd = fsd;
   for (uint64_t j = i + 1; j < nrec; ++j) {
     const uint64_t kj = keys[j];
     if (((kj ^ key) & PAIR) != 0) break;
-    const uint32_t k = recs[j];
-    const float s = sd[k];
+    const uint32_t k = j == i + 1 ? k1 : recs[j];
+    const float s = j == i + 1 ? s1 : sd[k];
     if (selfloop || ((kj ^ key) >> 63) == 0) { if (fsd < s) { fsd = s; fw = k; } }   /* same root */
     else { if (bsd < s) { bsd = s; bw = k; } }
   }
@@ -441,6 +451,7 @@ __global__ void k_row_offsets(const uint32_t *sorted_start, uint32_t *row,
 }
 
 #define GTS_GATHER_UNROLL 4
+template <int GTS_U>
 __global__ void k_gather_csr(const uint32_t *perm, const GtsEdgeRec *rec,
                              uint32_t *eend, int64_t *dist, int64_t *npairs,
                              float *sd, uint8_t *flags, uint8_t *state,
@@ -448,18 +459,18 @@ __global__ void k_gather_csr(const uint32_t *perm, const GtsEdgeRec *rec,
 {
   /* four edges a thread, the four random 32-byte records in flight together:
      one dependent gather per thread leaves the memory system idle (1.4 TB/s) */
-  const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x) * GTS_GATHER_UNROLL + threadIdx.x;
-  uint32_t id[GTS_GATHER_UNROLL];
-  GtsEdgeRec r[GTS_GATHER_UNROLL];
+  const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x) * GTS_U + threadIdx.x;
+  uint32_t id[GTS_U];
+  GtsEdgeRec r[GTS_U];
 #pragma unroll
-  for (int k = 0; k < GTS_GATHER_UNROLL; ++k) {
+  for (int k = 0; k < GTS_U; ++k) {
     const uint64_t p = base + (uint64_t)k * blockDim.x;
     id[k] = p < m ? perm[p] : 0u;
   }
 #pragma unroll
-  for (int k = 0; k < GTS_GATHER_UNROLL; ++k) r[k] = rec[id[k]];
+  for (int k = 0; k < GTS_U; ++k) r[k] = rec[id[k]];
 #pragma unroll
-  for (int k = 0; k < GTS_GATHER_UNROLL; ++k) {
+  for (int k = 0; k < GTS_U; ++k) {
     const uint64_t p = base + (uint64_t)k * blockDim.x;
     if (p >= m) continue;
     eend[p] = r[k].end; dist[p] = r[k].dist; npairs[p] = r[k].npairs; sd[p] = r[k].sd;
@@ -467,11 +478,25 @@ __global__ void k_gather_csr(const uint32_t *perm, const GtsEdgeRec *rec,
     pos_of_eid[id[k]] = (uint32_t)p;
   }
 }
+template <int GTS_U>
 __global__ void k_twins(const uint32_t *eid, const uint32_t *pos_of_eid,
                         uint32_t *twin, uint32_t m)
 {
-  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < m) twin[p] = pos_of_eid[eid[p] ^ 1u];
+  /* four gathers a thread in flight (see k_gather_csr) */
+  const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x) * GTS_U + threadIdx.x;
+  uint32_t id[GTS_U], t[GTS_U];
+#pragma unroll
+  for (int k = 0; k < GTS_U; ++k) {
+    const uint64_t p = base + (uint64_t)k * blockDim.x;
+    id[k] = p < m ? eid[p] ^ 1u : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < GTS_U; ++k) t[k] = pos_of_eid[id[k]];
+#pragma unroll
+  for (int k = 0; k < GTS_U; ++k) {
+    const uint64_t p = base + (uint64_t)k * blockDim.x;
+    if (p < m) twin[p] = t[k];
+  }
 }
 __global__ void k_hub_flags(const uint32_t *row, uint32_t *flag, uint32_t n,
                             uint32_t hub_degree)
@@ -949,24 +974,44 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
                                uint32_t *cend, int64_t *cdist, uint8_t *cflags,
                                uint32_t *cgpos, uint8_t *cstate, uint32_t *cmap)
 {
-  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= G.m) return;
-  if (!incl[p]) { cmap[p] = GTS_NONE; return; }
-  const uint32_t a = estart[p], s = slot_of[a], base = slot_base[s];
-  const uint32_t k = coff[s] + (ipos[p] - ipos[G.row[a]]);
-  /* flags with the u-turn bit from the build.  An included edge's twin is live
-     or the edge is live itself; GTS_F_TWINLIVE matters only while the edge is
-     marked (d_arc) and is cleared with the twin's CYCLIC mark, the only way a
-     live edge dies (mark_vertex_cyclic takes both): set for every edge. */
-  const uint8_t f = G.flags[p];
-  cstart[k] = s - base; cend[k] = slot_of[G.end[p]] - base;
-  const int64_t d = G.dist[p];
-  /* the LDS layout adds up to 4095 distances in 32 bits (nd_t) */
-  if (d >= (1 << 19) || d <= -(1 << 19)) comp_wide[slot_comp[s]] = 1;
-  cdist[k] = d;
-  cflags[k] = (uint8_t)((f & 7u) | GTS_F_TWINLIVE);
-  cgpos[k] = (uint32_t)p; cstate[k] = G.state[p];
-  cmap[p] = k;
+  /* two edges a thread: the random reads of an edge (the slot of its end
+     vertex, the record of its start vertex' slot) are a chain of three; two
+     chains in flight hide half of it */
+  constexpr int U = 2;
+  const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x) * U + threadIdx.x;
+  uint64_t p[U];
+  bool in[U];
+  uint32_t a[U], b[U], s[U], sb[U], ip[U], r0[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    p[k] = base + (uint64_t)k * blockDim.x;
+    in[k] = p[k] < G.m && incl[p[k]];
+    if (p[k] < G.m && !in[k]) cmap[p[k]] = GTS_NONE;
+    a[k] = in[k] ? estart[p[k]] : 0u;
+    b[k] = in[k] ? G.end[p[k]] : 0u;
+    ip[k] = in[k] ? ipos[p[k]] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < U; ++k) { s[k] = slot_of[a[k]]; sb[k] = slot_of[b[k]]; r0[k] = G.row[a[k]]; }
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    if (!in[k]) continue;
+    const uint32_t base_s = slot_base[s[k]];
+    const uint32_t kk = coff[s[k]] + (ip[k] - ipos[r0[k]]);
+    /* flags with the u-turn bit from the build.  An included edge's twin is live
+       or the edge is live itself; GTS_F_TWINLIVE matters only while the edge is
+       marked (d_arc) and is cleared with the twin's CYCLIC mark, the only way a
+       live edge dies (mark_vertex_cyclic takes both): set for every edge. */
+    const uint8_t f = G.flags[p[k]];
+    cstart[kk] = s[k] - base_s; cend[kk] = sb[k] - base_s;
+    const int64_t d = G.dist[p[k]];
+    /* the LDS layout adds up to 4095 distances in 32 bits (nd_t) */
+    if (d >= (1 << 19) || d <= -(1 << 19)) comp_wide[slot_comp[s[k]]] = 1;
+    cdist[kk] = d;
+    cflags[kk] = (uint8_t)((f & 7u) | GTS_F_TWINLIVE);
+    cgpos[kk] = (uint32_t)p[k]; cstate[kk] = G.state[p[k]];
+    cmap[p[k]] = kk;
+  }
 }
 
 /* gfx950 wave policy of gts_component.hpp */
@@ -1767,8 +1812,9 @@ void gtsg_destroy(GtsgEngine *e)
   collect_times(e);
   free_graph(e, true);
   void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->vtime, e->pool, e->d_scalars,
-                  e->gtask_pool, e->team_pool};
+                  e->gtask_pool, e->team_pool, e->text_buf};
   for (void *p : ptrs) if (p) hipFree(p);
+  if (e->text_host) hipHostFree(e->text_host);
   for (auto ev : e->free_events) hipEventDestroy(ev);
   for (int k = 0; k < GTS_NSTREAMS; ++k) if (e->side[k]) hipStreamDestroy(e->side[k]);
   for (int k = 0; k < GTS_NKLASS; ++k) if (e->ev_join[k]) hipEventDestroy(e->ev_join[k]);
@@ -1798,6 +1844,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "pool_components")) e->pool_components = value != 0;
   else if (!strcmp(name, "pool_waves") && value >= 1 && value <= GTS_POOL_WAVES) e->pool_waves = value;
   else if (!strcmp(name, "lds_poison") && value >= -1 && value <= 255) e->lds_poison = value;
+  else if (!strcmp(name, "gather_unroll") && value >= 1) e->gather_unroll = value;
   else if (!strcmp(name, "pool_wait_limit_us") && value >= 0) e->pool_wait_limit_us = value;
   else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NSTREAMS) e->class_streams = value;
   else if (!strcmp(name, "mixed_task_limit") && value >= 0) e->mixed_task_limit = value;
@@ -1979,9 +2026,16 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
       return fail(e, GTSG_EHIP, "CSR sort ended in the wrong buffer");
     LAUNCH("build_row_offsets", k_row_offsets, nblk((uint64_t)m + 1), GTS_BLOCK, e->estart,
            e->row, n, m);
-    LAUNCH("build_gather_csr", k_gather_csr, nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK, e->eid, rec, e->eend,
-           e->dist, e->npairs, e->sd, e->flags, e->state, e->pos_of_eid, m);
-    LAUNCH("build_twins", k_twins, nblk(m), GTS_BLOCK, e->eid, e->pos_of_eid, e->twin, m);
+    if (e->gather_unroll > 1) {
+      LAUNCH("build_gather_csr", k_gather_csr<GTS_GATHER_UNROLL>, nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK,
+             e->eid, rec, e->eend, e->dist, e->npairs, e->sd, e->flags, e->state, e->pos_of_eid, m);
+      LAUNCH("build_twins", k_twins<GTS_GATHER_UNROLL>, nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK, e->eid,
+             e->pos_of_eid, e->twin, m);
+    } else {
+      LAUNCH("build_gather_csr", k_gather_csr<1>, nblk(m), GTS_BLOCK, e->eid, rec, e->eend, e->dist, e->npairs,
+             e->sd, e->flags, e->state, e->pos_of_eid, m);
+      LAUNCH("build_twins", k_twins<1>, nblk(m), GTS_BLOCK, e->eid, e->pos_of_eid, e->twin, m);
+    }
   } else
     HIPCHK(hipMemsetAsync(e->row, 0, ((size_t)n + 1) * 4, e->st));
   /* hub list */
@@ -2547,7 +2601,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cflags, uint8_t, (size_t)nce + 1); PALLOC(cstate, uint8_t, (size_t)nce + 1);
     PALLOC(cmap, uint32_t, (size_t)m + 1);
     if (m)
-      LAUNCH("comp_compact_fill", k_compact_fill, nblk(m), GTS_BLOCK, G, e->estart, incl, ipos,
+      LAUNCH("comp_compact_fill", k_compact_fill, nblk(m, GTS_BLOCK * 2), GTS_BLOCK, G, e->estart, incl, ipos,
              slot_of, slot_base, coff, slot_comp, comp_wide, cstart, cend, cdist, cflags, cgpos,
              cstate, cmap);
     /* walk queue pool of the reference search */
@@ -2635,6 +2689,14 @@ static int run_components(GtsgEngine *e, int mode)
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
     C.fast_walks = (int)e->fast_walks; C.batch_walks = (int)e->batch_walks; C.nd = s_nd;
     C.team_slab = nullptr; C.team_used = nullptr; C.team_cap = 0; C.team_stat = nullptr;
+    C.small_stat = nullptr; C.tspan = nullptr;
+    if (e->profile >= 2) {
+      PALLOC(tspan, uint64_t, 2 * (size_t)ncomp);
+      HIPCHK(hipMemsetAsync(tspan, 0, 16 * (size_t)ncomp, e->st));
+      C.tspan = tspan;
+      C.small_stat = (unsigned long long *)(e->d_scalars + GTS_S_SMALLSTAT);
+      HIPCHK(hipMemsetAsync(C.small_stat, 0, 32, e->st));
+    }
     bool team_ran = false; C.plen = s_plen; C.tight = s_tight;
     C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat; C.stat_clean = stat_clean;
     C.stat_ncc = stat_ncc;
@@ -2898,6 +2960,14 @@ static int run_components(GtsgEngine *e, int mode)
                   "pages %llu); states restored", (unsigned long long)pst[6], (unsigned long long)pst[7],
                   (unsigned long long)pst[8]);
     }
+    if (C.small_stat) {
+      uint64_t ss[4] = {0, 0, 0, 0};
+      HIPCHK(hipMemcpy(ss, C.small_stat, 32, hipMemcpyDeviceToHost));
+      e->stats["small_all_live_components"] = (int64_t)ss[0];
+      e->stats["small_other_components"] = (int64_t)ss[1];
+      e->stats["small_all_live_removecycles_us"] = (int64_t)(ss[2] / 100);
+      e->stats["small_other_removecycles_us"] = (int64_t)(ss[3] / 100);
+    }
     if (team_ran) {
       static const char *tn[8] = {"team_ccs", "team_batches", "team_sweep_steps", "team_ccs_with_tie",
                                   "team_us_clear", "team_us_sweep", "team_us_paths", "team_us_wave0_barriers"};
@@ -2969,6 +3039,28 @@ static int run_components(GtsgEngine *e, int mode)
           e->stats["size_band" + std::to_string(b) + "_components"] = (int64_t)bc[b];
           e->stats["size_band" + std::to_string(b) + "_us"] = (int64_t)(bt[b] / 100);
           e->stats["size_band" + std::to_string(b) + "_walk_us"] = (int64_t)(bw[b] / 100);
+        }
+      }
+      if (C.tspan) {   /* who finishes last: start and end of the component programs since the first start */
+        std::vector<uint64_t> sp(2 * (size_t)ncomp);
+        HIPCHK(hipMemcpy(sp.data(), C.tspan, sp.size() * 8, hipMemcpyDeviceToHost));
+        uint64_t t_min = ~0ull;
+        for (uint32_t c2 = 0; c2 < ncomp; ++c2) if (sp[2 * (size_t)c2] && sp[2 * (size_t)c2] < t_min) t_min = sp[2 * (size_t)c2];
+        std::vector<uint32_t> idx(ncomp);
+        for (uint32_t c2 = 0; c2 < ncomp; ++c2) idx[c2] = c2;
+        const size_t top = ncomp < 8 ? ncomp : 8;
+        std::partial_sort(idx.begin(), idx.begin() + top, idx.end(),
+                          [&](uint32_t a, uint32_t b) { return sp[2 * (size_t)a + 1] > sp[2 * (size_t)b + 1]; });
+        for (size_t r = 0; r < top; ++r) {
+          const uint32_t c2 = idx[r];
+          const std::string pre = "last" + std::to_string(r) + "_";
+          e->stats[pre + "size"] = ho[c2 + 1] - ho[c2];
+          e->stats[pre + "terminals"] = hc[c2] >> 8;
+          e->stats[pre + "clean"] = hc[c2] & 1;
+          e->stats[pre + "start_us"] = (int64_t)((sp[2 * (size_t)c2] - t_min) / 100);
+          e->stats[pre + "end_us"] = (int64_t)((sp[2 * (size_t)c2 + 1] - t_min) / 100);
+          e->stats[pre + "removecycles_us"] = (int64_t)(ht[5 * (size_t)c2] / 100);
+          e->stats[pre + "walks_us"] = (int64_t)((ht[5 * (size_t)c2 + 2] + ht[5 * (size_t)c2 + 3]) / 100);
         }
       }
       auto total = [&](uint32_t c2) { const uint64_t *t = &ht[5 * (size_t)c2]; return t[0] + t[1] + t[2] + t[3]; };
@@ -3149,6 +3241,197 @@ int gtsg_alter_edge(GtsgEngine *e, uint64_t eid, int64_t dist, float std_dev, ui
   HIPCHK(hipMemcpyAsync(e->npairs + p, &np, 8, hipMemcpyHostToDevice, e->st));
   HIPCHK(hipMemcpyAsync(e->flags + p, &fp, 1, hipMemcpyHostToDevice, e->st));
   if (t != p) HIPCHK(hipMemcpyAsync(e->flags + t, &ft, 1, hipMemcpyHostToDevice, e->st));
+  return sync_stream(e);
+}
+
+/* ---- .dot text of the edges, formatted on the device ---------------------------
+   ref gt_scaffolder_graph.c:288-300: one line per edge, in edge-id order,
+     <start> -> <end> [color="<colour of the state>" label="<dist>" arrowhead="normal"|"inv"];
+   A thread per edge: the length of its line, a prefix sum, then the bytes. */
+__device__ __forceinline__ uint32_t dec_len(uint64_t v)
+{
+  uint32_t k = 1;
+  while (v >= 10) { v /= 10; ++k; }
+  return k;
+}
+__device__ __forceinline__ char *dec_put(char *p, uint64_t v)
+{
+  const uint32_t k = dec_len(v);
+  for (uint32_t i = k; i-- > 0;) { p[i] = (char)('0' + v % 10); v /= 10; }
+  return p + k;
+}
+__device__ __forceinline__ char *str_put(char *p, const char *s, uint32_t n)
+{
+  for (uint32_t i = 0; i < n; ++i) p[i] = s[i];
+  return p + n;
+}
+/* colours of the states 0..7 (graph.c:277-278) and their lengths */
+__constant__ char gts_dot_color[8][12] = {"black", "gray80", "gainsboro", "ivory3", "red", "green", "magenta", "blue"};
+__constant__ uint8_t gts_dot_clen[8] = {5, 6, 9, 6, 3, 5, 7, 4};
+__global__ void k_dot_len(const uint32_t *pos_of_eid, const uint32_t *estart, const uint32_t *eend,
+                          const int64_t *dist, const uint8_t *flags, const uint8_t *state,
+                          uint64_t first, uint32_t count, uint32_t *len)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t p = pos_of_eid[first + i];
+  const int64_t d = dist[p];
+  const uint64_t ad = d < 0 ? (uint64_t)0 - (uint64_t)d : (uint64_t)d;
+  len[i] = dec_len(estart[p]) + 4u + dec_len(eend[p]) + 9u + gts_dot_clen[state[p] & 7u] + 9u +
+           (d < 0 ? 1u : 0u) + dec_len(ad) + ((flags[p] & 1u) ? 23u : 20u);
+}
+__global__ void k_dot_write(const uint32_t *pos_of_eid, const uint32_t *estart, const uint32_t *eend,
+                            const int64_t *dist, const uint8_t *flags, const uint8_t *state,
+                            uint64_t first, uint32_t count, const uint32_t *off, char *text)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t p = pos_of_eid[first + i];
+  char *o = text + off[i];
+  const int64_t d = dist[p];
+  const uint32_t st = state[p] & 7u;
+  o = dec_put(o, estart[p]);
+  o = str_put(o, " -> ", 4);
+  o = dec_put(o, eend[p]);
+  o = str_put(o, " [color=\"", 9);
+  o = str_put(o, gts_dot_color[st], gts_dot_clen[st]);
+  o = str_put(o, "\" label=\"", 9);
+  if (d < 0) *o++ = '-';
+  o = dec_put(o, d < 0 ? (uint64_t)0 - (uint64_t)d : (uint64_t)d);
+  if (flags[p] & 1u) str_put(o, "\" arrowhead=\"normal\"];\n", 23);
+  else str_put(o, "\" arrowhead=\"inv\"];\n", 20);
+}
+static int format_dot_edges(GtsgEngine *e, uint64_t first, uint64_t count, char *host_buf, uint64_t cap,
+                            uint64_t *nbytes, const char **pinned);
+int gtsg_format_dot_edges(GtsgEngine *e, uint64_t first, uint64_t count, char *host_buf, uint64_t cap,
+                          uint64_t *nbytes)
+{
+  if (!e || !nbytes || (count && !host_buf)) return GTSG_EINVAL;
+  return format_dot_edges(e, first, count, host_buf, cap, nbytes, nullptr);
+}
+/* the same into a page-locked buffer of the engine's (valid until the next
+   call): the copy from the device runs at the bus' rate and the caller writes
+   the file straight from it */
+int gtsg_format_dot_edges_pinned(GtsgEngine *e, uint64_t first, uint64_t count, const char **text,
+                                 uint64_t *nbytes)
+{
+  if (!e || !nbytes || !text) return GTSG_EINVAL;
+  *text = nullptr;
+  return format_dot_edges(e, first, count, nullptr, 0, nbytes, text);
+}
+static int format_dot_edges(GtsgEngine *e, uint64_t first, uint64_t count, char *host_buf, uint64_t cap,
+                            uint64_t *nbytes, const char **pinned)
+{
+  *nbytes = 0;
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->built) return fail(e, GTSG_EINVAL, "graph not built");
+  if (first > e->m || count > e->m - first) return fail(e, GTSG_EINVAL, "edge range out of bounds");
+  if (!count) return 0;
+  if (count > (1u << 25)) return fail(e, GTSG_ELIMIT, "at most 2^25 edges a call (32-bit text offsets)");
+  int rc;
+  const uint32_t cnt = (uint32_t)count;
+  if ((rc = pool_reserve(e, (size_t)cnt * 8 + gts_scan_tmp_elems((uint64_t)cnt + 16) * 4 + (1u << 20)))) return rc;
+  PALLOC(len, uint32_t, (size_t)cnt + 1); PALLOC(off, uint32_t, (size_t)cnt + 2);
+  PALLOC(sctmp, uint32_t, gts_scan_tmp_elems((uint64_t)cnt + 16));
+  LAUNCH("dot_len", k_dot_len, nblk(cnt), GTS_BLOCK, e->pos_of_eid, e->estart, e->eend, e->dist, e->flags,
+         e->state, first, cnt, len);
+  gts_exscan<uint32_t, uint32_t>(len, off, cnt, sctmp, off + cnt, e->st);
+  uint32_t total = 0;
+  if ((rc = read_u32(e, off + cnt, &total))) return rc;
+  *nbytes = total;
+  if (pinned) {
+    if (e->text_host_cap < (size_t)total + 64) {
+      if (e->text_host) hipHostFree(e->text_host);
+      e->text_host = nullptr; e->text_host_cap = 0;
+      const size_t want = (size_t)total + total / 8 + 4096;
+      if (hipHostMalloc((void **)&e->text_host, want, hipHostMallocDefault) != hipSuccess)
+        return fail(e, GTSG_ENOMEM, "page-locked text buffer of %zu bytes", want);
+      e->text_host_cap = want;
+    }
+    host_buf = e->text_host;
+    *pinned = e->text_host;
+  } else if (total > cap)
+    return fail(e, GTSG_EINVAL, "text buffer too small: %u bytes needed", total);
+  if ((rc = dev_alloc(e, &e->text_buf, (size_t)total + 64))) return rc;
+  LAUNCH("dot_write", k_dot_write, nblk(cnt), GTS_BLOCK, e->pos_of_eid, e->estart, e->eend, e->dist, e->flags,
+         e->state, first, cnt, off, e->text_buf);
+  HIPCHK(hipMemcpyAsync(host_buf, e->text_buf, total, hipMemcpyDeviceToHost, e->st));
+  return sync_stream(e);
+}
+
+/* ---- the SCAFFOLD edges only (output side of the file API) ------------------
+   The scaffold record walk (ref algorithms.c:901-997) and the .scaf writer look
+   at SCAFFOLD edges and nothing else: a compact CSR of them -- adjacency order
+   kept, a few per cent of the edges -- instead of the whole edge list. */
+__global__ void k_scaf_flags(const uint8_t *state, uint8_t *flag, uint32_t m)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < m) flag[p] = state[p] == GIS_SCAFFOLD ? 1 : 0;
+}
+__global__ void k_scaf_rows(const uint32_t *row, const uint32_t *ipos, uint32_t *srow, uint32_t n)
+{
+  uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v <= n) srow[v] = ipos[row[v]];
+}
+__global__ void k_scaf_fill(const uint8_t *flag, const uint32_t *ipos, const uint32_t *eid,
+                            const uint32_t *eend, const int64_t *dist, const float *sd,
+                            const uint8_t *flags, uint32_t *o_eid, uint32_t *o_end, int64_t *o_dist,
+                            float *o_sd, uint8_t *o_flags, uint32_t m)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m || !flag[p]) return;
+  const uint32_t k = ipos[p];
+  o_eid[k] = eid[p]; o_end[k] = eend[p]; o_dist[k] = dist[p]; o_sd[k] = sd[p];
+  o_flags[k] = flags[p] & 3u;
+}
+int gtsg_get_scaffold_edges(GtsgEngine *e, uint64_t *count, uint32_t *row, uint32_t *eid,
+                            uint32_t *end, int64_t *dist, float *std_dev, uint8_t *flags)
+{
+  if (!e || !count) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->built) return fail(e, GTSG_EINVAL, "graph not built");
+  const uint32_t n = e->n, m = e->m;
+  int rc;
+  const size_t need = (size_t)m * 5 + (size_t)n * 4 + gts_scan_tmp_elems((uint64_t)m + 16) * 4 + (1u << 20);
+  if ((rc = pool_reserve(e, need))) return rc;
+  PALLOC(flag, uint8_t, (size_t)m + 1); PALLOC(ipos, uint32_t, (size_t)m + 2);
+  PALLOC(srow, uint32_t, (size_t)n + 1);
+  PALLOC(sctmp, uint32_t, gts_scan_tmp_elems((uint64_t)m + 16));
+  uint32_t cnt = 0;
+  if (m) {
+    LAUNCH("scaf_flags", k_scaf_flags, nblk(m), GTS_BLOCK, e->state, flag, m);
+    gts_exscan<uint8_t, uint32_t>(flag, ipos, m, sctmp, ipos + m, e->st);
+    if ((rc = read_u32(e, ipos + m, &cnt))) return rc;
+  }
+  *count = cnt;
+  if (!row) return 0;            /* first call: the caller sizes its arrays */
+  if (!eid || !end || !dist || !std_dev || !flags) return GTSG_EINVAL;
+  if (m) LAUNCH("scaf_rows", k_scaf_rows, nblk((uint64_t)n + 1), GTS_BLOCK, e->row, ipos, srow, n);
+  else HIPCHK(hipMemsetAsync(srow, 0, ((size_t)n + 1) * 4, e->st));
+  HIPCHK(hipMemcpyAsync(row, srow, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, e->st));
+  if (cnt) {
+    /* (a second reservation would move the pool: the outputs come from one of their own) */
+    uint32_t *o_eid = nullptr, *o_end = nullptr;
+    int64_t *o_dist = nullptr;
+    float *o_sd = nullptr;
+    uint8_t *o_fl = nullptr;
+    char *buf = nullptr;
+    if (hipMalloc((void **)&buf, (size_t)cnt * 21 + 64) != hipSuccess) return fail(e, GTSG_ENOMEM, "scaffold edge buffer");
+    o_dist = (int64_t *)buf; o_eid = (uint32_t *)(o_dist + cnt); o_end = o_eid + cnt;
+    o_sd = (float *)(o_end + cnt); o_fl = (uint8_t *)(o_sd + cnt);
+    LAUNCH("scaf_fill", k_scaf_fill, nblk(m), GTS_BLOCK, flag, ipos, e->eid, e->eend, e->dist, e->sd,
+           e->flags, o_eid, o_end, o_dist, o_sd, o_fl, m);
+    hipError_t h1 = hipMemcpyAsync(eid, o_eid, (size_t)cnt * 4, hipMemcpyDeviceToHost, e->st);
+    hipError_t h2 = hipMemcpyAsync(end, o_end, (size_t)cnt * 4, hipMemcpyDeviceToHost, e->st);
+    hipError_t h3 = hipMemcpyAsync(dist, o_dist, (size_t)cnt * 8, hipMemcpyDeviceToHost, e->st);
+    hipError_t h4 = hipMemcpyAsync(std_dev, o_sd, (size_t)cnt * 4, hipMemcpyDeviceToHost, e->st);
+    hipError_t h5 = hipMemcpyAsync(flags, o_fl, (size_t)cnt, hipMemcpyDeviceToHost, e->st);
+    rc = sync_stream(e);
+    hipFree(buf);
+    if (h1 != hipSuccess || h2 != hipSuccess || h3 != hipSuccess || h4 != hipSuccess || h5 != hipSuccess)
+      return fail(e, GTSG_EHIP, "copying the scaffold edges");
+    return rc;
+  }
   return sync_stream(e);
 }
 

@@ -12,6 +12,7 @@
 #define _GNU_SOURCE
 #include "gt_scaffolder_host.h"
 
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -52,12 +53,20 @@ struct GtScaffolderGraph {
   char err[512];
 };
 
+typedef struct {             /* an edge of a scaffold record: what the .scaf line prints of it */
+  uint32_t eid, end;
+  int64_t dist;
+  float std_dev;
+  uint8_t flags;
+} REdge;
+
 struct GtScaffolderGraphRecords {
   const GtScaffolderGraph *g;
   uint64_t n, cap;
   uint64_t *root;
   uint64_t *off;             /* n+1 offsets into edge */
-  uint64_t *edge, nedge, capedge;
+  REdge *edge;
+  uint64_t nedge, capedge;
 };
 
 static int seterr(char *err, size_t n, const char *fmt, ...)
@@ -545,6 +554,10 @@ static int read_distance_records(const GtScaffolderGraph *g, const char *path,
    the fallback for files outside its regular form (default), 1 the host code
    only, 2 the GPU parser or an error (tests). */
 void gt_scaffolder_set_distance_parser(int mode) { g_host_parser = mode; }
+/* who formats the edge lines of gt_scaffolder_graph_print: 0 (default) the GPU
+   for a graph that lives there, 1 the host (the reference's loop by hand) */
+static int g_host_dot;
+void gt_scaffolder_set_dot_writer(int mode) { g_host_dot = mode; }
 
 /* The GPU parser of the graph with the sorted headers as its name table.
    *have = 0: there is none (host-only mode, no GPU, too many names). */
@@ -883,26 +896,30 @@ static int refresh(GtScaffolderGraph *g)
   return engine_err(g, rc, NULL, 0);
 }
 
-/* buffered text output without stdio's formatting */
-typedef struct { FILE *f; size_t n; int bad; char buf[1 << 16]; } OutBuf;
-static void ob_init(OutBuf *o, FILE *f) { o->f = f; o->n = 0; o->bad = 0; }
+/* buffered text output without stdio's formatting: a 1 MB buffer, pieces are
+   copied (or digits written) straight into it while there is room */
+#define OB_CAP (1u << 20)
+typedef struct { FILE *f; size_t n; int bad; char *buf; } OutBuf;
+static void ob_init(OutBuf *o, FILE *f) { o->f = f; o->n = 0; o->bad = 0; o->buf = xcalloc(OB_CAP, 1); }
 static int ob_flush(OutBuf *o)
 {
   if (o->n && fwrite(o->buf, 1, o->n, o->f) != o->n) o->bad = 1;
   o->n = 0;
   return o->bad;
 }
-static void ob_mem(OutBuf *o, const char *p, size_t len)
+static int ob_close(OutBuf *o) { int bad = ob_flush(o); free(o->buf); o->buf = NULL; return bad; }
+static inline void ob_mem(OutBuf *o, const char *p, size_t len)
 {
+  if (len <= OB_CAP - o->n) { memcpy(o->buf + o->n, p, len); o->n += len; return; }
   while (len) {
-    size_t room = sizeof o->buf - o->n, k = len < room ? len : room;
+    size_t room = OB_CAP - o->n, k = len < room ? len : room;
     memcpy(o->buf + o->n, p, k);
     o->n += k; p += k; len -= k;
-    if (o->n == sizeof o->buf) ob_flush(o);
+    if (o->n == OB_CAP) ob_flush(o);
   }
 }
-static void ob_str(OutBuf *o, const char *s) { ob_mem(o, s, strlen(s)); }
-static void ob_u64(OutBuf *o, uint64_t v)
+static inline void ob_str(OutBuf *o, const char *s) { ob_mem(o, s, strlen(s)); }
+static inline void ob_u64(OutBuf *o, uint64_t v)
 {
   char t[24];
   int k = 24;
@@ -939,6 +956,36 @@ int gt_scaffolder_graph_print(const GtScaffolderGraph *cg, const char *filename,
   FILE *f;
   OutBuf ob;
   uint64_t i;
+  if (g->eng && !g_host_dot) {
+    /* a graph on the GPU: its edge lines (all but a few per cent of the file)
+       are formatted there, 2^23 edges at a time; only the vertex states cross
+       the bus besides the text */
+    const uint64_t chunk = 1ull << 23;
+    int rc = gtsg_get_vertex_states(g->eng, g->vstate);
+    if (rc) { engine_err(g, rc, NULL, 0); return seterr(err, errlen, "%s", g->err); }
+    f = fopen(filename, "w");
+    if (!f) return seterr(err, errlen, "cannot open %s for writing", filename);
+    ob_init(&ob, f);
+    ob_str(&ob, "digraph {\n");
+    for (i = 0; i < g->nof_vertices; i++) {
+      ob_u64(&ob, i);
+      ob_str(&ob, " [color=\""); ob_str(&ob, color[g->vstate[i] & 7]);
+      ob_str(&ob, "\" label=\""); ob_str(&ob, g->ctg[i].name);
+      ob_str(&ob, "\"];\n");
+    }
+    rc = ob_close(&ob);
+    for (i = 0; i < g->nof_edges && !rc; i += chunk) {
+      uint64_t cnt = g->nof_edges - i < chunk ? g->nof_edges - i : chunk, nb = 0;
+      const char *text = NULL;
+      rc = gtsg_format_dot_edges_pinned(g->eng, i, cnt, &text, &nb);
+      if (rc) { engine_err(g, rc, NULL, 0); break; }
+      if (fwrite(text, 1, nb, f) != nb) rc = -1;
+    }
+    if (!rc && fwrite("}\n", 1, 2, f) != 2) rc = -1;
+    if (fclose(f) != 0) rc = rc ? rc : -1;
+    if (rc) return seterr(err, errlen, g->err[0] ? "%s" : "cannot write %s", g->err[0] ? g->err : filename);
+    return 0;
+  }
   if (refresh(g)) return seterr(err, errlen, "%s", g->err);
   f = fopen(filename, "w");
   if (!f) return seterr(err, errlen, "cannot open %s for writing", filename);
@@ -962,7 +1009,7 @@ int gt_scaffolder_graph_print(const GtScaffolderGraph *cg, const char *filename,
     ob_str(&ob, (e->flags & 1) ? "\" arrowhead=\"normal\"];\n" : "\" arrowhead=\"inv\"];\n");
   }
   ob_str(&ob, "}\n");
-  if (ob_flush(&ob)) { fclose(f); return seterr(err, errlen, "cannot write %s", filename); }
+  if (ob_close(&ob)) { fclose(f); return seterr(err, errlen, "cannot write %s", filename); }
   fclose(f);
   return 0;
 }
@@ -1044,44 +1091,100 @@ int gt_scaffolder_parser_read_distances_test(const char *filename, const char *o
    of the final states (adjacency = edges grouped by start in id order)      */
 
 static bool v_marked(uint8_t s) { return s == 1 || s == 3 || s == 7; }
-static bool e_marked(uint8_t s) { return s == 2 || s == 1 || s == 7 || s == 3; }
 
+/* The SCAFFOLD edges of the graph as a compact CSR in adjacency order (creation
+   order per vertex): the record walk looks at nothing else.  From the engine
+   (gtsg_get_scaffold_edges: a few per cent of the edge list cross the bus) or,
+   for a hand-built graph, from the host's own edge list. */
+typedef struct { uint32_t *row; REdge *e; uint64_t cnt; } ScafCsr;
+
+static void scaf_free(ScafCsr *c) { free(c->row); free(c->e); memset(c, 0, sizeof *c); }
+
+static int scaf_csr(GtScaffolderGraph *g, ScafCsr *c)
+{
+  uint64_t n = g->nof_vertices, m = g->nof_edges, k, v;
+  memset(c, 0, sizeof *c);
+  c->row = xcalloc(n + 1, sizeof *c->row);
+  if (g->eng) {
+    uint64_t cnt = 0;
+    uint32_t *eid, *end;
+    int64_t *dist;
+    float *sd;
+    uint8_t *fl;
+    int rc = gtsg_get_scaffold_edges(g->eng, &cnt, NULL, NULL, NULL, NULL, NULL, NULL);
+    if (rc) { scaf_free(c); return rc; }
+    eid = xcalloc(cnt, 4); end = xcalloc(cnt, 4); dist = xcalloc(cnt, 8); sd = xcalloc(cnt, 4);
+    fl = xcalloc(cnt, 1);
+    rc = gtsg_get_scaffold_edges(g->eng, &cnt, c->row, eid, end, dist, sd, fl);
+    if (!rc) {
+      c->e = xcalloc(cnt, sizeof *c->e);
+      c->cnt = cnt;
+      for (k = 0; k < cnt; k++) {
+        c->e[k].eid = eid[k]; c->e[k].end = end[k]; c->e[k].dist = dist[k];
+        c->e[k].std_dev = sd[k]; c->e[k].flags = fl[k];
+      }
+    }
+    free(eid); free(end); free(dist); free(sd); free(fl);
+    if (rc) { scaf_free(c); return rc; }
+    return 0;
+  }
+  /* hand-built: a vertex' list is its edges in id order */
+  for (k = 0; k < m; k++) if (g->estate[k] == 6) c->row[g->edges[k].start + 1]++;
+  for (v = 0; v < n; v++) c->row[v + 1] += c->row[v];
+  c->cnt = c->row[n];
+  c->e = xcalloc(c->cnt, sizeof *c->e);
+  {
+    uint32_t *fill = xcalloc(n, sizeof *fill);
+    for (k = 0; k < m; k++)
+      if (g->estate[k] == 6) {
+        const HEdge *x = g->edges + k;
+        REdge *o = c->e + c->row[x->start] + fill[x->start]++;
+        o->eid = (uint32_t)k; o->end = x->end; o->dist = x->dist; o->std_dev = x->std_dev; o->flags = x->flags;
+      }
+    free(fill);
+  }
+  return 0;
+}
+
+/* ref gt_scaffolder_algorithms.c:901-997.  Vertices in index order; a record
+   starts at an unvisited vertex with at most one SCAFFOLD edge and follows the
+   SCAFFOLD edges while the way on is unique.  Every test of the reference's
+   loop over a vertex' list asks for state SCAFFOLD, so the walk runs on the
+   compact CSR of those edges. */
 GtScaffolderGraphRecords *
 gt_scaffolder_graph_iterate_scaffolds(GtScaffolderGraph *g, uint64_t **scaf_seqlen)
 {
   GtScaffolderGraphRecords *r;
-  uint64_t n, m, v, k, *row, *adj, *fill, *seqlen = NULL;
+  uint64_t n, v, k, *seqlen = NULL;
   uint8_t *vs;
-  if (!g || refresh(g)) return NULL;
-  n = g->nof_vertices; m = g->nof_edges;
+  ScafCsr c;
+  if (!g) return NULL;
+  if (g->eng) {
+    int rc = gtsg_get_vertex_states(g->eng, g->vstate);
+    if (rc) { engine_err(g, rc, NULL, 0); return NULL; }
+  }
+  if (scaf_csr(g, &c) != 0) {
+    if (g->eng) engine_err(g, -1, NULL, 0);
+    return NULL;
+  }
+  n = g->nof_vertices;
   r = xcalloc(1, sizeof *r);
   r->g = g;
-  row = xcalloc(n + 1, sizeof *row);
-  adj = xcalloc(m, sizeof *adj);
-  fill = xcalloc(n, sizeof *fill);
-  if (g->eng) {
-    /* the engine's lists are the reference's: edge ids per vertex in creation order */
-    uint32_t *row32 = xcalloc(n + 1, sizeof *row32), *adj32 = xcalloc(m, sizeof *adj32);
-    if (gtsg_get_csr(g->eng, row32, adj32) != 0) {
-      free(row32); free(adj32); free(row); free(adj); free(fill); free(r);
-      return NULL;
-    }
-    for (v = 0; v <= n; v++) row[v] = row32[v];
-    for (k = 0; k < m; k++) adj[k] = adj32[k];
-    free(row32); free(adj32);
-  } else {
-    for (k = 0; k < m; k++) row[g->edges[k].start + 1]++;
-    for (v = 0; v < n; v++) row[v + 1] += row[v];
-    for (k = 0; k < m; k++) { uint32_t s = g->edges[k].start; adj[row[s] + fill[s]++] = k; }
-  }
+  /* at most a record per contig and (but for revisits) an entry per SCAFFOLD
+     edge: sized once, not grown by doubling */
+  r->cap = n ? n : 1;
+  r->root = xrealloc(NULL, r->cap * sizeof *r->root);
+  r->off = xrealloc(NULL, (r->cap + 1) * sizeof *r->off);
+  seqlen = xrealloc(NULL, r->cap * sizeof *seqlen);
+  r->capedge = c.cnt + 16;
+  r->edge = xrealloc(NULL, r->capedge * sizeof *r->edge);
   vs = g->vstate;
   for (v = 0; v < n; v++)
     if (!v_marked(vs[v]) && vs[v] != 6) vs[v] = 0;
   for (v = 0; v < n; v++) {
-    uint64_t nscaf = 0, pick = 0, len;
+    uint64_t nscaf, len;
     if (vs[v] == 4 || v_marked(vs[v])) continue;
-    for (k = row[v]; k < row[v + 1]; k++)
-      if (g->estate[adj[k]] == 6) { nscaf++; pick = adj[k]; }
+    nscaf = c.row[v + 1] - c.row[v];
     if (nscaf > 1) continue;
     if (r->n == r->cap) {
       r->cap = r->cap ? 2 * r->cap : 256;
@@ -1094,32 +1197,31 @@ gt_scaffolder_graph_iterate_scaffolds(GtScaffolderGraph *g, uint64_t **scaf_seql
     len = g->ctg[v].seq_len;
     vs[v] = 4;
     if (nscaf == 1) {
-      uint64_t cur = pick;
+      const REdge *ce = c.e + c.row[v];
+      uint32_t from = (uint32_t)v;
       for (;;) {
-        const HEdge *ce = g->edges + cur;
         uint32_t w = ce->end;
-        uint64_t cnt = 0, nxt = 0;
+        uint64_t cnt = 0;
+        const REdge *nxt = NULL;
         bool sense = ce->flags & 1, same = ce->flags & 2, dir;
         if (r->nedge == r->capedge) {
           r->capedge = r->capedge ? 2 * r->capedge : 1024;
           r->edge = xrealloc(r->edge, r->capedge * sizeof *r->edge);
         }
-        r->edge[r->nedge++] = cur;
+        r->edge[r->nedge++] = *ce;
         len += (uint64_t)ce->dist;
         len += g->ctg[w].seq_len;
         if (vs[w] == 4) break;
         vs[w] = 4;
         dir = same ? sense : !sense;
-        for (k = row[w]; k < row[w + 1]; k++) {
-          const HEdge *x = g->edges + adj[k];
-          if (((x->flags & 1) != 0) == dir && !e_marked(g->estate[adj[k]]) &&
-              !(x->end == ce->start && x->start == ce->end) && g->estate[adj[k]] == 6) {
-            cnt++;
-            nxt = adj[k];
-          }
+        for (k = c.row[w]; k < c.row[w + 1]; k++) {
+          const REdge *x = c.e + k;
+          /* (not the edge back to where the walk came from: the twin) */
+          if (((x->flags & 1) != 0) == dir && x->end != from) { cnt++; nxt = x; }
         }
         if (cnt != 1) break;
-        cur = nxt;
+        from = w;
+        ce = nxt;
       }
     }
     seqlen[r->n] = len;
@@ -1129,7 +1231,7 @@ gt_scaffolder_graph_iterate_scaffolds(GtScaffolderGraph *g, uint64_t **scaf_seql
     r->off = xrealloc(r->off, (r->n + 1) * sizeof *r->off);
     r->off[r->n] = r->nedge;
   }
-  free(row); free(adj); free(fill);
+  scaf_free(&c);
   if (scaf_seqlen) *scaf_seqlen = seqlen; else free(seqlen);
   return r;
 }
@@ -1143,23 +1245,70 @@ void gt_scaffolder_graph_records_delete(GtScaffolderGraphRecords *r)
 }
 
 /* ref gt_scaffolder_algorithms.c:1000-1042 */
+/* printf("%f") of a float, by hand: the value is a double with at most 24
+   significant bits, so the integer part and six decimals -- rounded to nearest,
+   ties to even, as glibc does on the exact value -- come out of exact double
+   arithmetic (fraction * 10^6 has at most 44 bits).  Anything else (1e15 and
+   above, infinities, NaN) goes through snprintf. */
+static void ob_f6(OutBuf *o, float x)
+{
+  double d = (double)x, a = d < 0 ? -d : d, ip, fr, y;
+  char t[32];
+  if (!(a < 1e15)) {
+    char big[400];
+    int k = snprintf(big, sizeof big, "%f", d);
+    ob_mem(o, big, (size_t)(k > 0 ? k : 0));
+    return;
+  }
+  ip = floor(a);
+  fr = a - ip;                       /* exact */
+  y = nearbyint(fr * 1e6);           /* exact product, round half to even */
+  if (y >= 1e6) { y -= 1e6; ip += 1.0; }
+  if (signbit(d)) ob_mem(o, "-", 1);
+  ob_u64(o, (uint64_t)ip);
+  {
+    uint64_t q = (uint64_t)y;
+    int k;
+    t[0] = '.';
+    for (k = 6; k >= 1; k--) { t[k] = (char)('0' + q % 10); q /= 10; }
+    ob_mem(o, t, 7);
+  }
+}
+
+/* ref gt_scaffolder_algorithms.c:1000-1040: one line per record,
+   "root\tcontig,dist,std_dev,sense,same,\t..." */
 int gt_scaffolder_graph_write_scaffold(const GtScaffolderGraphRecords *r,
                                        const char *file_name, char *err, size_t errlen)
 {
   FILE *f;
+  OutBuf obuf, *ob = &obuf;
   uint64_t i, j;
+  int bad;
   if (!r) return seterr(err, errlen, "no records");
   f = fopen(file_name, "w");
   if (!f) return seterr(err, errlen, "can not create file %s", file_name);
+  ob_init(ob, f);
   for (i = 0; i < r->n; i++) {
-    fprintf(f, "%s", r->g->ctg[r->root[i]].name);
+    ob_str(ob, r->g->ctg[r->root[i]].name);
     for (j = r->off[i]; j < r->off[i + 1]; j++) {
-      const HEdge *e = r->g->edges + r->edge[j];
-      fprintf(f, "\t%s,%ld,%f,%d,%d,", r->g->ctg[e->end].name, (long)e->dist, e->std_dev,
-              (e->flags & 1) ? 1 : 0, (e->flags & 2) ? 1 : 0);
+      const REdge *e = r->edge + j;
+      /* the headers of the end contigs are strings of their own all over the
+         heap: two cache misses an edge unless they are asked for ahead of time */
+      if (j + 16 < r->nedge) __builtin_prefetch(&r->g->ctg[r->edge[j + 16].end]);
+      if (j + 8 < r->nedge) __builtin_prefetch(r->g->ctg[r->edge[j + 8].end].name);
+      ob_mem(ob, "\t", 1);
+      ob_str(ob, r->g->ctg[e->end].name);
+      ob_mem(ob, ",", 1);
+      if (e->dist < 0) { ob_mem(ob, "-", 1); ob_u64(ob, (uint64_t)0 - (uint64_t)e->dist); }
+      else ob_u64(ob, (uint64_t)e->dist);
+      ob_mem(ob, ",", 1);
+      ob_f6(ob, e->std_dev);
+      ob_mem(ob, (e->flags & 1) ? ",1" : ",0", 2);
+      ob_mem(ob, (e->flags & 2) ? ",1," : ",0,", 3);
     }
-    fputc('\n', f);
+    ob_mem(ob, "\n", 1);
   }
-  fclose(f);
+  bad = ob_close(ob);
+  if (fclose(f) != 0 || bad) return seterr(err, errlen, "can not write file %s", file_name);
   return 0;
 }

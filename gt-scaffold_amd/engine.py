@@ -26,6 +26,7 @@ SYMBOLS = [
     "gtsg_deparser_parse", "gtsg_deparser_records", "gtsg_deparser_download", "gtsg_deparser_parse_astat",
     "gtsg_deparser_trim", "gtsg_sort_names", "gtsg_fasta_records", "gtsg_deparser_accumulate",
     "gtsg_find_edge", "gtsg_alter_edge", "gtsg_plan_weights", "gtsg_plan_deal", "gtsg_route_unpack_ex",
+    "gtsg_get_scaffold_edges", "gtsg_format_dot_edges", "gtsg_format_dot_edges_pinned",
 ]
 
 
@@ -43,7 +44,7 @@ HOST_SYMBOLS = [
     "gt_scaffolder_parser_count_distances", "gt_scaffolder_parser_read_distances",
     "gt_scaffolder_set_distance_parser", "gt_scaffolder_graph_get_edges",
     "gt_scaffolder_graph_find_edge", "gt_scaffolder_graph_get_vertex_id",
-    "gt_scaffolder_graph_get_vertex", "gt_scaffolder_graph_alter_edge",
+    "gt_scaffolder_graph_get_vertex", "gt_scaffolder_graph_alter_edge", "gt_scaffolder_set_dot_writer",
 ]
 
 
@@ -140,6 +141,7 @@ def lib():
         L.gt_scaffolder_parser_count_distances.argtypes = [vp, cp, C.POINTER(u64), cp, sz]
         L.gt_scaffolder_parser_read_distances.argtypes = [cp, vp, b, cp, sz]
         L.gt_scaffolder_set_distance_parser.argtypes = [ci]
+        L.gt_scaffolder_set_dot_writer.argtypes = [ci]
         L.gt_scaffolder_graph_get_edges.argtypes = [vp] * 7
         L.gt_scaffolder_graph_find_edge.argtypes = [vp, u64, u64]
         L.gt_scaffolder_graph_find_edge.restype = u64

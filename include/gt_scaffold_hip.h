@@ -180,6 +180,24 @@ int gtsg_get_edges(GtsgEngine *e, uint32_t *start, uint32_t *end, int64_t *dist,
    edge ids of a vertex in creation order (the order of the reference's
    vertex->edges array, graph.c:137-160) */
 int gtsg_get_csr(GtsgEngine *e, uint32_t *row, uint32_t *adj);
+/* The .dot lines of the edges first .. first + count - 1 (edge-id order) as
+   gt_scaffolder_graph_print_generic writes them (ref gt_scaffolder_graph.c:
+   288-300), formatted on the device and copied to host_buf (cap bytes; 107 per
+   edge always suffice); *nbytes = their length.  At most 2^25 edges a call. */
+int gtsg_format_dot_edges(GtsgEngine *e, uint64_t first, uint64_t count, char *host_buf,
+                          uint64_t cap, uint64_t *nbytes);
+/* the same into a page-locked buffer owned by the engine: *text points at the
+   lines until the next call on this engine */
+int gtsg_format_dot_edges_pinned(GtsgEngine *e, uint64_t first, uint64_t count,
+                                 const char **text, uint64_t *nbytes);
+/* The SCAFFOLD edges only, as a compact CSR in adjacency order: what the
+   scaffold record walk (ref gt_scaffolder_algorithms.c:901-997) and the .scaf
+   writer (:1000-1040) read of the graph after makescaffold.  *count = their
+   number; with row == NULL nothing else is written (size the arrays, call
+   again).  row: num_vertices + 1 offsets; per edge its id, end vertex,
+   distance, deviation and flags (bit 0 sense, bit 1 same).  Host pointers. */
+int gtsg_get_scaffold_edges(GtsgEngine *e, uint64_t *count, uint32_t *row, uint32_t *eid,
+                            uint32_t *end, int64_t *dist, float *std_dev, uint8_t *flags);
 /* ref gt_scaffolder_graph.c:174-193 gt_scaffolder_graph_find_edge: the id of
    the first edge in vertex_1's list (creation order) that ends in vertex_2,
    GTSG_NO_EDGE if there is none */

@@ -146,6 +146,9 @@ void gt_scaffolder_set_device(int device);
    for a file outside its regular form; 1 the host code only; 2 the GPU parser
    or an error */
 void gt_scaffolder_set_distance_parser(int mode);
+/* who formats the edge lines of gt_scaffolder_graph_print for a graph on the
+   GPU: 0 (default) the GPU (gtsg_format_dot_edges), 1 the host */
+void gt_scaffolder_set_dot_writer(int mode);
 
 #ifdef __cplusplus
 }

@@ -317,6 +317,13 @@ def test_file_api_on_synthetic_files(tmp_path):
     og.filter(); G.filter(); og.makescaffold(True); G.makescaffold()
     og.print_dot(str(tmp_path / "o.dot")); G.print_dot(str(tmp_path / "e.dot"))
     assert filecmp.cmp(tmp_path / "o.dot", tmp_path / "e.dot", shallow=False)
+    # the edge lines are formatted on the GPU (gtsg_format_dot_edges); the host's loop gives the same file
+    pkg.engine.lib().gt_scaffolder_set_dot_writer(1)
+    try:
+        G.print_dot(str(tmp_path / "h.dot"))
+    finally:
+        pkg.engine.lib().gt_scaffolder_set_dot_writer(0)
+    assert filecmp.cmp(tmp_path / "o.dot", tmp_path / "h.dot", shallow=False)
     og.write_scaffold(str(tmp_path / "o.scaf"))
     lens = G.write_scaffold(str(tmp_path / "e.scaf"))
     assert filecmp.cmp(tmp_path / "o.scaf", tmp_path / "e.scaf", shallow=False)

@@ -97,3 +97,25 @@ def test_missing_files_and_empty_de(tmp_path, golden_dir):
     bad.write_text("ACGT\n")
     with pytest.raises(engine.EngineError, match="has to be '>'"):
         engine.ScaffolderGraph.from_files(str(bad), golden_dir + "/libPE.de")
+
+
+def test_scaffold_records_of_a_hand_built_graph(tmp_path):
+    """ref algorithms.c:901-1040 on a graph built with add_vertex / add_edge (host
+    only): nothing is SCAFFOLD there, so every contig is a record of its own and
+    the .scaf file holds one header per line"""
+    L = engine.lib()
+    g = L.gt_scaffolder_graph_new(3, 2)
+    for name, ln in ((b"ctg_a", 100), (b"ctg_b", 200), (b"ctg_c", 300)):
+        assert L.gt_scaffolder_graph_add_vertex(g, name, ln, 1.0, 1.0) == 0
+    assert L.gt_scaffolder_graph_add_edge(g, 0, 1, 10, 1.5, 3, True, True) == 0
+    assert L.gt_scaffolder_graph_add_edge(g, 1, 0, 10, 1.5, 3, False, True) == 0
+    seqlen = C.POINTER(C.c_uint64)()
+    recs = L.gt_scaffolder_graph_iterate_scaffolds(g, C.byref(seqlen))
+    assert recs and L.gt_scaffolder_graph_records_size(recs) == 3
+    assert [seqlen[i] for i in range(3)] == [100, 200, 300]
+    err = C.create_string_buffer(256)
+    out = tmp_path / "hand.scaf"
+    assert L.gt_scaffolder_graph_write_scaffold(recs, str(out).encode(), err, 256) == 0
+    assert out.read_text() == "ctg_a\nctg_b\nctg_c\n"
+    L.gt_scaffolder_graph_records_delete(recs)
+    L.gt_scaffolder_graph_delete(g)
