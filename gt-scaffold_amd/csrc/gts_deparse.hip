@@ -75,7 +75,10 @@ struct GtsgDeParser {
   float *sd;
   uint8_t *flags, *valid;
   uint32_t *cand_cnt;               /* per stride, then its exclusive scan */
-  uint32_t *scan_tmp;
+  uint32_t *scan_tmp;               /* scratch of the prefix sums, grown like the rest (scan_cap u32) */
+  uint64_t scan_cap;
+  uint32_t *cpos;                   /* positions of the compaction (cpos_cap u32) */
+  uint64_t cpos_cap;
   uint64_t cap_cand, cap_blocks;
   /* compacted copies (only when a candidate is not a record) */
   uint32_t *root2, *ctg2;
@@ -344,7 +347,12 @@ k_dp_stride(const char *text, uint64_t len, uint32_t *cand_cnt, const uint32_t *
     uint32_t root = DP_NONE, ntl = 0;
     if (f != 0xFFFFu) {
       uint32_t e = tok_start[f];
-      while (e < n && txt[e] != ' ' && txt[e] != '\n') ++e;
+      /* the reference's token loop starts AT the root field (parser.c:338): a
+         first token that looks like a separator or like a record is scanned as
+         one there -- such a line is the host's */
+      bool odd = txt[e] == ';';
+      while (e < n && txt[e] != ' ' && txt[e] != '\n') { odd |= txt[e] == ','; ++e; }
+      if (odd) atomicOr(res + 1, 1ull);
       root = dp_lookup(txt, tok_start[f], e, names, name_off, table, mask);
       /* tokens of the line: up to the next line that has one */
       uint32_t g = f + 1;
@@ -717,6 +725,20 @@ int gtsg_deparser_create(GtsgDeParser **out, int device, void *stream)
   return 0;
 }
 
+/* scratch of the parser's prefix sums: kept between calls (a file in pieces is
+   one call per piece), grown when a call needs more */
+static int dp_scan_scratch(GtsgDeParser *p, uint64_t elems)
+{
+  if (p->scan_cap >= elems) return 0;
+  if (p->scan_tmp) hipFree(p->scan_tmp);
+  p->scan_tmp = nullptr; p->scan_cap = 0;
+  if (hipMalloc((void **)&p->scan_tmp, elems * sizeof(uint32_t)) != hipSuccess) {
+    snprintf(p->err, sizeof p->err, "out of device memory (scan scratch)");
+    return GTSG_ENOMEM;
+  }
+  p->scan_cap = elems;
+  return 0;
+}
 static void dp_free_acc(GtsgDeParser *p)
 {
   void *ptrs[] = {p->a_root, p->a_ctg, p->a_dist, p->a_np, p->a_sd, p->a_flags};
@@ -728,9 +750,10 @@ static void dp_free_acc(GtsgDeParser *p)
 static void dp_free_parse(GtsgDeParser *p)
 {
   void *ptrs[] = {p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->valid, p->cand_cnt, p->scan_tmp,
-                  p->root2, p->ctg2, p->dist2, p->np2, p->sd2, p->flags2};
+                  p->cpos, p->root2, p->ctg2, p->dist2, p->np2, p->sd2, p->flags2};
   for (void *q : ptrs) if (q) hipFree(q);
-  p->root = p->ctg = p->root2 = p->ctg2 = p->cand_cnt = p->scan_tmp = nullptr;
+  p->root = p->ctg = p->root2 = p->ctg2 = p->cand_cnt = p->scan_tmp = p->cpos = nullptr;
+  p->scan_cap = p->cpos_cap = 0;
   p->dist = p->np = p->dist2 = p->np2 = nullptr;
   p->sd = p->sd2 = nullptr;
   p->flags = p->valid = p->flags2 = nullptr;
@@ -837,8 +860,7 @@ int gtsg_deparser_parse(GtsgDeParser *p, const char *text, uint64_t len, int on_
   if (nblocks >= 0x7FFFFFFFull) return dp_fail(p, GTSG_ELIMIT, "distance file too large");
   if (p->cap_blocks < nblocks + 1) {
     if (p->cand_cnt) hipFree(p->cand_cnt);
-    if (p->scan_tmp) hipFree(p->scan_tmp);
-    p->cand_cnt = p->scan_tmp = nullptr; p->cap_blocks = 0;
+    p->cand_cnt = nullptr; p->cap_blocks = 0;
     DPCHK(hipMalloc((void **)&p->cand_cnt, (nblocks + 1) * sizeof(uint32_t)));
     p->cap_blocks = nblocks + 1;
   }
@@ -849,11 +871,8 @@ int gtsg_deparser_parse(GtsgDeParser *p, const char *text, uint64_t len, int on_
       nullptr, nullptr, nullptr, p->d_res);
   /* candidates per stride -> bases; a text of n bytes holds fewer than n / 2 tokens */
   {
-    const uint64_t need = gts_scan_tmp_elems(nblocks + 1) + 2;
-    uint32_t *tmp = nullptr;
-    DPCHK(hipMalloc((void **)&tmp, need * sizeof(uint32_t)));
-    if (p->scan_tmp) hipFree(p->scan_tmp);
-    p->scan_tmp = tmp;
+    const int rcs = dp_scan_scratch(p, gts_scan_tmp_elems(nblocks + 1) + 2);
+    if (rcs) return rcs;
     gts_exscan<uint32_t, uint32_t>(p->cand_cnt, p->cand_cnt, nblocks, p->scan_tmp, (uint32_t *)(p->d_res + 3), p->st);
   }
   unsigned long long h[4];
@@ -905,19 +924,21 @@ int gtsg_deparser_parse(GtsgDeParser *p, const char *text, uint64_t len, int on_
       DPCHK(hipMalloc((void **)&p->sd2, c * 4)); DPCHK(hipMalloc((void **)&p->flags2, c));
       p->cap2 = c;
     }
-    uint32_t *pos = nullptr, *tmp = nullptr;
-    DPCHK(hipMalloc((void **)&pos, (ncand + 1) * 4));
-    if (hipMalloc((void **)&tmp, (gts_scan_tmp_elems(ncand) + 2) * 4) != hipSuccess) {
-      hipFree(pos);
-      return dp_fail(p, GTSG_ENOMEM, "out of device memory");
+    if (p->cpos_cap < ncand + 1) {
+      if (p->cpos) hipFree(p->cpos);
+      p->cpos = nullptr; p->cpos_cap = 0;
+      DPCHK(hipMalloc((void **)&p->cpos, (ncand + 1) * 4));
+      p->cpos_cap = ncand + 1;
     }
-    gts_exscan<uint8_t, uint32_t>(p->valid, pos, ncand, tmp, (uint32_t *)nullptr, p->st);
+    {
+      const int rcs = dp_scan_scratch(p, gts_scan_tmp_elems(ncand) + 2);
+      if (rcs) return rcs;
+    }
+    gts_exscan<uint8_t, uint32_t>(p->valid, p->cpos, ncand, p->scan_tmp, (uint32_t *)nullptr, p->st);
     k_dp_compact<<<(uint32_t)((ncand + 255) / 256), 256, 0, p->st>>>(
-        p->valid, pos, ncand, p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->root2, p->ctg2, p->dist2,
+        p->valid, p->cpos, ncand, p->root, p->ctg, p->dist, p->np, p->sd, p->flags, p->root2, p->ctg2, p->dist2,
         p->np2, p->sd2, p->flags2);
-    hipError_t es = hipStreamSynchronize(p->st);
-    hipFree(pos); hipFree(tmp);
-    DPCHK(es);
+    DPCHK(hipStreamSynchronize(p->st));
     DPCHK(hipGetLastError());
     p->compacted = true;
   }
@@ -927,9 +948,13 @@ int gtsg_deparser_parse(GtsgDeParser *p, const char *text, uint64_t len, int on_
       uint64_t cap = p->a_cap ? p->a_cap : 1u << 20;
       while (cap < need) cap *= 2;
       uint32_t *r2 = nullptr, *c2 = nullptr; int64_t *d2 = nullptr, *n2 = nullptr; float *s2 = nullptr; uint8_t *f2 = nullptr;
-      DPCHK(hipMalloc((void **)&r2, cap * 4)); DPCHK(hipMalloc((void **)&c2, cap * 4));
-      DPCHK(hipMalloc((void **)&d2, cap * 8)); DPCHK(hipMalloc((void **)&n2, cap * 8));
-      DPCHK(hipMalloc((void **)&s2, cap * 4)); DPCHK(hipMalloc((void **)&f2, cap));
+      if (hipMalloc((void **)&r2, cap * 4) != hipSuccess || hipMalloc((void **)&c2, cap * 4) != hipSuccess ||
+          hipMalloc((void **)&d2, cap * 8) != hipSuccess || hipMalloc((void **)&n2, cap * 8) != hipSuccess ||
+          hipMalloc((void **)&s2, cap * 4) != hipSuccess || hipMalloc((void **)&f2, cap) != hipSuccess) {
+        void *tmpv[] = {r2, c2, d2, n2, s2, f2};
+        for (void *q : tmpv) if (q) hipFree(q);
+        return dp_fail(p, GTSG_ENOMEM, "out of device memory (record accumulator)");
+      }
       if (p->a_n) {
         DPCHK(hipMemcpyAsync(r2, p->a_root, p->a_n * 4, hipMemcpyDeviceToDevice, p->st));
         DPCHK(hipMemcpyAsync(c2, p->a_ctg, p->a_n * 4, hipMemcpyDeviceToDevice, p->st));
@@ -1180,16 +1205,19 @@ int gtsg_deparser_download(GtsgDeParser *p, uint32_t *root, uint32_t *ctg, int64
                            int64_t *num_pairs, uint8_t *flags)
 {
   if (!p) return GTSG_EINVAL;
-  const uint64_t n = p->n_records;
+  /* the records gtsg_deparser_records hands out: all pieces in accumulate mode,
+     else those of the last parse */
+  const bool acc = p->accumulate;
+  const uint64_t n = acc ? p->a_n : p->n_records;
   if (!n) return 0;
   DPCHK(hipSetDevice(p->device));
   const bool c = p->compacted;
-  if (root) DPCHK(hipMemcpy(root, c ? p->root2 : p->root, n * 4, hipMemcpyDeviceToHost));
-  if (ctg) DPCHK(hipMemcpy(ctg, c ? p->ctg2 : p->ctg, n * 4, hipMemcpyDeviceToHost));
-  if (dist) DPCHK(hipMemcpy(dist, c ? p->dist2 : p->dist, n * 8, hipMemcpyDeviceToHost));
-  if (std_dev) DPCHK(hipMemcpy(std_dev, c ? p->sd2 : p->sd, n * 4, hipMemcpyDeviceToHost));
-  if (num_pairs) DPCHK(hipMemcpy(num_pairs, c ? p->np2 : p->np, n * 8, hipMemcpyDeviceToHost));
-  if (flags) DPCHK(hipMemcpy(flags, c ? p->flags2 : p->flags, n, hipMemcpyDeviceToHost));
+  if (root) DPCHK(hipMemcpy(root, acc ? p->a_root : c ? p->root2 : p->root, n * 4, hipMemcpyDeviceToHost));
+  if (ctg) DPCHK(hipMemcpy(ctg, acc ? p->a_ctg : c ? p->ctg2 : p->ctg, n * 4, hipMemcpyDeviceToHost));
+  if (dist) DPCHK(hipMemcpy(dist, acc ? p->a_dist : c ? p->dist2 : p->dist, n * 8, hipMemcpyDeviceToHost));
+  if (std_dev) DPCHK(hipMemcpy(std_dev, acc ? p->a_sd : c ? p->sd2 : p->sd, n * 4, hipMemcpyDeviceToHost));
+  if (num_pairs) DPCHK(hipMemcpy(num_pairs, acc ? p->a_np : c ? p->np2 : p->np, n * 8, hipMemcpyDeviceToHost));
+  if (flags) DPCHK(hipMemcpy(flags, acc ? p->a_flags : c ? p->flags2 : p->flags, n, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -140,6 +140,7 @@ struct GtsgEngine {
   int64_t task_reference_walks = 1;
   int64_t pool_components = 1;        /* all LDS components in one launch (k_components_pool) */
   int64_t pool_waves = GTS_POOL_WAVES; /* wavefronts per workgroup of that launch */
+  int64_t pool_fill_kb = 4;            /* the pool's fill cursor starts at the components of at most this footprint */
   int64_t gather_unroll = 4;           /* edges a thread of the gather-shaped build kernels (1: A/B measurements) */
   int64_t lds_poison = -1;             /* test aid: fill a component's pages with this byte before staging */
   int64_t pool_wait_limit_us = 10000000; /* bound of every wait inside that launch (0: test aid, a wait gives up at once) */
@@ -1265,10 +1266,13 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
    by LDS at the start and by wave slots at the end, not by one of them after
    the other as a launch per size class is.
 
-   Claims: one 64-bit counter, a front claim of B adds B, a back claim B * 2^32;
-   the value before the add (h, t) gives the indices h .. h+B-1 resp.
-   count-1-t downwards, those of them valid that the other end has not reached
-   (h' + t' < count) -- every index is handed out once.  The workgroup claims
+   Claims: one 64-bit counter, a front claim of B adds B, a fill ("back") claim
+   B * 2^32; the value before the add (h, t) gives the indices h .. h+B-1 below
+   g0 resp. g0+t .. g0+t+B-1 below count, g0 = the first component of at most
+   two pages -- every index is handed out once.  Both cursors move towards the
+   smaller components (round 2: the back cursor came up from the smallest and
+   the two met among components of 50 - 80 contigs, where one that is not clean
+   takes milliseconds: they set a tail of 1.4 ms).  The workgroup claims
    for its wavefronts and keeps the indices in stock (a single counter hit
    once per component by 4096 wavefronts is what the launch would wait for:
    same-address atomics across the XCDs run at a few tens per microsecond):
@@ -1360,7 +1364,7 @@ __global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
 k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_key, uint32_t first,
                   uint32_t count, int mode,
                   unsigned long long *cursor, unsigned long long *pstat, uint32_t nbig, int poison,
-                  uint64_t wait_limit)
+                  uint64_t wait_limit, uint32_t g0)
 {
   /* pstat (100 MHz ticks, summed over the wavefronts): [0] staging + program,
      [1] waiting for pages, [2] whole life of the wavefront; [3] first exit,
@@ -1394,8 +1398,8 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
           if (v->f_next == v->f_end && !v->f_done) {
             const uint32_t want = v->f_end < nbig ? 1u : GTS_POOL_BATCH;
             const unsigned long long old = atomicAdd(cursor, (unsigned long long)want);
-            const uint64_t h = old & 0xFFFFFFFFull, t = old >> 32;
-            const uint64_t lim = (uint64_t)count > t ? (uint64_t)count - t : 0;   /* the back holds [lim, count) */
+            const uint64_t h = old & 0xFFFFFFFFull;
+            const uint64_t lim = g0;                                              /* the fill cursor holds [g0, count) */
             if (h < lim) { v->f_next = (uint32_t)h; v->f_end = (uint32_t)(h + want < lim ? h + want : lim); }
             else v->f_done = 1;
           }
@@ -1405,12 +1409,12 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
         if (!front) {
           if (v->b_cnt == 0 && !v->b_done) {
             const unsigned long long old = atomicAdd(cursor, (unsigned long long)GTS_POOL_BATCH << 32);
-            const uint64_t h = old & 0xFFFFFFFFull, t = old >> 32;
-            const uint64_t avail = h + t < (uint64_t)count ? (uint64_t)count - h - t : 0;
-            if (avail) { v->b_next = count - 1u - (uint32_t)t; v->b_cnt = (uint32_t)(avail < GTS_POOL_BATCH ? avail : GTS_POOL_BATCH); }
+            const uint64_t t = old >> 32, at = (uint64_t)g0 + t;
+            const uint64_t avail = at < (uint64_t)count ? (uint64_t)count - at : 0;
+            if (avail) { v->b_next = (uint32_t)at; v->b_cnt = (uint32_t)(avail < GTS_POOL_BATCH ? avail : GTS_POOL_BATCH); }
             else v->b_done = 1;
           }
-          if (v->b_cnt) { idx = v->b_next; v->b_next = idx - 1u; v->b_cnt = v->b_cnt - 1u; }
+          if (v->b_cnt) { idx = v->b_next; v->b_next = idx + 1u; v->b_cnt = v->b_cnt - 1u; }
         }
         /* nothing for this wavefront now, but the front (held by the one that
            waits for pages) has: look again later */
@@ -1845,6 +1849,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "pool_waves") && value >= 1 && value <= GTS_POOL_WAVES) e->pool_waves = value;
   else if (!strcmp(name, "lds_poison") && value >= -1 && value <= 255) e->lds_poison = value;
   else if (!strcmp(name, "gather_unroll") && value >= 1) e->gather_unroll = value;
+  else if (!strcmp(name, "pool_fill_kb") && value >= 0) e->pool_fill_kb = value;
   else if (!strcmp(name, "pool_wait_limit_us") && value >= 0) e->pool_wait_limit_us = value;
   else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NSTREAMS) e->class_streams = value;
   else if (!strcmp(name, "mixed_task_limit") && value >= 0) e->mixed_task_limit = value;
@@ -2774,6 +2779,13 @@ static int run_components(GtsgEngine *e, int mode)
         hipStream_t ss = e->side[0];
         uint32_t nbig = 0;   /* components above 8 KB: claimed one at a time */
         for (uint32_t k = 0; k < nk; ++k) if (klass_h[k] > 8192u) nbig += kcount[k];
+        /* the fill cursor starts where the footprints fit two pages and moves on
+           towards the smallest: the last components claimed are the smallest, so
+           a component that turns out slow (not clean: ten times the time per
+           contig) cannot start late and set the launch's tail */
+        uint32_t g0 = 0;
+        for (uint32_t k = 0; k < nk; ++k) if (klass_h[k] > (uint32_t)e->pool_fill_kb * 1024u) g0 += kcount[k];
+        if (g0 > pooled) g0 = pooled;
         unsigned long long *cursor = (unsigned long long *)(e->d_scalars + GTS_S_POOLCUR);
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         HIPCHK(hipMemsetAsync(cursor, 0, 8, ss));
@@ -2786,7 +2798,7 @@ static int run_components(GtsgEngine *e, int mode)
         const uint32_t pw = (uint32_t)e->pool_waves;
         k_components_pool<<<e->n_cus, pw * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, order, order_key, first, pooled, mode,
                                                                           cursor, pstat, nbig, (int)e->lds_poison,
-                                                                          (uint64_t)e->pool_wait_limit_us * 100ull);
+                                                                          (uint64_t)e->pool_wait_limit_us * 100ull, g0);
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_pool"
                                                                               : "components_removecycles_pool",

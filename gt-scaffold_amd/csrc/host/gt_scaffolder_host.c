@@ -49,6 +49,7 @@ struct GtScaffolderGraph {
   GtsgEngine *eng;           /* NULL for hand-built graphs */
   GtsgDeParser *dp;          /* GPU parser of the distance file (holds the name table) */
   bool dp_names;             /* its name table is the sorted headers */
+  bool dup_names;            /* two contigs share a header: the GPU name table would pick either */
   bool sorted;               /* contigs in header order (ids are final) */
   char err[512];
 };
@@ -370,10 +371,19 @@ static int scan_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len
    14 bytes are sorted on the GPU (gtsg_sort_names, two radix sorts), runs that
    agree in them with qsort / strcmp here. */
 #define GPU_SORT_MIN 50000u
+static void sort_contigs_inner(GtScaffolderGraph *g);
 static void sort_contigs(GtScaffolderGraph *g)
 {
-  uint64_t n = g->nof_vertices;
+  uint64_t i;
   if (g->sorted) return;
+  sort_contigs_inner(g);
+  g->dup_names = false;
+  for (i = 1; i < g->nof_vertices && !g->dup_names; i++)
+    g->dup_names = strcmp(g->ctg[i - 1].name, g->ctg[i].name) == 0;
+}
+static void sort_contigs_inner(GtScaffolderGraph *g)
+{
+  uint64_t n = g->nof_vertices;
   g->sorted = true;
   if (n >= GPU_SORT_MIN && g_host_parser != 1) {
     uint64_t i, total = 0, *off = xcalloc(n + 1, sizeof *off);
@@ -567,6 +577,12 @@ static int ensure_parser(GtScaffolderGraph *g, int *have, char *err, size_t errl
   *have = 0;
   if (g_host_parser == 1) return 0;
   sort_contigs(g);
+  if (g->dup_names) {
+    /* which of two equal headers a look-up returns is fixed for the host's
+       binary search and a matter of insertion order for the GPU table */
+    if (g_host_parser == 2) return seterr(err, errlen, "duplicate contig headers: the GPU distance parser does not take them");
+    return 0;
+  }
   if (!g->dp) {
     if (gtsg_deparser_create(&g->dp, g_device, NULL) != 0) {
       g->dp = NULL;

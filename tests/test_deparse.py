@@ -151,6 +151,10 @@ IRREGULAR = {
     "inf": "c0 c1+,10,5,inf ;\n",
     "twenty_significant_digits": "c0 c1+,10,5,1.2345678901234567891 ;\n",
     "semicolon_token": "c0 ;c1+,10,5,1.5\n",
+    # the reference's token loop starts at the root field (parser.c:338): a root that
+    # looks like a separator or like a record is scanned as one there
+    "root_is_a_separator": "; c1+,10,5,1.5 ;\n",
+    "root_with_commas": "c0,1,2,3.5 c1+,10,5,1.5 ;\n",
     "long_line": "c0 " + " ".join("c1+,10,5,1.5" for _ in range(90)) + " ;\n",
 }
 
@@ -429,3 +433,50 @@ def test_distance_file_in_pieces(tmp_path, monkeypatch):
     monkeypatch.delenv("GTS_DE_CHUNK")
     same_edges(pieces, whole)
     same_edges(pieces, graph_arrays(fa, de, 1))
+
+
+def test_duplicate_headers_go_to_the_host_parser(tmp_path):
+    """two contigs with one header: the host's binary search has a fixed answer,
+    the GPU name table would return whichever was inserted first -- such a contig
+    file sends the distance file to the host code (mode 2: an error)"""
+    fa, de = str(tmp_path / "d.fa"), str(tmp_path / "d.de")
+    write_fasta(fa, ["c0", "c1", "c1", "c2"])
+    with open(de, "w") as f:
+        f.write("c0 c1+,10,5,1.5 ; c2-,7,3,2.25\nc1 c2+,4,2,0.5 ;\n")
+    same_edges(graph_arrays(fa, de, 0), graph_arrays(fa, de, 1))
+    host_mode(2)
+    with pytest.raises(engine.EngineError, match="duplicate contig headers"):
+        engine.ScaffolderGraph.from_files(fa, de, 200)
+
+
+def test_contigs_read_after_the_name_table_was_uploaded(tmp_path):
+    """read_contigs, count_distances (sorts the vertices, uploads the GPU parser's
+    name table), read_contigs again: the vertex set has changed, the table is
+    stale and must be rebuilt -- same edges as with the host parser"""
+    L = engine.lib()
+    fa1, fa2, de = str(tmp_path / "a.fa"), str(tmp_path / "b.fa"), str(tmp_path / "x.de")
+    write_fasta(fa1, ["c%02d" % i for i in range(0, 40, 2)])
+    write_fasta(fa2, ["c%02d" % i for i in range(1, 40, 2)])
+    with open(de, "w") as f:
+        for i in range(0, 38):      # neighbours (one of the two is missing at first) and next-but-one
+            f.write("c%02d c%02d+,%d,5,1.5 ; c%02d-,%d,4,2.5\n" % (i, i + 1, 10 + i, i + 2, 50 + i))
+    out = []
+    for mode in (1, 0):
+        host_mode(mode)
+        err = C.create_string_buffer(512)
+        h = C.c_void_p(L.gt_scaffolder_graph_new(40, 0))
+        nd = C.c_uint64()
+        assert L.gt_scaffolder_parser_read_contigs(h, fa1.encode(), 200, False, err, 512) == 0, err.value
+        assert L.gt_scaffolder_parser_count_distances(h, de.encode(), C.byref(nd), err, 512) == 0, err.value
+        assert L.gt_scaffolder_parser_read_contigs(h, fa2.encode(), 200, False, err, 512) == 0, err.value
+        assert L.gt_scaffolder_parser_count_distances(h, de.encode(), C.byref(nd), err, 512) == 0, err.value
+        assert L.gt_scaffolder_parser_read_distances(de.encode(), h, False, err, 512) == 0, err.value
+        m = int(L.gt_scaffolder_graph_nof_edges(h))
+        assert m == 4 * 38
+        a = {k: np.zeros(m, dt) for k, dt in (("start", np.uint32), ("end", np.uint32), ("dist", np.int64),
+                                               ("std_dev", np.float32), ("num_pairs", np.int64), ("flags", np.uint8))}
+        assert L.gt_scaffolder_graph_get_edges(h, *[a[k].ctypes.data_as(C.c_void_p) for k in a]) == 0
+        out.append(a)
+        L.gt_scaffolder_graph_delete(h)
+    same_edges(out[0], out[1])
+    assert list(out[0]["start"][:4]) == [0, 1, 0, 2]      # ids are the ranks among all forty headers
