@@ -124,12 +124,12 @@ def kernel_groups(kt):
 PMC_NAMES = {
     "build_sort_pairs": ["k_onesweep_hist<unsigned long>", "k_radix_scatter<unsigned long, 12>"],
     "build_pair_keys": ["k_pair_keys"], "build_pair_segments": ["k_pair_segments"],
-    "build_emit_edges": ["k_emit_edges"], "build_gather_csr": ["k_gather_csr"],
-    "build_twins": ["k_twins"], "repeat_edges": ["k_repeat_edges"],
+    "build_emit_edges": ["k_emit_edges"], "build_gather_csr": ["k_gather_csr<4>", "k_gather_csr<1>", "k_gather_csr"],
+    "build_twins": ["k_twins<4>", "k_twins<1>", "k_twins"], "repeat_edges": ["k_repeat_edges"],
     "filter_pairs": ["k_filter_pairs"], "filter_ovf_init": ["k_filter_ovf_init"],
     "filter_final": ["k_filter_final"], "filter_tpoly": ["k_filter_tpoly"],
     "filter_lasthit": ["k_filter_lasthit"], "comp_live_union": ["k_live_union"],
-    "comp_compact_fill": ["k_compact_fill"], "build_twins": ["k_twins"],
+    "comp_compact_fill": ["k_compact_fill"],
 }
 
 

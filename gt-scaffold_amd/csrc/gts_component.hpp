@@ -285,6 +285,14 @@ struct GtsCompMemT {
      with distmap.  0 slots: no batched walks (global arrays). */
   GTS_P(char) wbase;
   uint32_t wslots;
+  /* walk tasks only (or null): the arcs of every vertex split by sense -- sarc
+     holds the compact edges of vertex v with sense 1 in list order at
+     [coff[v], smid[v]) and those with sense 0 at [smid[v], coff[v+1]).  The
+     reference's search relaxes only the arcs that leave a vertex in the node's
+     direction (algorithms.c:699): with the split view half as many lanes carry
+     an arc that cannot be relaxed (create_walk_reference) */
+  GTS_P(const idx_t) sarc;
+  GTS_P(const idx_t) smid;
 };
 typedef GtsCompMemT<false> GtsCompMem;
 
@@ -345,7 +353,7 @@ GTS_HD uint32_t gts_comp_lds_want(uint32_t nv, uint32_t ne, uint32_t big_nv, uin
 /* (float)GT_WORD_MAX, ref algorithms.c:650 */
 #define GTS_DIST_UNSET 9223372036854775808.0f
 
-template <class W, bool LDS = false>
+template <class W, bool LDS = false, bool SPLIT = false>
 struct GtsComponent {
   const GtsCompView &C;
   const GtsCompMemT<LDS> &M;
@@ -396,7 +404,7 @@ struct GtsComponent {
     m.ccoff = C.ccoff + s0 + comp; m.st_dir = C.st_dir + s0; m.tight = C.tight + s0;
     m.distmap = C.distmap + s0; m.nd = C.nd + s0; m.plen = C.plen + s0;
     m.gorient = C.gorient + s0; m.topo = C.topo + s0; m.tpos = C.tpos + s0;
-    m.wbase = nullptr; m.wslots = 0;
+    m.wbase = nullptr; m.wslots = 0; m.sarc = nullptr; m.smid = nullptr;
     return m;
   }
 
@@ -761,7 +769,11 @@ struct GtsComponent {
       }
       const uint64_t len0 = cc_len;
       const uint32_t n0 = cc_n;
-      if (create_walk_reference_once(start, cc_len, cc_n)) return true;
+      bool done;
+      if constexpr (SPLIT) done = M.sarc ? create_walk_reference_once<true>(start, cc_len, cc_n)
+                                         : create_walk_reference_once<false>(start, cc_len, cc_n);
+      else done = create_walk_reference_once<false>(start, cc_len, cc_n);
+      if (done) return true;
       if (err != GTS_CERR_WALKQ_OVERFLOW) return false;
       const uint64_t need = qcap * 8;
       const uint64_t off = W::alloc(C.wq_used, need);
@@ -771,6 +783,8 @@ struct GtsComponent {
     }
   }
 
+  /* SV: the split view of the arcs (GtsCompMemT::sarc) is there */
+  template <bool SV>
   GTS_HD bool create_walk_reference_once(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     const uint32_t lane = W::lane();
@@ -780,6 +794,18 @@ struct GtsComponent {
     bool ok = true;
     /* lastpop may share its storage with the labels of the linear walks */
     for (uint32_t s = lane; s < nv; s += W::WIDTH) M.lastpop[s] = 0;
+    if constexpr (SV) {
+      /* which vertices are terminals (algorithms.c:694: no live edge in one of
+         the two senses) does not change during a walk: once per vertex here
+         instead of once per popped node from the node's own arcs */
+      for (uint32_t s = lane; s < nv; s += W::WIDTH) {
+        const uint32_t b = M.coff[s], m = M.smid[s], e = M.coff[s + 1];
+        bool hs = false, ha = false;
+        for (uint32_t k = b; k < m; ++k) hs |= !gts_edge_is_marked(M.cstate[M.sarc[k]]);
+        for (uint32_t k = m; k < e; ++k) ha |= !gts_edge_is_marked(M.cstate[M.sarc[k]]);
+        M.tight[s] = (hs && ha) ? 0 : 1;
+      }
+    }
     W::fence();
     /* seed with the start's live edges, algorithms.c:661-679 */
     {
@@ -841,7 +867,11 @@ struct GtsComponent {
         if constexpr (LDS) from = pw >> 16; else from = M.cstart[pe];
         dir = gts_next_dir(M.cflags[pe]);
         eb = M.coff[endv] - M.e0;
-        const uint32_t ee = M.coff[endv + 1] - M.e0;
+        uint32_t ee = M.coff[endv + 1] - M.e0;
+        if constexpr (SV) {      /* only the arcs that leave in the node's direction */
+          const uint32_t mid = M.smid[endv];
+          if (dir) ee = mid; else eb = mid;
+        }
         if (lane == 0) eb += cur_off;
         deg = ee - eb;
       }
@@ -869,8 +899,9 @@ struct GtsComponent {
       float distance = 0.0f, old = 0.0f;
       if (act) {
         ce = r_eb + (lane - r_excl);
+        if constexpr (SV) ce = M.sarc[ce];
         live = !gts_edge_is_marked(M.cstate[ce]);
-        sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
+        sense = SV ? r_dir : (M.cflags[ce] & GTS_F_SENSE) != 0;
         nb = M.cend[ce];
         q = live && sense == r_dir && nb != r_from && !gts_vertex_is_marked(M.vst[nb]);
         distance = (float)(r_nd + M.cdist[ce]);
@@ -920,10 +951,13 @@ struct GtsComponent {
       const uint32_t ndone = W::popc(W::ballot(done));
       bool term = false;
       if (done) {
-        const uint64_t mine = W::range_mask(excl, incl);
-        const bool hs = (bs & mine) != 0 || (lane == 0 && carry_s);
-        const bool ha = (ba & mine) != 0 || (lane == 0 && carry_a);
-        term = !(hs && ha);          /* algorithms.c:694 */
+        if constexpr (SV) term = M.tight[endv] != 0;
+        else {
+          const uint64_t mine = W::range_mask(excl, incl);
+          const bool hs = (bs & mine) != 0 || (lane == 0 && carry_s);
+          const bool ha = (ba & mine) != 0 || (lane == 0 && carry_a);
+          term = !(hs && ha);          /* algorithms.c:694 */
+        }
       }
       uint32_t prev = 1;
       if (term)                      /* remember the LAST pop of a terminal */
@@ -1006,6 +1040,8 @@ struct GtsComponent {
     }
     for (uint32_t k = lane; k < nwt; k += W::WIDTH)
       M.lastpop[M.wterm[k]] = 0;
+    if constexpr (SV)
+      for (uint32_t s = lane; s < nv; s += W::WIDTH) M.tight[s] = 0;
     W::fence();
     return ok;
   }

@@ -1215,10 +1215,20 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   M.queue = lds_carve<idx_t>(p, nv); M.visited = lds_carve<idx_t>(p, nv);
   M.st_v = lds_carve<idx_t>(p, nv); M.wterm = lds_carve<idx_t>(p, nv);
   M.st_par = lds_carve<idx_t>(p, nv);
+  M.sarc = nullptr; M.smid = nullptr;
+  idx_t __attribute__((address_space(3))) *sarc = nullptr, *smid = nullptr;
   {
     const uint32_t need = (uint32_t)(p - (gts_lds_cursor)smem);
-    const uint32_t more = avail > need ? (avail - need) / gts_walk_slot_bytes(nv) : 0u;
-    M.wslots = 2u + more < GTS_WALK_SLOTS_MAX ? 2u + more : GTS_WALK_SLOTS_MAX;
+    if (with_analysis) {
+      /* a walk task: what the launch has behind the footprint holds the arcs
+         split by sense for the reference's search (GtsCompMemT::sarc) */
+      const uint32_t vb = ((ne * 2u + 15u) / 16u) * 16u + (((nv + 1u) * 2u + 15u) / 16u) * 16u;
+      M.wslots = 2u;
+      if (avail >= need + vb) { sarc = lds_carve<idx_t>(p, ne); smid = lds_carve<idx_t>(p, nv + 1); }
+    } else {
+      const uint32_t more = avail > need ? (avail - need) / gts_walk_slot_bytes(nv) : 0u;
+      M.wslots = 2u + more < GTS_WALK_SLOTS_MAX ? 2u + more : GTS_WALK_SLOTS_MAX;
+    }
   }
   /* never live at the same time (gts_comp_lds_bytes) */
   M.st_cur = M.cc_best; M.touched = M.visited;
@@ -1239,6 +1249,18 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
     cfs[i] = (uint8_t)((G0.cflags[i] & 15u) | (G0.cstate[i] << 4));
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (sarc) {
+    /* stable partition of every list by sense, a lane per vertex */
+    for (uint32_t v = lane; v < nv; v += GTS_WAVE) {
+      const uint32_t b = coff[v], e = coff[v + 1];
+      uint32_t k = b;
+      for (uint32_t ce = b; ce < e; ++ce) if (cfs[ce] & GTS_F_SENSE) sarc[k++] = (idx_t)ce;
+      smid[v] = (idx_t)k;
+      for (uint32_t ce = b; ce < e; ++ce) if (!(cfs[ce] & GTS_F_SENSE)) sarc[k++] = (idx_t)ce;
+    }
+    M.sarc = sarc; M.smid = smid;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
 }
 __global__ void __launch_bounds__(GTS_WAVE)
 k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
@@ -1505,22 +1527,22 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
    launched once per LDS size class, a workgroup whose task belongs to another
    class leaves at once */
 __global__ void __launch_bounds__(GTS_WAVE)
-k_walk_tasks(GtsCompView C, uint32_t klass, uint32_t count)
+k_walk_tasks(GtsCompView C, uint32_t klass, uint32_t count, uint32_t lds_bytes)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (blockIdx.x >= count) return;
   const uint32_t t = C.tq[C.tq_base[klass] + blockIdx.x];
   const uint32_t c = C.task_comp[t];
   GtsCompMemT<true> M;
-  stage_component(C, c, smem, M, true, 0u);
-  GtsComponent<GtsWave64, true> prog(C, M, c);
+  stage_component(C, c, smem, M, true, lds_bytes);
+  GtsComponent<GtsWave64, true, true> prog(C, M, c);
   prog.walk_task(t);
 }
 /* the same for the pending tasks of all classes in one launch (few tasks: the
    rounds after the first), with the LDS of the largest class among them */
 struct GtsTaskPrefix { uint32_t pre[GTS_NKLASS + 1]; };
 __global__ void __launch_bounds__(GTS_WAVE)
-k_walk_tasks_mixed(GtsCompView C, GtsTaskPrefix P)
+k_walk_tasks_mixed(GtsCompView C, GtsTaskPrefix P, uint32_t lds_bytes)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (blockIdx.x >= P.pre[GTS_NKLASS]) return;
@@ -1529,8 +1551,8 @@ k_walk_tasks_mixed(GtsCompView C, GtsTaskPrefix P)
   const uint32_t t = C.tq[C.tq_base[k] + blockIdx.x - P.pre[k]];
   const uint32_t c = C.task_comp[t];
   GtsCompMemT<true> M;
-  stage_component(C, c, smem, M, true, 0u);
-  GtsComponent<GtsWave64, true> prog(C, M, c);
+  stage_component(C, c, smem, M, true, lds_bytes);
+  GtsComponent<GtsWave64, true, true> prog(C, M, c);
   prog.walk_task(t);
 }
 /* Deferred walks of the components that run from global memory (too large or
@@ -2869,7 +2891,8 @@ static int run_components(GtsgEngine *e, int mode)
             ++task_launches;
             hipEvent_t _a = nullptr, _b = nullptr;
             if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, e->st); }
-            k_walk_tasks_mixed<<<acc, GTS_WAVE, klass_h[kmax], e->st>>>(C, P);
+            const uint32_t lds_m = klass_h[kmax + 1 < nk ? kmax + 1 : kmax];   /* a class up: room for the split arcs */
+            k_walk_tasks_mixed<<<acc, GTS_WAVE, lds_m, e->st>>>(C, P, lds_m);
             if (e->profile) { hipEventRecord(_b, e->st); e->pending.push_back({"components_walk_tasks", _a, _b}); }
             for (uint32_t k = 0; k < nk; ++k) pend[k] = 0;   /* nothing to join */
           }
@@ -2895,7 +2918,8 @@ static int run_components(GtsgEngine *e, int mode)
             HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
             hipEvent_t _a = nullptr, _b = nullptr;
             if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
-            k_walk_tasks<<<(uint32_t)pend[k], GTS_WAVE, klass_h[k], ss>>>(C, (uint32_t)k, (uint32_t)pend[k]);
+            const uint32_t lds_k = klass_h[(uint32_t)k + 1 < nk ? k + 1 : k];
+            k_walk_tasks<<<(uint32_t)pend[k], GTS_WAVE, lds_k, ss>>>(C, (uint32_t)k, (uint32_t)pend[k], lds_k);
             if (e->profile) { hipEventRecord(_b, ss); e->pending.push_back({"components_walk_tasks", _a, _b}); }
             HIPCHK(hipEventRecord(e->ev_join[k], ss));
           }
