@@ -150,6 +150,7 @@ struct GtsgEngine {
      (walks_clean_batch); from batch_big_contigs contigs on a component asks for
      LDS for batch_big_slots walk slots */
   int64_t batch_walks = 1, batch_big_contigs = 128, batch_big_slots = 4;
+  int64_t small_masks = 1;   /* topological order of components of at most 64 contigs on bit masks (peel_small) */
   /* walks of global-memory components fan out only on request: the components
      that end up there on the 50 M workload are scaffolds tied together by an
      unmarked hub, where every accepted cc revives an arc out of the hub and
@@ -1861,6 +1862,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "fast_walks")) e->fast_walks = value != 0;
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "batch_walks")) e->batch_walks = value != 0;
+  else if (!strcmp(name, "small_masks")) e->small_masks = value != 0;
   else if (!strcmp(name, "batch_big_contigs") && value >= 0) e->batch_big_contigs = value;
   else if (!strcmp(name, "batch_big_slots") && value >= 2 && value <= GTS_WALK_SLOTS_MAX) e->batch_big_slots = value;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
@@ -2714,7 +2716,8 @@ static int run_components(GtsgEngine *e, int mode)
     C.distmap = s_distmap; C.ccoff = s_ccoff; C.wq_edge = wq_edge; C.wq_used = wq_used;
     C.wq_pool = wq_pool; C.wq_factor = (uint64_t)factor;
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
-    C.fast_walks = (int)e->fast_walks; C.batch_walks = (int)e->batch_walks; C.nd = s_nd;
+    C.fast_walks = (int)e->fast_walks; C.batch_walks = (int)e->batch_walks; C.small_masks = (int)e->small_masks;
+    C.nd = s_nd;
     C.team_slab = nullptr; C.team_used = nullptr; C.team_cap = 0; C.team_stat = nullptr;
     C.small_stat = nullptr; C.tspan = nullptr;
     if (e->profile >= 2) {
