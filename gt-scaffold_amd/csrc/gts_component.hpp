@@ -1937,6 +1937,111 @@ struct GtsComponent {
     r_len = best_len; r_t = best_t; r_bad = bad;
   }
 
+
+  /* walks_clean_batch for a component of at most 64 contigs: the labelled
+     positions a sweep has not handled yet are a 64-bit set in the registers of
+     the group (bit tpos[v] joins when v gets its first label, OR-ed over the
+     group's eight lanes with three DPP steps), so "the next labelled vertex in
+     sweep order" is a count of leading or trailing zeros and not two dependent
+     LDS reads per eight positions: a step is four dependent LDS reads (topo,
+     the vertex' record, its arcs, the arcs' targets) instead of seven. */
+  GTS_HD void walks_clean_batch_small(uint32_t j0, uint32_t nb, uint32_t &r_len, uint32_t &r_t, bool &r_bad)
+  {
+    typedef typename GtsCompMemT<LDS>::idx_t idx_t;
+    constexpr uint32_t L = 8;
+    const uint32_t lane = W::lane(), g = lane / L, a = lane % L;
+    const uint32_t gsh = g * L;
+    const uint64_t gm = (1ull << L) - 1ull;
+    const uint32_t p4 = ((nv * 4 + 15) / 16) * 16, p2 = ((nv * 2 + 15) / 16) * 16;
+    bool active = g < nb;
+    auto sbase = M.wbase + (active ? g : 0u) * (2 * p4 + 2 * p2);
+    auto dist = (GTS_P(float))sbase;
+    auto plen = (GTS_P(uint32_t))(sbase + p4);
+    auto emap = (GTS_P(idx_t))(sbase + 2 * p4);
+    auto par = (GTS_P(idx_t))(sbase + 2 * p4 + p2);
+    const uint32_t start = active ? (uint32_t)M.term[j0 + g] : 0u;
+    const uint32_t sb0 = M.coff[start], se0 = M.coff[start + 1];
+    bool hs = false, ha = false;
+    for (uint32_t cur0 = sb0; W::ballot(active && cur0 < se0); cur0 += L) {
+      const uint32_t ce = cur0 + a;
+      const bool in = active && ce < se0;
+      const uint32_t fs = edge_bits(in ? ce : sb0);
+      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+      const bool sense = (fs & GTS_F_SENSE) != 0;
+      const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
+      hs |= ((bs >> gsh) & gm) != 0;
+      ha |= ((ba >> gsh) & gm) != 0;
+    }
+    bool bad = active && hs && ha;
+    if (bad || !(hs || ha)) active = false;
+    const bool forward = hs == ((M.gorient[start] & 3u) == 2);
+    bool have_u = active, is_start = true;
+    uint32_t u = start, cur = sb0, ub = sb0, ue = se0;
+    bool du = hs, us = false, ua = false;
+    int32_t ndu = 0;
+    uint32_t plu = (uint32_t)M.cseq[start];
+    uint32_t best_len = 0, best_t = GTS_NONE;
+    uint64_t pend = 0;          /* positions labelled and not handled yet (the same in the lanes of a group) */
+    while (W::ballot(active)) {
+      /* (1) the next labelled position of the sweep */
+      if (active && !have_u) {
+        if (pend) {
+          const uint32_t p = forward ? W::ctz(pend) : 63u - W::clz64(pend);
+          pend &= ~(1ull << p);
+          u = M.topo[p];
+          have_u = true; is_start = false; us = ua = false;
+          ub = cur = M.coff[u]; ue = M.coff[u + 1];
+          du = ((M.gorient[u] & 3u) == 2) == forward;
+          ndu = (int32_t)dist[u];
+          plu = plen[u];
+        } else
+          active = false;
+      }
+      /* (2) up to L arcs of the current vertex (its label is final) */
+      const bool proc = active && have_u;
+      const uint32_t ce = cur + a;
+      const bool in = proc && ce < ue;
+      const uint32_t cec = in ? ce : ub;
+      const uint32_t fs = edge_bits(cec);
+      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+      const bool sense = (fs & GTS_F_SENSE) != 0;
+      const bool arc = live && sense == du;
+      const uint32_t v = M.cend[cec];
+      const float cand = (float)(ndu + (int32_t)M.cdist[cec]);
+      const float old = dist[v];
+      const uint32_t sv = (uint32_t)M.cseq[v];
+      const uint32_t tv = M.tpos[v];
+      const bool imp = arc && (old == GTS_DIST_UNSET || old > cand);
+      const bool tie = arc && !imp && old == cand;
+      const bool fresh = imp && old == GTS_DIST_UNSET;
+      if (imp) {
+        dist[v] = cand;
+        emap[v] = (idx_t)ce;
+        par[v] = (idx_t)u;
+        plen[v] = plu + sv;
+      }
+      pend |= W::group8_or(fresh ? 1ull << tv : 0ull);
+      const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
+      const uint64_t tm = W::ballot(tie);
+      us |= ((bs >> gsh) & gm) != 0;
+      ua |= ((ba >> gsh) & gm) != 0;
+      if ((tm >> gsh) & gm) bad = true;
+      if (proc) {
+        cur += L;
+        if (cur >= ue) {
+          if (!is_start && !(us && ua)) {
+            if (plu > best_len) { best_len = plu; best_t = u; }
+            else if (plu == best_len && best_t != GTS_NONE) bad = true;
+          }
+          have_u = false;
+        }
+      }
+      if (bad) active = false;
+      W::fence();
+    }
+    r_len = best_len; r_t = best_t; r_bad = bad;
+  }
+
   /* labels of the walk slots back to "unset" (slot 0's are distmap) */
   GTS_HD void clear_walk_slots(uint32_t nslots)
   {
@@ -1969,7 +2074,8 @@ struct GtsComponent {
       used = nb;
       uint32_t r_len, r_t;
       bool r_bad;
-      walks_clean_batch<L>(j0, nb, r_len, r_t, r_bad);
+      if (L == 8 && nv <= 64 && C.small_masks) walks_clean_batch_small(j0, nb, r_len, r_t, r_bad);
+      else walks_clean_batch<L>(j0, nb, r_len, r_t, r_bad);
       if (W::ballot(r_bad)) { ok = false; break; }
       /* first strictly longest walk in terminal order, algorithms.c:826-832 */
       uint32_t wg = GTS_NONE;
@@ -2686,6 +2792,8 @@ struct GtsWave1 {
   static const uint32_t WIDTH = 1;
   static const bool TEAM = false;
   static GTS_HD void and_bits(uint32_t *p, uint32_t m) { *p &= m; }
+  static GTS_HD uint64_t group8_or(uint64_t x) { return x; }
+  static GTS_HD uint32_t clz64(uint64_t v) { uint32_t n = 0; while (n < 64 && !(v & (0x8000000000000000ull >> n))) ++n; return n; }
   static GTS_HD uint32_t lane() { return 0; }
   static GTS_HD uint64_t ballot(bool p) { return p ? 1u : 0u; }
   static GTS_HD uint32_t popc(uint64_t m) { return (uint32_t)(m & 1u); }

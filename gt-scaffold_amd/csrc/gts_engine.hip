@@ -1021,6 +1021,20 @@ struct GtsWave64 {
   static const uint32_t WIDTH = 64;
   static const bool TEAM = false;
   static __device__ __forceinline__ void and_bits(uint32_t *p, uint32_t m) { atomicAnd(p, m); }
+  static __device__ __forceinline__ uint32_t clz64(uint64_t v) { return (uint32_t)__clzll((long long)v); }
+  /* OR over the eight lanes of a group (lanes 8k .. 8k+7), result in all of
+     them: two quad permutations and a half-row mirror, no LDS */
+  static __device__ __forceinline__ uint32_t group8_or32(uint32_t x)
+  {
+    x |= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);    /* quad_perm [1,0,3,2] */
+    x |= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);    /* quad_perm [2,3,0,1] */
+    x |= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);   /* row_half_mirror */
+    return x;
+  }
+  static __device__ __forceinline__ uint64_t group8_or(uint64_t x)
+  {
+    return (uint64_t)group8_or32((uint32_t)x) | (uint64_t)group8_or32((uint32_t)(x >> 32)) << 32;
+  }
   static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
   static __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
   static __device__ __forceinline__ uint32_t popc(uint64_t m) { return (uint32_t)__popcll(m); }
