@@ -125,6 +125,7 @@ struct GtsCompView {
   uint64_t *task_roff;       /* task_cap: offset of the task's bitmap in paths */
   uint64_t *comp_ring;       /* per component: 2 x u64, ring of select_walks' reference searches */
   const uint8_t *comp_klass; /* per component: LDS size class (launch group of its tasks) */
+  const uint8_t *comp_d32;   /* per component: a distance does not fit 16 bits (packed layout: int32 distances) */
   uint32_t *tq;              /* task_cap: pending tasks, one segment per class */
   const uint32_t *tq_base;   /* per class: start of its segment */
   unsigned long long *tq_cnt;/* per class: pending tasks */
@@ -253,6 +254,12 @@ struct GtsCompMemT {
   typename GtsEdgeArrays<LDS>::start_t cstart;
   GTS_P(const idx_t) cend;
   GTS_P(const dist_t) cdist;
+  /* packed LDS layout: a component whose distances all fit 16 bits (comp_d32 = 0)
+     keeps them as int16 -- 5 instead of 7 bytes per edge; the launch is bound
+     by LDS x time, so a seventh less footprint is a seventh more components in
+     flight (read through GtsComponent::dist_of) */
+  GTS_P(const int16_t) cdist16;
+  bool d16;
   typename GtsEdgeArrays<LDS>::flags_t cflags;   /* GTS_F_TWINLIVE is cleared when a twin dies */
   GTS_P(const seq_t) cseq;
   typename GtsEdgeArrays<LDS>::state_t cstate;
@@ -299,7 +306,7 @@ typedef GtsCompMemT<false> GtsCompMem;
 
 /* LDS bytes needed to stage a component in the packed layout (every array
    16-byte aligned) */
-GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
+GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne, bool d32 = true)
 {
   const uint32_t a = 16;
   uint32_t b = 0;
@@ -314,7 +321,7 @@ GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne)
   b += ((nv * 4 + a - 1) / a) * a * 4;                /* cseq | distmap, plen, nd */
   b += ((nv + a - 1) / a) * a * 4;                    /* vst, st_dir, tight, gorient */
   b += ((ne * 2 + a - 1) / a) * a;                    /* cend */
-  b += ((ne * 4 + a - 1) / a) * a;                    /* cdist */
+  b += ((ne * (d32 ? 4u : 2u) + a - 1) / a) * a;      /* cdist: int32, or int16 when every distance fits */
   b += ((ne + a - 1) / a) * a;                        /* flags + state */
   return b;
 }
@@ -337,9 +344,9 @@ GTS_HD uint32_t gts_walk_slot_bytes(uint32_t nv)
    side (walks_clean_batch).  Smaller components use what their last page has
    left. */
 GTS_HD uint32_t gts_comp_lds_want(uint32_t nv, uint32_t ne, uint32_t big_nv, uint32_t big_slots,
-                                  uint32_t limit)
+                                  uint32_t limit, bool d32 = true)
 {
-  uint32_t need = gts_comp_lds_bytes(nv, ne);
+  uint32_t need = gts_comp_lds_bytes(nv, ne, d32);
   if (big_nv && nv >= big_nv && need <= limit) {
     const uint32_t sb = gts_walk_slot_bytes(nv);
     uint32_t extra = big_slots > 2 ? big_slots - 2 : 0;
@@ -396,7 +403,7 @@ struct GtsComponent {
     const uint32_t e0 = C.coff[s0];
     m.nv = s1 - s0; m.ne = C.coff[s1] - e0; m.e0 = e0;
     m.coff = C.coff + s0; m.cstart = C.cstart + e0; m.cend = C.cend + e0;
-    m.cdist = C.cdist + e0; m.cflags = C.cflags + e0; m.cseq = C.cseq + s0;
+    m.cdist = C.cdist + e0; m.cdist16 = nullptr; m.d16 = false; m.cflags = C.cflags + e0; m.cseq = C.cseq + s0;
     m.cstate = C.cstate + e0; m.vst = C.vst + s0;
     m.queue = C.queue + s0; m.term = C.term + s0; m.visited = C.visited + s0;
     m.st_v = C.st_v + s0; m.st_par = C.st_par + s0; m.st_cur = C.st_cur + s0;
@@ -416,6 +423,12 @@ struct GtsComponent {
   static GTS_HD int64_t uni_t(int64_t v) { return W::uni64(v); }
   static GTS_HD uint64_t uni_t(uint64_t v) { return (uint64_t)W::uni64((int64_t)v); }
   GTS_HD uint32_t eoff(uint32_t ls) const { return W::uni(M.coff[ls]) - M.e0; }
+  /* distance of a compact edge (GtsCompMemT::cdist16) */
+  GTS_HD typename GtsCompMemT<LDS>::dist_t dist_of(uint32_t ce) const
+  {
+    if constexpr (LDS) { if (M.d16) return (typename GtsCompMemT<LDS>::dist_t)M.cdist16[ce]; }
+    return M.cdist[ce];
+  }
   /* flags (low nibble) and state (high nibble) of a compact edge; the packed
      LDS layout keeps them in one byte */
   GTS_HD uint32_t edge_bits(uint32_t ce) const
@@ -819,7 +832,7 @@ struct GtsComponent {
         if (ce < ee) {
           live = !gts_edge_is_marked(M.cstate[ce]);
           nb = M.cend[ce];
-          d = M.cdist[ce];
+          d = dist_of(ce);
         }
         if (W::popc(W::ballot(live && nb == start)) >= 2)
           ok = relax_ordered(live, nb, ce, (float)d, d, true);
@@ -905,7 +918,7 @@ struct GtsComponent {
         sense = SV ? r_dir : (M.cflags[ce] & GTS_F_SENSE) != 0;
         nb = M.cend[ce];
         q = live && sense == r_dir && nb != r_from && !gts_vertex_is_marked(M.vst[nb]);
-        distance = (float)(r_nd + M.cdist[ce]);
+        distance = (float)(r_nd + dist_of(ce));
         if (q) old = M.distmap[nb];
       }
       const uint64_t bs = W::ballot(act && live && sense);
@@ -1159,7 +1172,7 @@ struct GtsComponent {
             if (ce < ee && !gts_edge_is_marked(M.cstate[ce]) &&
                 ((M.cflags[ce] & GTS_F_SENSE) != 0) == du) {
               const uint32_t v = M.cend[ce];
-              const nd_t w = (nd_t)M.cdist[ce];
+              const nd_t w = (nd_t)dist_of(ce);
               const float cand = (float)(ndu + w);
               const float old = M.distmap[v];
               if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
@@ -1205,7 +1218,7 @@ struct GtsComponent {
           sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
           if (live && sense == du) {
             v = M.cend[ce];
-            const nd_t w = (nd_t)M.cdist[ce];
+            const nd_t w = (nd_t)dist_of(ce);
             const float cand = (float)(ndu + w);
             take = cand == M.distmap[v] && !(orient[v] & 4u);
           }
@@ -1332,7 +1345,7 @@ struct GtsComponent {
             arc = live && sense == du;
             if (arc) {
               v = M.cend[ce];
-              const nd_t w = (nd_t)M.cdist[ce];
+              const nd_t w = (nd_t)dist_of(ce);
               const float cand = (float)(ndu + w);
               const float old = M.distmap[v];
               if (!(cand > -16777216.0f && cand < 16777216.0f)) inexact = true;
@@ -1697,7 +1710,7 @@ struct GtsComponent {
         const bool sense = (fs & GTS_F_SENSE) != 0;
         const bool arc = live && sense == du;
         const uint32_t v = M.cend[cec];
-        const nd_t w = (nd_t)M.cdist[cec];
+        const nd_t w = (nd_t)dist_of(cec);
         const float cand = (float)(ndu + w);
         const float old = M.distmap[v];
         const bool imp = arc && (old == GTS_DIST_UNSET || old > cand);
@@ -1902,7 +1915,7 @@ struct GtsComponent {
       const bool sense = (fs & GTS_F_SENSE) != 0;
       const bool arc = live && sense == du;
       const uint32_t v = M.cend[cec];
-      const float cand = (float)(ndu + (int32_t)M.cdist[cec]);
+      const float cand = (float)(ndu + (int32_t)dist_of(cec));
       const float old = dist[v];
       const bool imp = arc && (old == GTS_DIST_UNSET || old > cand);
       const bool tie = arc && !imp && old == cand;
@@ -2007,7 +2020,7 @@ struct GtsComponent {
       const bool sense = (fs & GTS_F_SENSE) != 0;
       const bool arc = live && sense == du;
       const uint32_t v = M.cend[cec];
-      const float cand = (float)(ndu + (int32_t)M.cdist[cec]);
+      const float cand = (float)(ndu + (int32_t)dist_of(cec));
       const float old = dist[v];
       const uint32_t sv = (uint32_t)M.cseq[v];
       const uint32_t tv = M.tpos[v];
@@ -2199,7 +2212,7 @@ struct GtsComponent {
       const bool sense = (fs & GTS_F_SENSE) != 0;
       const bool arc = live && sense == du;
       const uint32_t v = M.cend[cec];
-      const int64_t w = (int64_t)M.cdist[cec];
+      const int64_t w = (int64_t)dist_of(cec);
       const float cand = (float)(ndu + w);
       const float old = dist[v];
       const bool imp = arc && (old == GTS_DIST_UNSET || old > cand);

@@ -150,6 +150,7 @@ struct GtsgEngine {
      (walks_clean_batch); from batch_big_contigs contigs on a component asks for
      LDS for batch_big_slots walk slots */
   int64_t batch_walks = 1, batch_big_contigs = 128, batch_big_slots = 4;
+  int64_t lds_int16_distances = 1;   /* packed layout: int16 distances for components whose distances all fit */
   int64_t small_masks = 1;   /* topological order of components of at most 64 contigs on bit masks (peel_small) */
   /* walks of global-memory components fan out only on request: the components
      that end up there on the 50 M workload are scaffolds tied together by an
@@ -972,7 +973,7 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
                                const uint8_t *incl, const uint32_t *ipos,
                                const uint32_t *slot_of, const uint32_t *slot_base,
                                const uint32_t *coff, const uint32_t *slot_comp,
-                               uint8_t *comp_wide, uint32_t *cstart,
+                               uint8_t *comp_wide, uint8_t *comp_d32, uint32_t *cstart,
                                uint32_t *cend, int64_t *cdist, uint8_t *cflags,
                                uint32_t *cgpos, uint8_t *cstate, uint32_t *cmap)
 {
@@ -1009,6 +1010,7 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
     const int64_t d = G.dist[p[k]];
     /* the LDS layout adds up to 4095 distances in 32 bits (nd_t) */
     if (d >= (1 << 19) || d <= -(1 << 19)) comp_wide[slot_comp[s[k]]] = 1;
+    if (d > 32767 || d < -32768) comp_d32[slot_comp[s[k]]] = 1;   /* int16 distances in LDS otherwise */
     cdist[kk] = d;
     cflags[kk] = (uint8_t)((f & 7u) | GTS_F_TWINLIVE);
     cgpos[kk] = (uint32_t)p[k]; cstate[kk] = G.state[p[k]];
@@ -1219,7 +1221,10 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   M.vst = lds_carve<uint8_t>(p, nv); M.st_dir = lds_carve<uint8_t>(p, nv);
   M.tight = lds_carve<uint8_t>(p, nv); M.gorient = lds_carve<uint8_t>(p, nv);
   auto cend = lds_carve<idx_t>(p, ne);
-  auto cdist = lds_carve<int32_t>(p, ne);
+  const bool d32 = C.comp_d32[c] != 0;
+  int32_t __attribute__((address_space(3))) *cdist = nullptr;
+  int16_t __attribute__((address_space(3))) *cdist16 = nullptr;
+  if (d32) cdist = lds_carve<int32_t>(p, ne); else cdist16 = lds_carve<int16_t>(p, ne);
   auto cfs = lds_carve<uint8_t>(p, ne);   /* flags | state << 4 */
   /* the walk scratch, in one piece (gts_comp_lds_bytes): slot 0 of the batched
      walks is distmap, plen, edgemap, par */
@@ -1249,7 +1254,7 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   M.st_cur = M.cc_best; M.touched = M.visited;
   M.lastpop = (uint32_t __attribute__((address_space(3))) *)M.nd;
   M.cflags.b = cfs; M.cstate.b = cfs;
-  M.coff = coff; M.cseq = cseq; M.cend = cend; M.cdist = cdist;
+  M.coff = coff; M.cseq = cseq; M.cend = cend; M.cdist = cdist; M.cdist16 = cdist16; M.d16 = !d32;
   M.cstart.coff = coff; M.cstart.nv = nv;
   for (uint32_t i = lane; i <= nv; i += GTS_WAVE) coff[i] = (idx_t)(G0.coff[i] - G0.e0);
   for (uint32_t i = lane; i < nv; i += GTS_WAVE) {
@@ -1260,7 +1265,8 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
     }
   }
   for (uint32_t i = lane; i < ne; i += GTS_WAVE) {
-    cend[i] = (idx_t)G0.cend[i]; cdist[i] = (int32_t)G0.cdist[i];
+    cend[i] = (idx_t)G0.cend[i];
+    if (d32) cdist[i] = (int32_t)G0.cdist[i]; else cdist16[i] = (int16_t)G0.cdist[i];
     cfs[i] = (uint8_t)((G0.cflags[i] & 15u) | (G0.cstate[i] << 4));
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1618,7 +1624,7 @@ k_select_walks(GtsCompView C, uint32_t ndeferred)
    components fit each size class */
 __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 uint32_t *keys, uint32_t *vals, uint32_t ncomp,
-                                const uint8_t *comp_wide, const unsigned long long *comp_len,
+                                const uint8_t *comp_wide, const uint8_t *comp_d32, const unsigned long long *comp_len,
                                 uint8_t *comp_klass, const uint32_t *klass, uint32_t nklass,
                                 uint32_t *klass_count, unsigned long long *klass_bytes,
                                 uint32_t *klass_slots, uint32_t big_nv, uint32_t big_slots)
@@ -1634,7 +1640,7 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
     const uint32_t s0 = comp_off[c], s1 = comp_off[c + 1];
     const uint32_t cnv = s1 - s0, cne = coff[s1] - coff[s0];
     /* footprint, and room for walk slots from big_nv contigs on (gts_comp_lds_want) */
-    uint32_t need = gts_comp_lds_want(cnv, cne, big_nv, big_slots, GTS_POOL_BYTES - 16u);
+    uint32_t need = gts_comp_lds_want(cnv, cne, big_nv, big_slots, GTS_POOL_BYTES - 16u, comp_d32[c] != 0);
     /* not representable in the packed LDS layout: run from global memory */
     if (comp_wide[c] || cnv >= 4096u || cne > GTS_LDS_MAX_INDEX || comp_len[c] >= (1ull << 32))
       need = 0x7FFFFFFFu;
@@ -1877,6 +1883,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "batch_walks")) e->batch_walks = value != 0;
   else if (!strcmp(name, "small_masks")) e->small_masks = value != 0;
+  else if (!strcmp(name, "lds_int16_distances")) e->lds_int16_distances = value != 0;
   else if (!strcmp(name, "batch_big_contigs") && value >= 0) e->batch_big_contigs = value;
   else if (!strcmp(name, "batch_big_slots") && value >= 2 && value <= GTS_WALK_SLOTS_MAX) e->batch_big_slots = value;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
@@ -2626,6 +2633,8 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(slot_base, uint32_t, nslots);
     PALLOC(slot_comp, uint32_t, nslots); PALLOC(comp_wide, uint8_t, (size_t)ncomp + 1);
     HIPCHK(hipMemsetAsync(comp_wide, 0, (size_t)ncomp + 1, e->st));
+    PALLOC(comp_d32, uint8_t, (size_t)ncomp + 1);
+    HIPCHK(hipMemsetAsync(comp_d32, e->lds_int16_distances ? 0 : 1, (size_t)ncomp + 1, e->st));
     PALLOC(comp_len, unsigned long long, (size_t)ncomp + 1);
     HIPCHK(hipMemsetAsync(comp_len, 0, ((size_t)ncomp + 1) * 8, e->st));
     LAUNCH("comp_slot_bases", k_slot_bases, nblk(nslots), GTS_BLOCK, head, cidx, comp_off, cseq,
@@ -2645,7 +2654,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cmap, uint32_t, (size_t)m + 1);
     if (m)
       LAUNCH("comp_compact_fill", k_compact_fill, nblk(m, GTS_BLOCK * 2), GTS_BLOCK, G, e->estart, incl, ipos,
-             slot_of, slot_base, coff, slot_comp, comp_wide, cstart, cend, cdist, cflags, cgpos,
+             slot_of, slot_base, coff, slot_comp, comp_wide, comp_d32, cstart, cend, cdist, cflags, cgpos,
              cstate, cmap);
     /* walk queue pool of the reference search */
     const uint64_t wq_pool = (uint64_t)pool_entries;
@@ -2692,7 +2701,7 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_KSIZE, 0, (GTS_S_NDEF + 4 - GTS_S_KSIZE) * 4, e->st));
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, nklass * sizeof(uint32_t), hipMemcpyHostToDevice, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
-           ncomp, comp_wide, comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? nklass : 0), klass_count,
+           ncomp, comp_wide, comp_d32, comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? nklass : 0), klass_count,
            (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS,
            (uint32_t)(e->batch_walks && mode == GTS_MODE_MAKESCAFFOLD ? e->batch_big_contigs : 0),
            (uint32_t)e->batch_big_slots);
@@ -2723,7 +2732,7 @@ static int run_components(GtsgEngine *e, int mode)
     GtsCompView C;
     C.G = G; C.cmap = cmap; C.ncomp = ncomp; C.comp_off = comp_off; C.slot_v = slot_v;
     C.cseq = cseq; C.coff = coff; C.cstart = cstart; C.cend = cend; C.cdist = cdist;
-    C.cflags = cflags; C.cgpos = cgpos; C.cstate = cstate; C.vst = vst;
+    C.cflags = cflags; C.cgpos = cgpos; C.cstate = cstate; C.vst = vst; C.comp_d32 = comp_d32;
     C.queue = s_queue; C.term = s_term; C.visited = s_visited; C.st_v = s_stv;
     C.st_par = s_stpar; C.st_cur = s_stcur; C.edgemap = s_edgemap; C.par = s_par; C.lastpop = s_lastpop;
     C.wterm = s_wterm; C.touched = s_touched; C.cc_best = s_ccbest; C.st_dir = s_stdir;

@@ -154,6 +154,20 @@ def test_contig_ids_above_2_to_24():
     assert eng.ne == og.ne and eng.ne > 0
 
 
+@pytest.mark.parametrize("scale", [1, 40, 400])
+def test_distance_widths_of_the_packed_lds_layout(scale):
+    """the packed LDS layout keeps the distances of a component as int16 when
+    they all fit and as int32 otherwise (GtsCompMemT::cdist16); scale 40 puts
+    some components above 2^15, scale 400 most of them (a few above 2^19, which
+    run from global memory); the option that turns int16 off gives the same states"""
+    g = make_inputs(6000, 78, p_chimeric=0.03)
+    g["dist"] = g["dist"] * scale
+    eng, _ = run_pipeline(g, ocutoff=400 * scale)
+    eng0, _ = run_pipeline(g, ocutoff=400 * scale, lds_int16_distances=0)
+    assert eng.digest() == eng0.digest()
+    assert eng.stat("components_global_mem") < eng.stat("components")
+
+
 @pytest.mark.parametrize("what", ["distances", "lengths", "length_sums"])
 def test_values_the_packed_lds_layout_cannot_carry(what):
     """components with a distance of 2^19 or more, a contig of 2^31 bases or
