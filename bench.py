@@ -435,7 +435,6 @@ def main():
                    component_kernel=dict(
                        walks_fast=eng.stat("fast_walks"), walks_reference=eng.stat("slow_walks"),
                        clean_components=eng.stat("clean_components"),
-                       suspect_components=eng.stat("suspect_components"),
                        components_per_lds_class={"%dk" % eng.stat("lds_class%d_kb" % i):
                                                  eng.stat("components_lds_class%d" % i)
                                                  for i in range(MAX_LDS_CLASSES)

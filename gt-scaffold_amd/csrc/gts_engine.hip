@@ -64,7 +64,6 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_S_TEAMUSED 424 /* u64: bytes of the team slab handed out */
 #define GTS_S_TEAMSTAT 432 /* 8 x u64: statistics of k_components_team */
 #define GTS_S_SMALLSTAT 448 /* 4 x u64: small components by "all edges live" */
-#define GTS_S_NSUSPECT 456  /* u32: components the pool claims first (GTS_KEY_SUSPECT) */
 
 static const char *klass_event(int makescaffold, uint32_t bytes)
 {
@@ -151,7 +150,6 @@ struct GtsgEngine {
      (walks_clean_batch); from batch_big_contigs contigs on a component asks for
      LDS for batch_big_slots walk slots */
   int64_t batch_walks = 1, batch_big_contigs = 64, batch_big_slots = 3;
-  int64_t suspects_first = 1;        /* components with a u-turn pair or a self loop are claimed first by the pool */
   int64_t lds_int16_distances = 1;   /* packed layout: int16 distances for components whose distances all fit */
   int64_t small_masks = 1;   /* topological order of components of at most 64 contigs on bit masks (peel_small) */
   /* walks of global-memory components fan out only on request: the components
@@ -975,7 +973,7 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
                                const uint8_t *incl, const uint32_t *ipos,
                                const uint32_t *slot_of, const uint32_t *slot_base,
                                const uint32_t *coff, const uint32_t *slot_comp,
-                               uint8_t *comp_wide, uint8_t *comp_d32, uint8_t *comp_suspect, uint32_t *cstart,
+                               uint8_t *comp_wide, uint8_t *comp_d32, uint32_t *cstart,
                                uint32_t *cend, int64_t *cdist, uint8_t *cflags,
                                uint32_t *cgpos, uint8_t *cstate, uint32_t *cmap)
 {
@@ -1016,7 +1014,6 @@ __global__ void k_compact_fill(GtsGraphView G, const uint32_t *estart,
     /* a u-turn pair or a self loop: the component has no strand assignment, its
        program takes the slow paths (ten times the time per contig) -- it is
        claimed before the others of the launch so that it cannot set the tail */
-    if ((f & GTS_F_UTURN) || a[k] == b[k]) comp_suspect[slot_comp[s[k]]] = 1;
     cdist[kk] = d;
     cflags[kk] = (uint8_t)((f & 7u) | GTS_F_TWINLIVE);
     cgpos[kk] = (uint32_t)p[k]; cstate[kk] = G.state[p[k]];
@@ -1331,7 +1328,6 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
    A waiting wavefront holds no pages, and what it waits for is released by
    wavefronts that run to completion, so it gets its turn; while it waits, back
    components may only take pages above the ones it needs. */
-#define GTS_KEY_SUSPECT 0x20000000u   /* bit of the footprint sort key: claim this component first */
 #define GTS_POOL_PAGE 1536u
 #define GTS_POOL_PAGES 104u                     /* 156 KB: one workgroup per CU (2 KB pages: 25 % more of a small component's last page wasted) */
 #define GTS_POOL_BYTES (GTS_POOL_PAGES * GTS_POOL_PAGE)
@@ -1479,7 +1475,7 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
         __builtin_amdgcn_s_sleep(16);
       }
       if (idx != GTS_NONE) {
-        need = ~order_key[first + idx] & (GTS_KEY_SUSPECT - 1u);   /* the sort key: one load instead of three dependent ones */
+        need = ~order_key[first + idx];   /* the sort key: one load instead of three dependent ones */
         npages = (need + GTS_POOL_PAGE - 1u) / GTS_POOL_PAGE;
         bool waiting = false;
         const uint64_t tw0 = GtsWave64::clock();
@@ -1635,11 +1631,11 @@ k_select_walks(GtsCompView C, uint32_t ndeferred)
    components fit each size class */
 __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 uint32_t *keys, uint32_t *vals, uint32_t ncomp,
-                                const uint8_t *comp_wide, const uint8_t *comp_d32, const uint8_t *comp_suspect,
+                                const uint8_t *comp_wide, const uint8_t *comp_d32,
                                 const unsigned long long *comp_len,
                                 uint8_t *comp_klass, const uint32_t *klass, uint32_t nklass,
                                 uint32_t *klass_count, unsigned long long *klass_bytes,
-                                uint32_t *klass_slots, uint32_t big_nv, uint32_t big_slots, uint32_t *nsuspect)
+                                uint32_t *klass_slots, uint32_t big_nv, uint32_t big_slots)
 {
   /* counters are summed per workgroup in LDS first: seven global counters hit by
      every component serialise */
@@ -1656,11 +1652,7 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
     /* not representable in the packed LDS layout: run from global memory */
     if (comp_wide[c] || cnv >= 4096u || cne > GTS_LDS_MAX_INDEX || comp_len[c] >= (1ull << 32))
       need = 0x7FFFFFFFu;
-    /* ascending sort = largest first; a suspect (k_compact_fill) before all others
-       of the pool (GTS_KEY_SUSPECT: the pool masks it off again) */
-    const bool sus = comp_suspect && comp_suspect[c] && need < GTS_KEY_SUSPECT;
-    keys[c] = ~(need | (sus ? GTS_KEY_SUSPECT : 0u));
-    if (sus) atomicAdd(nsuspect, 1u);
+    keys[c] = ~need;   /* ascending sort = largest first */
     vals[c] = (uint32_t)c;
     uint32_t k = 0;
     while (k < nklass && need > klass[k]) ++k;   /* klass ascending; nklass = global */
@@ -1900,7 +1892,6 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "batch_walks")) e->batch_walks = value != 0;
   else if (!strcmp(name, "small_masks")) e->small_masks = value != 0;
   else if (!strcmp(name, "lds_int16_distances")) e->lds_int16_distances = value != 0;
-  else if (!strcmp(name, "suspects_first")) e->suspects_first = value != 0;
   else if (!strcmp(name, "batch_big_contigs") && value >= 0) e->batch_big_contigs = value;
   else if (!strcmp(name, "batch_big_slots") && value >= 2 && value <= GTS_WALK_SLOTS_MAX) e->batch_big_slots = value;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
@@ -2650,8 +2641,6 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(slot_base, uint32_t, nslots);
     PALLOC(slot_comp, uint32_t, nslots); PALLOC(comp_wide, uint8_t, (size_t)ncomp + 1);
     HIPCHK(hipMemsetAsync(comp_wide, 0, (size_t)ncomp + 1, e->st));
-    PALLOC(comp_suspect, uint8_t, (size_t)ncomp + 1);
-    HIPCHK(hipMemsetAsync(comp_suspect, 0, (size_t)ncomp + 1, e->st));
     PALLOC(comp_d32, uint8_t, (size_t)ncomp + 1);
     HIPCHK(hipMemsetAsync(comp_d32, e->lds_int16_distances ? 0 : 1, (size_t)ncomp + 1, e->st));
     PALLOC(comp_len, unsigned long long, (size_t)ncomp + 1);
@@ -2673,7 +2662,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(cmap, uint32_t, (size_t)m + 1);
     if (m)
       LAUNCH("comp_compact_fill", k_compact_fill, nblk(m, GTS_BLOCK * 2), GTS_BLOCK, G, e->estart, incl, ipos,
-             slot_of, slot_base, coff, slot_comp, comp_wide, comp_d32, comp_suspect, cstart, cend, cdist, cflags, cgpos,
+             slot_of, slot_base, coff, slot_comp, comp_wide, comp_d32, cstart, cend, cdist, cflags, cgpos,
              cstate, cmap);
     /* walk queue pool of the reference search */
     const uint64_t wq_pool = (uint64_t)pool_entries;
@@ -2718,14 +2707,13 @@ static int run_components(GtsgEngine *e, int mode)
     const uint32_t nklass = GTS_NKLASS;
     uint32_t *klass_d = e->d_scalars + GTS_S_KSIZE, *klass_count = e->d_scalars + GTS_S_KCOUNT;
     HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_KSIZE, 0, (GTS_S_NDEF + 4 - GTS_S_KSIZE) * 4, e->st));
-    HIPCHK(hipMemsetAsync(e->d_scalars + GTS_S_NSUSPECT, 0, 4, e->st));
     HIPCHK(hipMemcpyAsync(klass_d, klass_h, nklass * sizeof(uint32_t), hipMemcpyHostToDevice, e->st));
     LAUNCH("comp_lds_keys", k_comp_lds_keys, nblk(ncomp), GTS_BLOCK, comp_off, coff, ok0, ov0,
-           ncomp, comp_wide, comp_d32, e->pool_components && e->lds_components && e->suspects_first ? comp_suspect : (uint8_t *)nullptr,
+           ncomp, comp_wide, comp_d32,
            comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? nklass : 0), klass_count,
            (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS,
            (uint32_t)(e->batch_walks && mode == GTS_MODE_MAKESCAFFOLD ? e->batch_big_contigs : 0),
-           (uint32_t)e->batch_big_slots, e->d_scalars + GTS_S_NSUSPECT);
+           (uint32_t)e->batch_big_slots);
     LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + GTS_S_KSLOTS, e->d_scalars + GTS_S_TQBASE);
     const uint32_t *order, *order_key;   /* order_key[i] = ~footprint of component order[i] */
     {
@@ -2739,8 +2727,6 @@ static int run_components(GtsgEngine *e, int mode)
     uint64_t kbytes[GTS_NKLASS + 1];
     HIPCHK(hipMemcpyAsync(kcount, klass_count, sizeof kcount, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(kslots_h, e->d_scalars + GTS_S_KSLOTS, sizeof kslots_h, hipMemcpyDeviceToHost, e->st));
-    uint32_t nsuspect_h = 0;
-    HIPCHK(hipMemcpyAsync(&nsuspect_h, e->d_scalars + GTS_S_NSUSPECT, 4, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(kbytes, e->d_scalars + GTS_S_KBYTES, sizeof kbytes, hipMemcpyDeviceToHost, e->st));
     /* largest component: sizes the scratch slabs of walks deferred from global memory */
     uint32_t maxcomp = 0;
@@ -2850,8 +2836,6 @@ static int run_components(GtsgEngine *e, int mode)
         hipStream_t ss = e->side[0];
         uint32_t nbig = 0;   /* components above 8 KB: claimed one at a time */
         for (uint32_t k = 0; k < nk; ++k) if (klass_h[k] > 8192u) nbig += kcount[k];
-        nbig += nsuspect_h;   /* (they come first in the list, whatever their size) */
-        e->stats["suspect_components"] = nsuspect_h;
         /* the fill cursor starts where the footprints fit two pages and moves on
            towards the smallest: the last components claimed are the smallest, so
            a component that turns out slow (not clean: ten times the time per
