@@ -1844,6 +1844,7 @@ struct GtsComponent {
   GTS_HD void walks_clean_batch(uint32_t j0, uint32_t nb, uint32_t &r_len, uint32_t &r_t, bool &r_bad)
   {
     typedef typename GtsCompMemT<LDS>::idx_t idx_t;
+    static_assert(L == 8 || W::WIDTH == 1, "the group reductions are written for eight lanes");
     const uint32_t lane = W::lane(), g = lane / L, a = lane % L;
     const uint32_t gsh = g * L;
     const uint64_t gm = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
@@ -1868,96 +1869,103 @@ struct GtsComponent {
       hs |= ((bs >> gsh) & gm) != 0;
       ha |= ((ba >> gsh) & gm) != 0;
     }
-    bool bad = active && hs && ha;
+    uint32_t bad = active && hs && ha ? 1u : 0u;
     if (bad || !(hs || ha)) active = false;          /* (nothing reachable: empty walk) */
     const bool forward = hs == ((M.gorient[start] & 3u) == 2);
     const int32_t step = forward ? 1 : -1;
-    int32_t pos = (int32_t)M.tpos[start] + step;
-    /* the group's current vertex: the start first */
-    bool have_u = active, is_start = true;
-    uint32_t u = start, cur = sb0, ub = sb0, ue = se0;
-    bool du = hs, us = false, ua = false;
-    int32_t ndu = 0;
-    uint32_t plu = (uint32_t)M.cseq[start];
-    uint32_t pending = 0, best_len = 0, best_t = GTS_NONE;
-    while (W::ballot(active)) {
-      /* (1) the next labelled vertex in sweep order, L positions at a time */
-      const bool scan = active && !have_u;
-      const int32_t p = pos + (int32_t)a * step;
-      const bool inr = scan && p >= 0 && p < (int32_t)nv;
-      const uint32_t cv = M.topo[inr ? (uint32_t)p : 0u];
-      const float lbl = dist[cv];
-      const uint64_t rb = (W::ballot(inr && lbl != GTS_DIST_UNSET) >> gsh) & gm;
-      if (scan) {
-        if (rb) {
-          const uint32_t k = W::ctz(rb);
-          const int32_t p1 = pos + (int32_t)k * step;
-          u = M.topo[(uint32_t)p1];
-          pos = p1 + step;
-          have_u = true; is_start = false; us = ua = false;
-          --pending;
-          ub = cur = M.coff[u]; ue = M.coff[u + 1];
-          du = ((M.gorient[u] & 3u) == 2) == forward;
-          ndu = (int32_t)dist[u];                   /* the integer the reference pushes with the node */
-          plu = plen[u];
-        } else {
-          pos += (int32_t)L * step;
-          if (pos < 0 || pos >= (int32_t)nv) active = false;
-        }
-      }
-      /* (2) up to L arcs of the current vertex (its label is final) */
-      const bool proc = active && have_u;
-      const uint32_t ce = cur + a;
-      const bool in = proc && ce < ue;
-      const uint32_t cec = in ? ce : ub;
-      const uint32_t fs = edge_bits(cec);
-      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
-      const bool sense = (fs & GTS_F_SENSE) != 0;
-      const bool arc = live && sense == du;
-      const uint32_t v = M.cend[cec];
-      const float cand = (float)(ndu + (int32_t)dist_of(cec));
-      const float old = dist[v];
-      const bool imp = arc && (old == GTS_DIST_UNSET || old > cand);
-      const bool tie = arc && !imp && old == cand;
-      const bool fresh = imp && old == GTS_DIST_UNSET;
-      if (imp) {
-        dist[v] = cand;
-        emap[v] = (idx_t)ce;
-        par[v] = (idx_t)u;
-        plen[v] = plu + (uint32_t)M.cseq[v];
-      }
-      const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
-      const uint64_t fm = W::ballot(fresh), tm = W::ballot(tie);
-      us |= ((bs >> gsh) & gm) != 0;
-      ua |= ((ba >> gsh) & gm) != 0;
-      pending += W::popc((fm >> gsh) & gm);
-      if ((tm >> gsh) & gm) bad = true;
-      if (proc) {
-        cur += L;
-        if (cur >= ue) {
-          /* reached terminal (algorithms.c:694): candidate end of the walk */
-          if (!is_start && !(us && ua)) {
-            if (plu > best_len) { best_len = plu; best_t = u; }
-            else if (plu == best_len && best_t != GTS_NONE) bad = true;
+    /* The loop is written for the instruction issue it is bound by (see
+       walks_clean_batch_small): the state of a group is the number of labelled
+       positions it has not handled yet -- none = done, and a walk that met a tie
+       drops them --, the start is labelled in its slot like any other vertex,
+       one pass of the outer loop is one vertex, and what the lanes of a group
+       found is combined over the group once per vertex. */
+    if (active && a == 0) { dist[start] = 0.0f; plen[start] = (uint32_t)M.cseq[start]; }
+    int32_t pos = (int32_t)M.tpos[start];        /* the sweep has handled everything before pos */
+    uint32_t pending = active ? 1u : 0u;
+    uint32_t best_len = 0, best_t = GTS_NONE;
+    W::fence();
+    while (W::ballot(pending != 0)) {
+      bool on = pending != 0;
+      /* (1) the next labelled position at or after pos, L positions a step */
+      uint32_t u = 0;
+      bool found = !on;
+      while (W::ballot(!found)) {
+        const int32_t p = pos + (int32_t)a * step;
+        const bool inr = !found && p >= 0 && p < (int32_t)nv;
+        const uint32_t cv = M.topo[inr ? (uint32_t)p : 0u];
+        const float lbl = dist[cv];
+        const uint64_t rb = (W::ballot(inr && lbl != GTS_DIST_UNSET) >> gsh) & gm;
+        const uint32_t k = rb ? W::ctz(rb) : 0u;
+        const uint32_t uk = W::shfl(cv, gsh + k);
+        if (!found) {
+          if (rb) { u = uk; pos += (int32_t)(k + 1u) * step; found = true; }
+          else {
+            pos += (int32_t)L * step;
+            /* (a labelled position is ahead while pending != 0; never past the range) */
+            if (pos < 0 || pos >= (int32_t)nv) { found = true; on = false; pending = 0; }
           }
-          have_u = false;
-          if (pending == 0) active = false;
         }
       }
-      if (bad) active = false;
-      W::fence();
+      const uint32_t ub = M.coff[u], ue = M.coff[u + 1];
+      const bool du = ((M.gorient[u] & 3u) == 2) == forward;
+      const int32_t ndu = (int32_t)dist[u];                 /* the integer the reference pushes with the node */
+      const uint32_t plu = plen[u];
+      uint32_t mine = 0;       /* vertices this lane labelled first */
+      uint32_t seen = 0;       /* 1: live sense edge, 2: live antisense edge, 4: tie */
+      for (uint32_t cur = ub; W::ballot(on && cur < ue); cur += L) {
+        const uint32_t ce = cur + a;
+        const bool in = on && ce < ue;
+        const uint32_t cec = in ? ce : ub;
+        const uint32_t fs = edge_bits(cec);
+        const uint32_t v = M.cend[cec];
+        const float cand = (float)(ndu + (int32_t)dist_of(cec));
+        const float old = dist[v];
+        const uint32_t sv = (uint32_t)M.cseq[v];
+        const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+        const bool sense = (fs & GTS_F_SENSE) != 0;
+        const bool arc = live && sense == du;
+        const bool unset = old == GTS_DIST_UNSET;
+        const bool imp = arc && (unset || old > cand);
+        if (imp) {
+          dist[v] = cand;
+          emap[v] = (idx_t)ce;
+          par[v] = (idx_t)u;
+          plen[v] = plu + sv;
+        }
+        mine += imp && unset ? 1u : 0u;
+        seen |= live ? (sense ? 1u : 2u) : 0u;
+        seen |= arc && !imp && old == cand ? 4u : 0u;
+        W::fence();
+      }
+      mine = W::group8_add32(mine);
+      seen = W::group8_or32(seen);
+      if (on) {
+        pending += mine - 1u;
+        /* reached terminal (algorithms.c:694): candidate end of the walk */
+        if (u != start && (seen & 3u) != 3u) {
+          if (plu > best_len) { best_len = plu; best_t = u; }
+          else if (plu == best_len && best_t != GTS_NONE) bad = 1u;
+        }
+        bad |= seen >> 2;
+      }
+      if (bad) pending = 0;
     }
-    r_len = best_len; r_t = best_t; r_bad = bad;
+    r_len = best_len; r_t = best_t; r_bad = bad != 0;
   }
 
 
-  /* walks_clean_batch for a component of at most 64 contigs: the labelled
+  /* walks_clean_batch for a component of at most 64 contigs.  The labelled
      positions a sweep has not handled yet are a 64-bit set in the registers of
-     the group (bit tpos[v] joins when v gets its first label, OR-ed over the
-     group's eight lanes with three DPP steps), so "the next labelled vertex in
-     sweep order" is a count of leading or trailing zeros and not two dependent
-     LDS reads per eight positions: a step is four dependent LDS reads (topo,
-     the vertex' record, its arcs, the arcs' targets) instead of seven. */
+     the group (bit tpos[v] joins when v gets its first label), so "the next
+     labelled vertex in sweep order" is a count of leading or trailing zeros.
+     The loop is written for the instruction issue it is bound by (a step was
+     ~190 instructions, half of them scalar mask bookkeeping for a dozen
+     loop-carried conditions): the state of a group is its pending set -- empty
+     = done, and a walk that met a tie empties it --, the start is labelled in
+     its slot like any other vertex, one pass of the outer loop is one vertex
+     (its arcs in an inner loop that runs once unless a list has more than eight
+     entries), and what the lanes of a group found -- new positions, senses
+     seen, ties -- is OR-ed over the group once per vertex (DPP), not per step. */
   GTS_HD void walks_clean_batch_small(uint32_t j0, uint32_t nb, uint32_t &r_len, uint32_t &r_t, bool &r_bad)
   {
     typedef typename GtsCompMemT<LDS>::idx_t idx_t;
@@ -1985,74 +1993,65 @@ struct GtsComponent {
       hs |= ((bs >> gsh) & gm) != 0;
       ha |= ((ba >> gsh) & gm) != 0;
     }
-    bool bad = active && hs && ha;
+    uint32_t bad = active && hs && ha ? 1u : 0u;
     if (bad || !(hs || ha)) active = false;
     const bool forward = hs == ((M.gorient[start] & 3u) == 2);
-    bool have_u = active, is_start = true;
-    uint32_t u = start, cur = sb0, ub = sb0, ue = se0;
-    bool du = hs, us = false, ua = false;
-    int32_t ndu = 0;
-    uint32_t plu = (uint32_t)M.cseq[start];
+    /* the start: label 0, its own length, position pending (its sheet is the
+       sense of its live edges: (strand == 2) == forward is hs) */
+    if (active && a == 0) { dist[start] = 0.0f; plen[start] = (uint32_t)M.cseq[start]; }
+    uint64_t pend = active ? 1ull << (uint32_t)M.tpos[start] : 0ull;
     uint32_t best_len = 0, best_t = GTS_NONE;
-    uint64_t pend = 0;          /* positions labelled and not handled yet (the same in the lanes of a group) */
-    while (W::ballot(active)) {
-      /* (1) the next labelled position of the sweep */
-      if (active && !have_u) {
-        if (pend) {
-          const uint32_t p = forward ? W::ctz(pend) : 63u - W::clz64(pend);
-          pend &= ~(1ull << p);
-          u = M.topo[p];
-          have_u = true; is_start = false; us = ua = false;
-          ub = cur = M.coff[u]; ue = M.coff[u + 1];
-          du = ((M.gorient[u] & 3u) == 2) == forward;
-          ndu = (int32_t)dist[u];
-          plu = plen[u];
-        } else
-          active = false;
-      }
-      /* (2) up to L arcs of the current vertex (its label is final) */
-      const bool proc = active && have_u;
-      const uint32_t ce = cur + a;
-      const bool in = proc && ce < ue;
-      const uint32_t cec = in ? ce : ub;
-      const uint32_t fs = edge_bits(cec);
-      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
-      const bool sense = (fs & GTS_F_SENSE) != 0;
-      const bool arc = live && sense == du;
-      const uint32_t v = M.cend[cec];
-      const float cand = (float)(ndu + (int32_t)dist_of(cec));
-      const float old = dist[v];
-      const uint32_t sv = (uint32_t)M.cseq[v];
-      const uint32_t tv = M.tpos[v];
-      const bool imp = arc && (old == GTS_DIST_UNSET || old > cand);
-      const bool tie = arc && !imp && old == cand;
-      const bool fresh = imp && old == GTS_DIST_UNSET;
-      if (imp) {
-        dist[v] = cand;
-        emap[v] = (idx_t)ce;
-        par[v] = (idx_t)u;
-        plen[v] = plu + sv;
-      }
-      pend |= W::group8_or(fresh ? 1ull << tv : 0ull);
-      const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
-      const uint64_t tm = W::ballot(tie);
-      us |= ((bs >> gsh) & gm) != 0;
-      ua |= ((ba >> gsh) & gm) != 0;
-      if ((tm >> gsh) & gm) bad = true;
-      if (proc) {
-        cur += L;
-        if (cur >= ue) {
-          if (!is_start && !(us && ua)) {
-            if (plu > best_len) { best_len = plu; best_t = u; }
-            else if (plu == best_len && best_t != GTS_NONE) bad = true;
-          }
-          have_u = false;
+    W::fence();
+    while (W::ballot(pend != 0)) {
+      const bool on = pend != 0;
+      const uint32_t p = on ? (forward ? W::ctz(pend) : 63u - W::clz64(pend)) : 0u;
+      pend &= ~(1ull << p);
+      const uint32_t u = M.topo[p];
+      const uint32_t ub = M.coff[u], ue = M.coff[u + 1];
+      const bool du = ((M.gorient[u] & 3u) == 2) == forward;
+      const int32_t ndu = (int32_t)dist[u];                 /* the integer the reference pushes with the node */
+      const uint32_t plu = plen[u];
+      uint64_t mine = 0;       /* positions this lane labelled first */
+      uint32_t seen = 0;       /* 1: live sense edge, 2: live antisense edge, 4: tie */
+      for (uint32_t cur = ub; W::ballot(on && cur < ue); cur += L) {
+        const uint32_t ce = cur + a;
+        const bool in = on && ce < ue;
+        const uint32_t cec = in ? ce : ub;
+        const uint32_t fs = edge_bits(cec);
+        const uint32_t v = M.cend[cec];
+        const float cand = (float)(ndu + (int32_t)dist_of(cec));
+        const float old = dist[v];
+        const uint32_t sv = (uint32_t)M.cseq[v];
+        const uint32_t tv = M.tpos[v];
+        const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+        const bool sense = (fs & GTS_F_SENSE) != 0;
+        const bool arc = live && sense == du;
+        const bool unset = old == GTS_DIST_UNSET;
+        const bool imp = arc && (unset || old > cand);
+        if (imp) {
+          dist[v] = cand;
+          emap[v] = (idx_t)ce;
+          par[v] = (idx_t)u;
+          plen[v] = plu + sv;
         }
+        if (imp && unset) mine |= 1ull << tv;
+        seen |= live ? (sense ? 1u : 2u) : 0u;
+        seen |= arc && !imp && old == cand ? 4u : 0u;
+        W::fence();
       }
-      if (bad) active = false;
-      W::fence();
+      pend |= W::group8_or(mine);
+      seen = W::group8_or32(seen);
+      if (on) {
+        /* reached terminal (algorithms.c:694): candidate end of the walk */
+        if (u != start && (seen & 3u) != 3u) {
+          if (plu > best_len) { best_len = plu; best_t = u; }
+          else if (plu == best_len && best_t != GTS_NONE) bad = 1u;
+        }
+        bad |= seen >> 2;
+      }
+      if (bad) pend = 0;
     }
-    r_len = best_len; r_t = best_t; r_bad = bad;
+    r_len = best_len; r_t = best_t; r_bad = bad != 0;
   }
 
   /* labels of the walk slots back to "unset" (slot 0's are distmap) */
@@ -2806,6 +2805,8 @@ struct GtsWave1 {
   static const bool TEAM = false;
   static GTS_HD void and_bits(uint32_t *p, uint32_t m) { *p &= m; }
   static GTS_HD uint64_t group8_or(uint64_t x) { return x; }
+  static GTS_HD uint32_t group8_or32(uint32_t x) { return x; }
+  static GTS_HD uint32_t group8_add32(uint32_t x) { return x; }
   static GTS_HD uint32_t clz64(uint64_t v) { uint32_t n = 0; while (n < 64 && !(v & (0x8000000000000000ull >> n))) ++n; return n; }
   static GTS_HD uint32_t lane() { return 0; }
   static GTS_HD uint64_t ballot(bool p) { return p ? 1u : 0u; }

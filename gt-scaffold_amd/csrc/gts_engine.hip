@@ -1036,6 +1036,13 @@ struct GtsWave64 {
     x |= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);   /* row_half_mirror */
     return x;
   }
+  static __device__ __forceinline__ uint32_t group8_add32(uint32_t x)
+  {
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);
+    return x;
+  }
   static __device__ __forceinline__ uint64_t group8_or(uint64_t x)
   {
     return (uint64_t)group8_or32((uint32_t)x) | (uint64_t)group8_or32((uint32_t)(x >> 32)) << 32;

@@ -597,7 +597,7 @@ def test_full_size_sharded_pipeline_against_oracle_digest():
     shared = dist_mod.ThreadComm.Shared(world)
     vs = torch.zeros(n, dtype=torch.uint8, device=dev)
     es = torch.full((ne,), 255, dtype=torch.uint8, device=dev)
-    errs, lock, info = [], threading.Lock(), {}
+    errs, lock, info, reps = [], threading.Lock(), {}, {}
 
     def run(r):
         try:
@@ -622,11 +622,8 @@ def test_full_size_sharded_pipeline_against_oracle_digest():
                 es[eid] = st
                 own = owner[local] == r
                 vs[local[own]] = v[own]
-                rep = owner[local] < 0                           # repeat contigs: the same state everywhere
-                if r == 0:
-                    vs[local[rep]] = v[rep]
-                else:
-                    assert bool((vs[local[rep]] == v[rep]).all())
+                rep = owner[local] < 0                           # repeat contigs: on every rank, compared below
+                reps[r] = (local[rep], v[rep])
                 info[r] = (rounds, load.cpu().tolist(), int(local.numel()), len(e["start"]))
             eng.close()
         except BaseException as ex:   # noqa: B902
@@ -638,6 +635,9 @@ def test_full_size_sharded_pipeline_against_oracle_digest():
     for t in ts:
         t.join()
     assert not errs, errs
+    vs[reps[0][0]] = reps[0][1]
+    for r in range(1, world):                                    # repeat contigs: the same state everywhere
+        assert bool((vs[reps[r][0]] == reps[r][1]).all())
     assert bool((es != 255).all())                               # every edge of the graph is on some rank
     assert info[0][3] + info[1][3] == ne
     # the plan balances the records: the heavier rank holds less than 51 %
