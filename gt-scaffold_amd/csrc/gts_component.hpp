@@ -2779,6 +2779,12 @@ struct GtsComponent {
       deferred = deferred_late;
     }
     const uint64_t t2 = W::clock();
+    /* (not unrolled: an eight-fold copy hipcc 7.2 made of this loop inside
+       k_components_pool -- lane-dependent trip count, address registers spilled
+       around it -- left the states of the slots past the first 64 of a large
+       component unwritten in one build of this kernel; it showed in
+       tests/test_gpu_parity.py::test_small_graphs_stage_by_stage) */
+#pragma unroll 1
     for (uint32_t s = lane; s < nv; s += W::WIDTH) {
       const uint8_t st = M.vst[s];
       /* removecycles leaves every unmarked vertex UNVISITED (algorithms.c:
