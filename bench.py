@@ -465,6 +465,8 @@ def main():
                               "team_us_clear", "team_us_sweep", "team_us_paths", "team_us_wave0_barriers")},
                        walk_tasks=eng.stat("walk_tasks"), walk_task_rounds=eng.stat("walk_task_rounds"),
                        walk_task_runs=eng.stat("walk_task_runs"),
+                       walk_rounds=[dict(us=eng.stat("walk_round%d_us" % r), walks=eng.stat("walk_round%d_walks" % r))
+                                    for r in range(min(8, max(0, eng.stat("walk_task_rounds"))))],
                        deferred_components=eng.stat("deferred_components"),
                        by_size={"<=%s" % b: dict(components=eng.stat("size_band%d_components" % i),
                                                  wave_us=eng.stat("size_band%d_us" % i),

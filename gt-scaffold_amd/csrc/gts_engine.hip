@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -2915,6 +2916,7 @@ static int run_components(GtsgEngine *e, int mode)
         if ((rc = read_u64(e, (uint64_t *)(e->d_scalars + 128), &ntasks))) return rc;
         const uint64_t slab_stride = ((((uint64_t)maxcomp + 3) & ~3ull) * GTS_SLAB_BYTES + 255) & ~255ull;
         for (;; ++rounds) {
+          const auto round_t0 = std::chrono::steady_clock::now();
           uint64_t total = 0;
           for (uint32_t k = 0; k < nk; ++k) total += pend[k];
           /* pending walks of components that run from global memory (class nk) */
@@ -2971,6 +2973,11 @@ static int run_components(GtsgEngine *e, int mode)
           LAUNCH("components_select_walks", k_select_walks, (uint32_t)ndef, GTS_WAVE, C, (uint32_t)ndef);
           HIPCHK(hipMemcpyAsync(pend, e->d_scalars + GTS_S_TQCNT, sizeof pend, hipMemcpyDeviceToHost, e->st));
           if ((rc = sync_stream(e))) return rc;
+          if (e->profile >= 2 && rounds < 8) {   /* host clock: a round ends with a look at the queues anyway */
+            e->stats["walk_round" + std::to_string(rounds) + "_us"] = (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(
+                std::chrono::steady_clock::now() - round_t0).count();
+            e->stats["walk_round" + std::to_string(rounds) + "_walks"] = (int64_t)(total + gpend);
+          }
         }
       }
       if (e->profile) {

@@ -526,14 +526,18 @@ def test_full_size_properties():
     g = bench.make_inputs(pkg, n, 1234, "cuda:0", gen)
     g["num_pairs"] = g["num_pairs"].to(torch.int64)
     slow = []
-    for opts in (dict(), dict(defer_min_contigs=0, pool_components=0, class_streams=1)):
+    # (the last one: no walk leaves its component -- nothing is decided by the
+    # select pass and its test for walks that a revived arc made stale)
+    for opts in (dict(), dict(defer_min_contigs=0, pool_components=0, class_streams=1),
+                 dict(defer_min_contigs=0, defer_ref_min_contigs=0)):
         eng = pkg.engine.Engine(0)
         for k, v in opts.items():
             eng.set_option(k, v)
         bench.run_step(eng, g)
-        slow.append((eng.digest(), eng.stat("slow_walks")))
+        slow.append((eng.digest(), eng.stat("slow_walks"), eng.stat("walk_tasks")))
         del eng
-    assert slow[0][0] == slow[1][0] and slow[0][1] > 0 and slow[1][1] > 0, slow
+    assert slow[0][0] == slow[1][0] == slow[2][0] and slow[0][1] > 0 and slow[1][1] > 0, slow
+    assert slow[0][2] > 0 and slow[2][2] == 0, slow
     del g
     # the oracle on a sample of the same generator
     gs = make_inputs(100000, 99, **bench.WORKLOAD["gen"])
