@@ -101,6 +101,9 @@ struct GtsCompView {
      task per terminal, k_walk_tasks runs every walk on its own wavefront,
      the select pass keeps the best walk of every cc (gts_engine.hip) */
   uint32_t defer_min_nv;     /* 0: never defer */
+  uint64_t defer_unclean_work;   /* a component that is not clean (its walks are made one by one, ten
+                                    times the time per contig) defers from this many terminals x
+                                    contigs on; 0: the rule above only */
   uint64_t defer_min_work;   /* defer only if terminals x contigs reaches this: the walks of a
                                 component cost about that many vertex steps when made in place */
   uint32_t defer_ref_min_nv; /* 0: never.  A component of at least this many contigs that meets a walk
@@ -185,8 +188,12 @@ template <bool LDS> struct GtsEdgeArrays {
 typedef uint8_t __attribute__((address_space(3))) *gts_lds_u8p;
 struct GtsLdsStateRef {
   gts_lds_u8p p;
-  __device__ __forceinline__ operator uint8_t() const { return (uint8_t)(*p >> 4); }
-  __device__ __forceinline__ void operator=(uint8_t st) const { *p = (uint8_t)((*p & 15u) | (st << 4)); }
+  /* bit 7 of the byte: the state is a marked one (gts_edge_is_marked) -- the
+     test every traversal makes per edge, one AND instead of shift, mask, shift,
+     mask, compare */
+  __device__ __forceinline__ operator uint8_t() const { return (uint8_t)((*p >> 4) & 7u); }
+  __device__ __forceinline__ void operator=(uint8_t st) const
+  { *p = (uint8_t)((*p & 15u) | (st << 4) | (gts_edge_is_marked(st) ? 0x80u : 0u)); }
   __device__ __forceinline__ void operator=(const GtsLdsStateRef &o) const { *this = (uint8_t)o; }
 };
 struct GtsLdsFlagsRef {
@@ -429,8 +436,27 @@ struct GtsComponent {
     if constexpr (LDS) { if (M.d16) return (typename GtsCompMemT<LDS>::dist_t)M.cdist16[ce]; }
     return M.cdist[ce];
   }
+  /* the same with the width known at compile time (the sweep loops: no branch
+     on M.d16 per step) */
+  template <bool D16>
+  GTS_HD int32_t dist_w(uint32_t ce) const
+  {
+    if constexpr (LDS) { if constexpr (D16) return (int32_t)M.cdist16[ce]; else return (int32_t)M.cdist[ce]; }
+    else return (int32_t)M.cdist[ce];
+  }
   /* flags (low nibble) and state (high nibble) of a compact edge; the packed
      LDS layout keeps them in one byte */
+  /* marked state, from edge_bits() / of edge ce */
+  static GTS_HD bool bits_marked(uint32_t fs)
+  {
+    if constexpr (LDS) return (fs & 0x80u) != 0;
+    else return gts_edge_is_marked((uint8_t)(fs >> 4));
+  }
+  GTS_HD bool edge_marked(uint32_t ce) const
+  {
+    if constexpr (LDS) return (*(M.cflags.b + ce) & 0x80u) != 0;
+    else return gts_edge_is_marked(M.cstate[ce]);
+  }
   GTS_HD uint32_t edge_bits(uint32_t ce) const
   {
     if constexpr (LDS) return *(M.cflags.b + ce);
@@ -507,7 +533,7 @@ struct GtsComponent {
               const bool in = ce < ee;
               const uint32_t cec = in ? ce : eb;
               const uint32_t fl = edge_bits(cec);
-              const bool live = in && !gts_edge_is_marked((uint8_t)(fl >> 4));
+              const bool live = in && !bits_marked(fl);
               const bool sense = (fl & GTS_F_SENSE) != 0;
               const uint32_t nb = M.cend[cec];
               const bool unv = live && M.vst[nb] == GIS_UNVISITED;
@@ -571,7 +597,7 @@ struct GtsComponent {
           fl = M.cflags[ce];
           nb = M.cend[ce];
           if (((fl & GTS_F_SENSE) != 0) == dir &&
-              !gts_edge_is_marked(M.cstate[ce]) && nb != par) {
+              !edge_marked(ce) && nb != par) {
             vs = M.vst[nb];
             cand = !gts_vertex_is_marked((uint8_t)vs) && vs != GIS_PROCESSED;
           }
@@ -646,7 +672,7 @@ struct GtsComponent {
     bool all_live = C.fast_walks && nv > 1;
     for (uint32_t base = 0; base < M.ne && all_live; base += W::WIDTH) {
       const uint32_t ce = base + lane;
-      all_live = W::ballot(ce < M.ne && gts_edge_is_marked(M.cstate[ce])) == 0;
+      all_live = W::ballot(ce < M.ne && edge_marked(ce)) == 0;
     }
     was_all_live = all_live;
     bool oriented = false, first = true;
@@ -673,7 +699,7 @@ struct GtsComponent {
           bool live = false;
           uint32_t fl = 0;
           if (ce < ee) {
-            live = !gts_edge_is_marked(M.cstate[ce]);
+            live = !edge_marked(ce);
             fl = M.cflags[ce];
           }
           const uint64_t mask = W::ballot(live);
@@ -830,7 +856,7 @@ struct GtsComponent {
         uint32_t nb = 0;
         int64_t d = 0;
         if (ce < ee) {
-          live = !gts_edge_is_marked(M.cstate[ce]);
+          live = !edge_marked(ce);
           nb = M.cend[ce];
           d = dist_of(ce);
         }
@@ -914,7 +940,7 @@ struct GtsComponent {
       if (act) {
         ce = r_eb + (lane - r_excl);
         if constexpr (SV) ce = M.sarc[ce];
-        live = !gts_edge_is_marked(M.cstate[ce]);
+        live = !edge_marked(ce);
         sense = SV ? r_dir : (M.cflags[ce] & GTS_F_SENSE) != 0;
         nb = M.cend[ce];
         q = live && sense == r_dir && nb != r_from && !gts_vertex_is_marked(M.vst[nb]);
@@ -1169,7 +1195,7 @@ struct GtsComponent {
           const uint32_t eb = eoff(u), ee = eoff(u + 1);
           for (uint32_t eb2 = eb; eb2 < ee; eb2 += W::WIDTH) {
             const uint32_t ce = eb2 + lane;
-            if (ce < ee && !gts_edge_is_marked(M.cstate[ce]) &&
+            if (ce < ee && !edge_marked(ce) &&
                 ((M.cflags[ce] & GTS_F_SENSE) != 0) == du) {
               const uint32_t v = M.cend[ce];
               const nd_t w = (nd_t)dist_of(ce);
@@ -1214,7 +1240,7 @@ struct GtsComponent {
         bool live = false, sense = false, take = false;
         uint32_t v = 0;
         if (ce < ee) {
-          live = !gts_edge_is_marked(M.cstate[ce]);
+          live = !edge_marked(ce);
           sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
           if (live && sense == du) {
             v = M.cend[ce];
@@ -1258,7 +1284,7 @@ struct GtsComponent {
         const uint32_t ce = base + lane;
         bool live = false, sense = false;
         if (ce < ee) {
-          live = !gts_edge_is_marked(M.cstate[ce]);
+          live = !edge_marked(ce);
           sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
         }
         has_s |= W::ballot(live && sense) != 0;
@@ -1285,7 +1311,7 @@ struct GtsComponent {
         uint32_t v = 0, od = 0;
         if (ce < ee) {
           const uint32_t fl = M.cflags[ce];
-          arc = !gts_edge_is_marked(M.cstate[ce]) && ((fl & GTS_F_SENSE) != 0) == du;
+          arc = !edge_marked(ce) && ((fl & GTS_F_SENSE) != 0) == du;
           if (arc) {
             v = M.cend[ce];
             od = gts_next_dir((uint8_t)fl) ? 2u : 1u;
@@ -1340,7 +1366,7 @@ struct GtsComponent {
           bool live = false, sense = false, arc = false, ready = false, tie = false;
           uint32_t v = 0;
           if (ce < ee) {
-            live = !gts_edge_is_marked(M.cstate[ce]);
+            live = !edge_marked(ce);
             sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
             arc = live && sense == du;
             if (arc) {
@@ -1505,7 +1531,7 @@ struct GtsComponent {
   {
     const uint32_t fl = edge_bits(ce);
     return (((fl & GTS_F_SENSE) != 0) == ox) == forward &&
-           (!gts_edge_is_marked((uint8_t)(fl >> 4)) || (fl & GTS_F_TWINLIVE));
+           (!bits_marked(fl) || (fl & GTS_F_TWINLIVE));
   }
 
   /* Topological order of D for an oriented component (topo / tpos); true if
@@ -1542,7 +1568,7 @@ struct GtsComponent {
       const uint32_t ce = has ? eb + k : 0u;
       const uint32_t fl = edge_bits(ce);
       const uint32_t w = M.cend[ce];
-      const bool darc = has && (!gts_edge_is_marked((uint8_t)(fl >> 4)) || (fl & GTS_F_TWINLIVE));
+      const bool darc = has && (!bits_marked(fl) || (fl & GTS_F_TWINLIVE));
       const bool fwd = ((fl & GTS_F_SENSE) != 0) == os;
       if (darc && fwd) dout |= 1ull << w;
       if (darc && !fwd) din |= 1ull << w;
@@ -1666,7 +1692,7 @@ struct GtsComponent {
         const uint32_t ce = base + lane;
         bool live = false, sense = false;
         if (ce < ee) {
-          live = !gts_edge_is_marked(M.cstate[ce]);
+          live = !edge_marked(ce);
           sense = (M.cflags[ce] & GTS_F_SENSE) != 0;
         }
         has_s |= W::ballot(live && sense) != 0;
@@ -1706,7 +1732,7 @@ struct GtsComponent {
         const bool in = ce < ee;
         const uint32_t cec = in ? ce : eb;
         const uint32_t fs = edge_bits(cec);
-        const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+        const bool live = in && !bits_marked(fs);
         const bool sense = (fs & GTS_F_SENSE) != 0;
         const bool arc = live && sense == du;
         const uint32_t v = M.cend[cec];
@@ -1840,7 +1866,7 @@ struct GtsComponent {
      then makes the walks of this cc one by one (create_walk), which resolves
      them (pushed_after) or runs the reference's search.
      Slots must be clean (labels unset) on entry; clear_walk_slots() after. */
-  template <uint32_t L>
+  template <uint32_t L, bool D16>
   GTS_HD void walks_clean_batch(uint32_t j0, uint32_t nb, uint32_t &r_len, uint32_t &r_t, bool &r_bad)
   {
     typedef typename GtsCompMemT<LDS>::idx_t idx_t;
@@ -1863,7 +1889,7 @@ struct GtsComponent {
       const uint32_t ce = cur0 + a;
       const bool in = active && ce < se0;
       const uint32_t fs = edge_bits(in ? ce : sb0);
-      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+      const bool live = in && !bits_marked(fs);
       const bool sense = (fs & GTS_F_SENSE) != 0;
       const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
       hs |= ((bs >> gsh) & gm) != 0;
@@ -1918,10 +1944,10 @@ struct GtsComponent {
         const uint32_t cec = in ? ce : ub;
         const uint32_t fs = edge_bits(cec);
         const uint32_t v = M.cend[cec];
-        const float cand = (float)(ndu + (int32_t)dist_of(cec));
+        const float cand = (float)(ndu + dist_w<D16>(cec));
         const float old = dist[v];
         const uint32_t sv = (uint32_t)M.cseq[v];
-        const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+        const bool live = in && !bits_marked(fs);
         const bool sense = (fs & GTS_F_SENSE) != 0;
         const bool arc = live && sense == du;
         const bool unset = old == GTS_DIST_UNSET;
@@ -1966,6 +1992,7 @@ struct GtsComponent {
      (its arcs in an inner loop that runs once unless a list has more than eight
      entries), and what the lanes of a group found -- new positions, senses
      seen, ties -- is OR-ed over the group once per vertex (DPP), not per step. */
+  template <bool D16>
   GTS_HD void walks_clean_batch_small(uint32_t j0, uint32_t nb, uint32_t &r_len, uint32_t &r_t, bool &r_bad)
   {
     typedef typename GtsCompMemT<LDS>::idx_t idx_t;
@@ -1987,7 +2014,7 @@ struct GtsComponent {
       const uint32_t ce = cur0 + a;
       const bool in = active && ce < se0;
       const uint32_t fs = edge_bits(in ? ce : sb0);
-      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+      const bool live = in && !bits_marked(fs);
       const bool sense = (fs & GTS_F_SENSE) != 0;
       const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
       hs |= ((bs >> gsh) & gm) != 0;
@@ -2019,11 +2046,11 @@ struct GtsComponent {
         const uint32_t cec = in ? ce : ub;
         const uint32_t fs = edge_bits(cec);
         const uint32_t v = M.cend[cec];
-        const float cand = (float)(ndu + (int32_t)dist_of(cec));
+        const float cand = (float)(ndu + dist_w<D16>(cec));
         const float old = dist[v];
         const uint32_t sv = (uint32_t)M.cseq[v];
         const uint32_t tv = M.tpos[v];
-        const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+        const bool live = in && !bits_marked(fs);
         const bool sense = (fs & GTS_F_SENSE) != 0;
         const bool arc = live && sense == du;
         const bool unset = old == GTS_DIST_UNSET;
@@ -2086,8 +2113,12 @@ struct GtsComponent {
       used = nb;
       uint32_t r_len, r_t;
       bool r_bad;
-      if (L == 8 && nv <= 64 && C.small_masks) walks_clean_batch_small(j0, nb, r_len, r_t, r_bad);
-      else walks_clean_batch<L>(j0, nb, r_len, r_t, r_bad);
+      const bool d16 = LDS && M.d16;
+      if (L == 8 && nv <= 64 && C.small_masks) {
+        if (d16) walks_clean_batch_small<true>(j0, nb, r_len, r_t, r_bad);
+        else walks_clean_batch_small<false>(j0, nb, r_len, r_t, r_bad);
+      } else if (d16) walks_clean_batch<L, true>(j0, nb, r_len, r_t, r_bad);
+      else walks_clean_batch<L, false>(j0, nb, r_len, r_t, r_bad);
       if (W::ballot(r_bad)) { ok = false; break; }
       /* first strictly longest walk in terminal order, algorithms.c:826-832 */
       uint32_t wg = GTS_NONE;
@@ -2157,7 +2188,7 @@ struct GtsComponent {
       const uint32_t ce = cur0 + a;
       const bool in = active && ce < se0;
       const uint32_t fs = edge_bits(in ? ce : sb0);
-      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+      const bool live = in && !bits_marked(fs);
       const bool sense = (fs & GTS_F_SENSE) != 0;
       const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
       hs |= ((bs >> gsh) & gm) != 0;
@@ -2207,7 +2238,7 @@ struct GtsComponent {
       const bool in = proc && ce < ue;
       const uint32_t cec = in ? ce : ub;
       const uint32_t fs = edge_bits(cec);
-      const bool live = in && !gts_edge_is_marked((uint8_t)(fs >> 4));
+      const bool live = in && !bits_marked(fs);
       const bool sense = (fs & GTS_F_SENSE) != 0;
       const bool arc = live && sense == du;
       const uint32_t v = M.cend[cec];
@@ -2403,6 +2434,10 @@ struct GtsComponent {
        of defer_ref_min_nv contigs from the first cc with a walk that needs the
        reference's search.  (One call site: the body is inlined.) */
     bool want_defer = C.defer_min_nv && nv >= C.defer_min_nv, forced = false;
+    if (!clean && C.defer_unclean_work && (C.defer_min_nv || C.defer_ref_min_nv) && nterm >= 4 &&
+        (uint64_t)nterm * nv >= C.defer_unclean_work) {
+      want_defer = true; forced = true;
+    }
     bool may_late = C.defer_ref_min_nv && nv >= C.defer_ref_min_nv;
     uint32_t i0 = 0;
     for (;;) {
@@ -2493,7 +2528,7 @@ struct GtsComponent {
     bool any_live = false;
     for (uint32_t base = eb; base < ee; base += W::WIDTH) {
       const uint32_t ce = base + lane;
-      const bool live = ce < ee && !gts_edge_is_marked(M.cstate[ce]);
+      const bool live = ce < ee && !edge_marked(ce);
       any_live |= W::ballot(live) != 0;
     }
     if (!any_live) M.vst[v] = GIS_SCAFFOLD;

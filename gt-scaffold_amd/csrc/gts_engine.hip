@@ -133,6 +133,7 @@ struct GtsgEngine {
      deferral at all is fastest: 55.8 ms per step against 60.0 with every
      component of 256 contigs deferred (gpurun_out/r02m) */
   int64_t defer_min_work = 1ll << 17;
+  int64_t defer_unclean_work = 0;    /* components that are not clean: walks as tasks from this many terminals x contigs on (0: off) */
   /* a component of at least this many contigs hands a walk that needs the
      reference's search (and the walks of the ccs behind it) to tasks instead of
      replaying the search in line: 15 such walks of one 248-contig component
@@ -1236,7 +1237,7 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   int32_t __attribute__((address_space(3))) *cdist = nullptr;
   int16_t __attribute__((address_space(3))) *cdist16 = nullptr;
   if (d32) cdist = lds_carve<int32_t>(p, ne); else cdist16 = lds_carve<int16_t>(p, ne);
-  auto cfs = lds_carve<uint8_t>(p, ne);   /* flags | state << 4 */
+  auto cfs = lds_carve<uint8_t>(p, ne);   /* flags | state << 4 | marked << 7 */
   /* the walk scratch, in one piece (gts_comp_lds_bytes): slot 0 of the batched
      walks is distmap, plen, edgemap, par */
   M.wbase = (char __attribute__((address_space(3))) *)p;
@@ -1278,7 +1279,8 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
   for (uint32_t i = lane; i < ne; i += GTS_WAVE) {
     cend[i] = (idx_t)G0.cend[i];
     if (d32) cdist[i] = (int32_t)G0.cdist[i]; else cdist16[i] = (int16_t)G0.cdist[i];
-    cfs[i] = (uint8_t)((G0.cflags[i] & 15u) | (G0.cstate[i] << 4));
+    const uint8_t st = G0.cstate[i];
+    cfs[i] = (uint8_t)((G0.cflags[i] & 15u) | (st << 4) | (gts_edge_is_marked(st) ? 0x80u : 0u));   /* GtsLdsStateRef */
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (sarc) {
@@ -1904,6 +1906,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "batch_big_slots") && value >= 2 && value <= GTS_WALK_SLOTS_MAX) e->batch_big_slots = value;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
   else if (!strcmp(name, "defer_min_work") && value >= 0) e->defer_min_work = value;
+  else if (!strcmp(name, "defer_unclean_work") && value >= 0) e->defer_unclean_work = value;
   else if (!strcmp(name, "defer_ref_min_contigs") && value >= 0) e->defer_ref_min_contigs = value;
   else if (!strcmp(name, "task_reference_walks")) e->task_reference_walks = value != 0;
   else if (!strcmp(name, "pool_components")) e->pool_components = value != 0;
@@ -2773,6 +2776,7 @@ static int run_components(GtsgEngine *e, int mode)
     C.gorient = s_gorient; C.topo = s_topo; C.tpos = s_tpos;
     C.defer_min_nv = mode == GTS_MODE_MAKESCAFFOLD && e->lds_components ? (uint32_t)e->defer_min_contigs : 0u;
     C.defer_min_work = (uint64_t)e->defer_min_work;
+    C.defer_unclean_work = mode == GTS_MODE_MAKESCAFFOLD && e->lds_components ? (uint64_t)e->defer_unclean_work : 0;
     C.defer_ref_min_nv = mode == GTS_MODE_MAKESCAFFOLD && e->lds_components ? (uint32_t)e->defer_ref_min_contigs : 0u;
     C.task_reference = (int)e->task_reference_walks;
     C.defer_flag = defer_flag; C.comp_task0 = comp_task0; C.comp_ncc = comp_ncc; C.comp_nterm = comp_nterm;

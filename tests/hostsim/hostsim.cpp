@@ -248,7 +248,7 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   }
   std::vector<uint32_t> paths(path_cap);
   unsigned long long ntasks = 0, path_used = 0;
-  C.defer_min_nv = defer_min_nv; C.defer_min_work = 0; C.defer_flag = defer_flag.data();
+  C.defer_min_nv = defer_min_nv; C.defer_min_work = 0; C.defer_unclean_work = 0; C.defer_flag = defer_flag.data();
   C.defer_ref_min_nv = defer_ref_min_nv; C.task_reference = defer_ref_min_nv != 0;
   C.comp_task0 = comp_task0.data(); C.comp_ncc = comp_ncc.data(); C.comp_nterm = comp_nterm.data();
   unsigned long long task_bytes = 0;
