@@ -12,15 +12,39 @@
 #define _GNU_SOURCE
 #include "gt_scaffolder_host.h"
 
+#include <errno.h>
+#include <fcntl.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "gt_scaffold_hip.h"
 
 #define LINE_MAX_REF 1023 /* the reference reads lines with fgets(line, 1024) */
+
+/* GT_SCAFFOLDER_TIMING=1: the steps of the output functions on stderr */
+static double now_s(void)
+{
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+static void lap(const char *what, double *t0)
+{
+  static int on = -1;
+  double t;
+  if (on < 0) { const char *e = getenv("GT_SCAFFOLDER_TIMING"); on = e && *e && *e != '0'; }
+  if (!on) return;
+  t = now_s();
+  fprintf(stderr, "[gt_scaffolder] %-28s %8.1f ms\n", what, 1e3 * (t - *t0));
+  *t0 = t;
+}
 
 static int g_device = 0;
 void gt_scaffolder_set_device(int device) { g_device = device; }
@@ -94,12 +118,76 @@ static void *xrealloc(void *q, size_t sz)
   return p;
 }
 
+/* A large transfer between a file and memory in pieces side by side: one
+   thread copies to or from the page cache at 2 - 3 GB/s (and takes the page
+   faults of a fresh buffer one by one); the 3.9 GB contig file of the 3 M-contig
+   example was 1 s of every pass over it. */
+#define IO_PIECE_MIN ((size_t)32 << 20)
+#define IO_THREADS_MAX 8
+typedef struct { int fd, wr, bad; char *buf; size_t len; off_t off; } IoJob;
+static void *io_worker(void *p)
+{
+  IoJob *j = p;
+  size_t done = 0;
+  while (done < j->len) {
+    ssize_t k = j->wr ? pwrite(j->fd, j->buf + done, j->len - done, j->off + (off_t)done)
+                      : pread(j->fd, j->buf + done, j->len - done, j->off + (off_t)done);
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) { j->bad = 1; break; }
+    done += (size_t)k;
+  }
+  return NULL;
+}
+static int io_parallel(int fd, char *buf, size_t len, off_t off, int wr)
+{
+  IoJob job[IO_THREADS_MAX];
+  pthread_t th[IO_THREADS_MAX];
+  long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+  size_t n = len / IO_PIECE_MIN, i, piece;
+  int bad = 0, started[IO_THREADS_MAX];
+  if (n > IO_THREADS_MAX) n = IO_THREADS_MAX;
+  if (ncpu > 0 && n > (size_t)ncpu) n = (size_t)ncpu;
+  if (n < 1) n = 1;
+  piece = (len / n + 4095) & ~(size_t)4095;
+  for (i = 0; i < n; i++) {
+    size_t b = i * piece, e = i + 1 == n ? len : (i + 1) * piece;
+    if (b > len) b = len;
+    if (e > len) e = len;
+    job[i].fd = fd; job[i].wr = wr; job[i].bad = 0; job[i].buf = buf + b; job[i].len = e - b;
+    job[i].off = off + (off_t)b;
+    started[i] = i > 0 && pthread_create(&th[i], NULL, io_worker, &job[i]) == 0;
+  }
+  io_worker(&job[0]);
+  for (i = 1; i < n; i++) {
+    if (started[i]) pthread_join(th[i], NULL);
+    else io_worker(&job[i]);     /* no thread to be had: here */
+  }
+  for (i = 0; i < n; i++) bad |= job[i].bad;
+  return bad;
+}
+
 /* whole file into memory, NUL-terminated */
 static char *slurp(const char *path, size_t *len)
 {
-  FILE *f = fopen(path, "rb");
+  FILE *f;
   char *buf;
   long sz;
+  {
+    /* a regular file: sized by fstat, read in parallel pieces */
+    struct stat st;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return NULL;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 0) {
+      buf = malloc((size_t)st.st_size + 1);
+      if (!buf || io_parallel(fd, buf, (size_t)st.st_size, 0, 0)) { free(buf); close(fd); return NULL; }
+      buf[st.st_size] = '\0';
+      close(fd);
+      *len = (size_t)st.st_size;
+      return buf;
+    }
+    close(fd);
+  }
+  f = fopen(path, "rb");
   if (!f) return NULL;
   if (fseek(f, 0, SEEK_END) != 0 || (sz = ftell(f)) < 0) { fclose(f); return NULL; }
   rewind(f);
@@ -972,6 +1060,7 @@ int gt_scaffolder_graph_print(const GtScaffolderGraph *cg, const char *filename,
   FILE *f;
   OutBuf ob;
   uint64_t i;
+  double t0 = now_s();
   if (g->eng && !g_host_dot) {
     /* a graph on the GPU: its edge lines (all but a few per cent of the file)
        are formatted there, 2^23 edges at a time; only the vertex states cross
@@ -984,18 +1073,30 @@ int gt_scaffolder_graph_print(const GtScaffolderGraph *cg, const char *filename,
     ob_init(&ob, f);
     ob_str(&ob, "digraph {\n");
     for (i = 0; i < g->nof_vertices; i++) {
+      /* (the headers are strings of their own all over the heap) */
+      if (i + 16 < g->nof_vertices) __builtin_prefetch(g->ctg[i + 16].name);
       ob_u64(&ob, i);
       ob_str(&ob, " [color=\""); ob_str(&ob, color[g->vstate[i] & 7]);
       ob_str(&ob, "\" label=\""); ob_str(&ob, g->ctg[i].name);
       ob_str(&ob, "\"];\n");
     }
     rc = ob_close(&ob);
+    lap("dot: vertex lines", &t0);
     for (i = 0; i < g->nof_edges && !rc; i += chunk) {
       uint64_t cnt = g->nof_edges - i < chunk ? g->nof_edges - i : chunk, nb = 0;
       const char *text = NULL;
       rc = gtsg_format_dot_edges_pinned(g->eng, i, cnt, &text, &nb);
       if (rc) { engine_err(g, rc, NULL, 0); break; }
-      if (fwrite(text, 1, nb, f) != nb) rc = -1;
+      lap("dot: chunk formatted", &t0);
+      {
+        /* past stdio: the chunk (half a gigabyte) goes out in parallel pieces */
+        off_t at;
+        if (fflush(f) != 0 || (at = ftello(f)) < 0 ||
+            io_parallel(fileno(f), (char *)(uintptr_t)text, nb, at, 1) ||
+            fseeko(f, at + (off_t)nb, SEEK_SET) != 0)
+          rc = -1;
+      }
+      lap("dot: chunk written", &t0);
     }
     if (!rc && fwrite("}\n", 1, 2, f) != 2) rc = -1;
     if (fclose(f) != 0) rc = rc ? rc : -1;
@@ -1174,15 +1275,18 @@ gt_scaffolder_graph_iterate_scaffolds(GtScaffolderGraph *g, uint64_t **scaf_seql
   uint64_t n, v, k, *seqlen = NULL;
   uint8_t *vs;
   ScafCsr c;
+  double t0 = now_s();
   if (!g) return NULL;
   if (g->eng) {
     int rc = gtsg_get_vertex_states(g->eng, g->vstate);
     if (rc) { engine_err(g, rc, NULL, 0); return NULL; }
   }
+  lap("records: vertex states", &t0);
   if (scaf_csr(g, &c) != 0) {
     if (g->eng) engine_err(g, -1, NULL, 0);
     return NULL;
   }
+  lap("records: SCAFFOLD sub-CSR", &t0);
   n = g->nof_vertices;
   r = xcalloc(1, sizeof *r);
   r->g = g;
@@ -1197,56 +1301,95 @@ gt_scaffolder_graph_iterate_scaffolds(GtScaffolderGraph *g, uint64_t **scaf_seql
   vs = g->vstate;
   for (v = 0; v < n; v++)
     if (!v_marked(vs[v]) && vs[v] != 6) vs[v] = 0;
-  for (v = 0; v < n; v++) {
-    uint64_t nscaf, len;
-    if (vs[v] == 4 || v_marked(vs[v])) continue;
-    nscaf = c.row[v + 1] - c.row[v];
-    if (nscaf > 1) continue;
-    if (r->n == r->cap) {
-      r->cap = r->cap ? 2 * r->cap : 256;
-      r->root = xrealloc(r->root, r->cap * sizeof *r->root);
-      r->off = xrealloc(r->off, (r->cap + 1) * sizeof *r->off);
-      seqlen = xrealloc(seqlen, r->cap * sizeof *seqlen);
-    }
-    r->root[r->n] = v;
-    r->off[r->n] = r->nedge;
-    len = g->ctg[v].seq_len;
-    vs[v] = 4;
-    if (nscaf == 1) {
-      const REdge *ce = c.e + c.row[v];
-      uint32_t from = (uint32_t)v;
-      for (;;) {
-        uint32_t w = ce->end;
-        uint64_t cnt = 0;
-        const REdge *nxt = NULL;
-        bool sense = ce->flags & 1, same = ce->flags & 2, dir;
-        if (r->nedge == r->capedge) {
-          r->capedge = r->capedge ? 2 * r->capedge : 1024;
-          r->edge = xrealloc(r->edge, r->capedge * sizeof *r->edge);
-        }
-        r->edge[r->nedge++] = *ce;
-        len += (uint64_t)ce->dist;
-        len += g->ctg[w].seq_len;
-        if (vs[w] == 4) break;
-        vs[w] = 4;
-        dir = same ? sense : !sense;
-        for (k = c.row[w]; k < c.row[w + 1]; k++) {
-          const REdge *x = c.e + k;
-          /* (not the edge back to where the walk came from: the twin) */
-          if (((x->flags & 1) != 0) == dir && x->end != from) { cnt++; nxt = x; }
-        }
-        if (cnt != 1) break;
-        from = w;
-        ce = nxt;
+  {
+    /* The walk hops from contig to contig all over the graph: what a step asks
+       of the contig it arrives at -- its length, its first two SCAFFOLD edges
+       (end, flags; nearly every contig has at most two) and where its list
+       starts -- sits in one 32-byte record, one cache miss a step instead of
+       three dependent ones (contig table, row offsets, edge list).  The walk
+       keeps the positions of the edges it takes; the edges themselves and the
+       distances along a record are fetched afterwards, in order. */
+    typedef struct { uint64_t seq_len; uint32_t k0, end[2]; uint8_t ns, fl[2]; } VRec;
+    VRec *vr = xrealloc(NULL, (n ? n : 1) * sizeof *vr);
+    uint32_t *took = xrealloc(NULL, r->capedge * sizeof *took);
+    uint64_t capt = r->capedge, i;
+    for (v = 0; v < n; v++) {
+      const uint32_t b = c.row[v], e = c.row[v + 1];
+      VRec *x = vr + v;
+      x->seq_len = g->ctg[v].seq_len;
+      x->k0 = b;
+      x->ns = (uint8_t)(e - b > 255 ? 255 : e - b);
+      for (k = 0; k < 2; k++) {
+        x->end[k] = b + k < e ? c.e[b + k].end : 0;
+        x->fl[k] = b + k < e ? c.e[b + k].flags : 0;
       }
     }
-    seqlen[r->n] = len;
-    r->n++;
-  }
-  if (r->off || r->n == 0) {
-    r->off = xrealloc(r->off, (r->n + 1) * sizeof *r->off);
+    lap("records: arrays", &t0);
+    for (v = 0; v < n; v++) {
+      uint64_t len;
+      if (vs[v] == 4 || v_marked(vs[v])) continue;
+      if (vr[v].ns > 1) continue;
+      r->root[r->n] = v;
+      r->off[r->n] = r->nedge;
+      len = vr[v].seq_len;
+      vs[v] = 4;
+      if (vr[v].ns == 1) {
+        uint32_t from = (uint32_t)v, kk = vr[v].k0, w = vr[v].end[0];
+        uint8_t fl = vr[v].fl[0];
+        for (;;) {
+          const VRec *x = vr + w;
+          uint64_t cnt = 0;
+          uint32_t nk = 0, nw = 0;
+          uint8_t nf = 0;
+          bool sense = fl & 1, same = fl & 2, dir;
+          if (r->nedge == capt) {
+            capt = capt ? 2 * capt : 1024;
+            took = xrealloc(took, capt * sizeof *took);
+          }
+          took[r->nedge++] = kk;
+          len += x->seq_len;
+          if (vs[w] == 4) break;
+          vs[w] = 4;
+          dir = same ? sense : !sense;
+          if (x->ns <= 2) {
+            for (k = 0; k < x->ns; k++)
+              /* (not the edge back to where the walk came from: the twin) */
+              if (((x->fl[k] & 1) != 0) == dir && x->end[k] != from) {
+                cnt++; nk = x->k0 + (uint32_t)k; nw = x->end[k]; nf = x->fl[k];
+              }
+          } else
+            for (k = c.row[w]; k < c.row[w + 1]; k++) {
+              const REdge *y = c.e + k;
+              if (((y->flags & 1) != 0) == dir && y->end != from) {
+                cnt++; nk = (uint32_t)k; nw = y->end; nf = y->flags;
+              }
+            }
+          if (cnt != 1) break;
+          from = w;
+          kk = nk; w = nw; fl = nf;
+        }
+      }
+      seqlen[r->n] = len;
+      r->n++;
+    }
     r->off[r->n] = r->nedge;
+    lap("records: walk", &t0);
+    if (r->nedge > r->capedge) {
+      r->capedge = r->nedge;
+      r->edge = xrealloc(r->edge, r->capedge * sizeof *r->edge);
+    }
+    for (i = 0; i < r->n; i++) {
+      uint64_t j, d = 0;
+      for (j = r->off[i]; j < r->off[i + 1]; j++) {
+        r->edge[j] = c.e[took[j]];
+        d += (uint64_t)r->edge[j].dist;
+      }
+      seqlen[i] += d;
+    }
+    free(vr); free(took);
   }
+  if (r->off || r->n == 0) r->off = xrealloc(r->off, (r->n + 1) * sizeof *r->off);
+  lap("records: edges", &t0);
   scaf_free(&c);
   if (scaf_seqlen) *scaf_seqlen = seqlen; else free(seqlen);
   return r;

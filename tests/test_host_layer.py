@@ -119,3 +119,28 @@ def test_scaffold_records_of_a_hand_built_graph(tmp_path):
     assert out.read_text() == "ctg_a\nctg_b\nctg_c\n"
     L.gt_scaffolder_graph_records_delete(recs)
     L.gt_scaffolder_graph_delete(g)
+
+
+def test_large_contig_file_is_read_in_parallel_pieces(tmp_path):
+    """a contig file above the size from which it is read by several threads
+    (gt_scaffolder_host.c, io_parallel: pieces of at least 32 MB): every contig
+    is counted, the ones below min_ctg_len are not (ref parser.c:399-415)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("host table only: with a GPU the FASTA table is made there")
+    n, width = 45000, 70
+    long_seq = ("ACGT" * 18)[:width] + "\n"
+    fa = tmp_path / "big.fa"
+    with open(fa, "w") as f:
+        for i in range(n):
+            lines = 50 if i % 3 else 2            # 3500 or 140 bases
+            f.write(">ctg%07d some description\n" % i)
+            f.write(long_seq * lines)
+    assert fa.stat().st_size > 3 * (32 << 20)
+    L = engine.lib()
+    err = C.create_string_buffer(256)
+    cnt = C.c_uint64()
+    assert L.gt_scaffolder_parser_count_contigs(str(fa).encode(), 200, C.byref(cnt), err, 256) == 0
+    assert cnt.value == n - (n + 2) // 3
+    assert L.gt_scaffolder_parser_count_contigs(str(fa).encode(), 100, C.byref(cnt), err, 256) == 0
+    assert cnt.value == n
