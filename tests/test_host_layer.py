@@ -144,3 +144,46 @@ def test_large_contig_file_is_read_in_parallel_pieces(tmp_path):
     assert cnt.value == n - (n + 2) // 3
     assert L.gt_scaffolder_parser_count_contigs(str(fa).encode(), 100, C.byref(cnt), err, 256) == 0
     assert cnt.value == n
+
+
+def test_counting_pass_is_reused_only_for_the_same_file(tmp_path):
+    """gt_scaffolder_parser_count_contigs keeps its scan of the contig file for
+    ..._read_contigs (the reference reads the file twice, parser.c:399-415 and
+    :417-493); a file that changed in between is read again"""
+    import time
+    L = engine.lib()
+    err = C.create_string_buffer(256)
+    cnt = C.c_uint64()
+
+    def write(path, n, length):
+        with open(path, "w") as f:
+            for i in range(n):
+                f.write(">c%04d x\n%s\n" % (i, "ACGT" * (length // 4)))
+
+    def read(path):
+        g = L.gt_scaffolder_graph_new(0, 0)
+        assert L.gt_scaffolder_parser_read_contigs(g, str(path).encode(), 200, False, err, 256) == 0, err.value
+        n = L.gt_scaffolder_graph_nof_vertices(g)
+        L.gt_scaffolder_graph_delete(g)
+        return n
+
+    fa = tmp_path / "a.fa"
+    write(fa, 50, 400)
+    assert L.gt_scaffolder_parser_count_contigs(str(fa).encode(), 200, C.byref(cnt), err, 256) == 0
+    assert cnt.value == 50 and read(fa) == 50          # the kept scan
+    assert read(fa) == 50                              # nothing kept any more: a scan of its own
+    assert L.gt_scaffolder_parser_count_contigs(str(fa).encode(), 200, C.byref(cnt), err, 256) == 0
+    time.sleep(0.01)
+    write(fa, 70, 400)                                 # same path, other content
+    assert read(fa) == 70
+    # same size and path, newer: still not the kept scan
+    assert L.gt_scaffolder_parser_count_contigs(str(fa).encode(), 200, C.byref(cnt), err, 256) == 0
+    time.sleep(0.01)
+    write(fa, 70, 400)
+    with open(fa, "r+") as f:
+        f.write(">X")                                  # first header renamed in place
+    assert read(fa) == 70
+    other = tmp_path / "b.fa"
+    write(other, 30, 400)
+    assert L.gt_scaffolder_parser_count_contigs(str(fa).encode(), 200, C.byref(cnt), err, 256) == 0
+    assert read(other) == 30
