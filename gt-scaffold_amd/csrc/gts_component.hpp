@@ -103,7 +103,9 @@ struct GtsCompView {
   uint32_t defer_min_nv;     /* 0: never defer */
   uint64_t defer_unclean_work;   /* a component that is not clean (its walks are made one by one, ten
                                     times the time per contig) defers from this many terminals x
-                                    contigs on; 0: the rule above only */
+                                    contigs on -- if some component of the launch has deferred already,
+                                    so that rounds of walk tasks follow anyway (on their own they cost
+                                    more than the launch gains); 0: the rules above only */
   uint64_t defer_min_work;   /* defer only if terminals x contigs reaches this: the walks of a
                                 component cost about that many vertex steps when made in place */
   uint32_t defer_ref_min_nv; /* 0: never.  A component of at least this many contigs that meets a walk
@@ -2435,7 +2437,7 @@ struct GtsComponent {
        reference's search.  (One call site: the body is inlined.) */
     bool want_defer = C.defer_min_nv && nv >= C.defer_min_nv, forced = false;
     if (!clean && C.defer_unclean_work && (C.defer_min_nv || C.defer_ref_min_nv) && nterm >= 4 &&
-        (uint64_t)nterm * nv >= C.defer_unclean_work) {
+        (uint64_t)nterm * nv >= C.defer_unclean_work && W::peek(C.ndeferred) != 0) {
       want_defer = true; forced = true;
     }
     bool may_late = C.defer_ref_min_nv && nv >= C.defer_ref_min_nv;
@@ -2848,6 +2850,7 @@ struct GtsWave1 {
   static GTS_HD uint64_t group8_or(uint64_t x) { return x; }
   static GTS_HD uint32_t group8_or32(uint32_t x) { return x; }
   static GTS_HD uint32_t group8_add32(uint32_t x) { return x; }
+  static GTS_HD uint64_t peek(const unsigned long long *p) { return *p; }
   static GTS_HD uint32_t clz64(uint64_t v) { uint32_t n = 0; while (n < 64 && !(v & (0x8000000000000000ull >> n))) ++n; return n; }
   static GTS_HD uint32_t lane() { return 0; }
   static GTS_HD uint64_t ballot(bool p) { return p ? 1u : 0u; }

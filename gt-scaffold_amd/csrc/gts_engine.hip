@@ -133,7 +133,8 @@ struct GtsgEngine {
      deferral at all is fastest: 55.8 ms per step against 60.0 with every
      component of 256 contigs deferred (gpurun_out/r02m) */
   int64_t defer_min_work = 1ll << 17;
-  int64_t defer_unclean_work = 0;    /* components that are not clean: walks as tasks from this many terminals x contigs on (0: off) */
+  int64_t defer_unclean_work = 2048; /* components that are not clean: walks as tasks from this many terminals x contigs on,
+                                        once another component of the launch has deferred (0: off) */
   /* a component of at least this many contigs hands a walk that needs the
      reference's search (and the walks of the ccs behind it) to tasks instead of
      replaying the search in line: 15 such walks of one 248-contig component
@@ -1037,6 +1038,12 @@ struct GtsWave64 {
     x |= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);    /* quad_perm [2,3,0,1] */
     x |= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);   /* row_half_mirror */
     return x;
+  }
+  /* a counter other workgroups add to, as it is now (same value in every lane) */
+  static __device__ __forceinline__ uint64_t peek(const unsigned long long *p)
+  {
+    const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (uint64_t)uni64((int64_t)v);
   }
   static __device__ __forceinline__ uint32_t group8_add32(uint32_t x)
   {

@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
@@ -518,8 +519,10 @@ static int scan_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len
     g->max_nof_vertices = cap;
     g->sorted = false;
     g->dp_names = false;   /* the GPU parser's name table is that of the old vertex set */
-  } else
-    fascan_keep(sc);
+  } else if ((sc->doff[sc->n] + 16 * sc->n) >> 30 == 0)
+    fascan_keep(sc);          /* (up to 1 GB: 15 M contigs with 50-byte headers) */
+  else
+    fascan_free(sc);
   return 0;
 }
 
@@ -1378,7 +1381,12 @@ gt_scaffolder_graph_iterate_scaffolds(GtScaffolderGraph *g, uint64_t **scaf_seql
        keeps the positions of the edges it takes; the edges themselves and the
        distances along a record are fetched afterwards, in order. */
     typedef struct { uint64_t seq_len; uint32_t k0, end[2]; uint8_t ns, fl[2]; } VRec;
-    VRec *vr = xrealloc(NULL, (n ? n : 1) * sizeof *vr);
+    /* (on huge pages if the system hands them out: a hop is then a cache miss,
+       not a cache miss and a page-table walk) */
+    const size_t vr_bytes = (((n ? n : 1) * sizeof(VRec)) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    VRec *vr = aligned_alloc((size_t)2 << 20, vr_bytes);
+    if (!vr) { fprintf(stderr, "gt_scaffolder: out of memory\n"); abort(); }
+    madvise(vr, vr_bytes, MADV_HUGEPAGE);
     uint32_t *took = xrealloc(NULL, r->capedge * sizeof *took);
     uint64_t capt = r->capedge, i;
     for (v = 0; v < n; v++) {
