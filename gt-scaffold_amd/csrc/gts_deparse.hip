@@ -105,6 +105,7 @@ static int dp_fail(GtsgDeParser *p, int code, const char *msg)
   return code;
 }
 #define DPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
+  (void)hipGetLastError();   /* (not left with the thread for the next, unrelated call) */ \
   snprintf(p->err, sizeof p->err, "%s: %s", #x, hipGetErrorString(_e)); \
   return _e == hipErrorOutOfMemory ? GTSG_ENOMEM : GTSG_EHIP; } } while (0)
 

@@ -194,9 +194,11 @@ static int fail(GtsgEngine *e, int code, const char *fmt, ...)
 #define HIPCHK(call)                                                          \
   do {                                                                        \
     hipError_t _r = (call);                                                   \
-    if (_r != hipSuccess)                                                     \
+    if (_r != hipSuccess) {                                                   \
+      (void)hipGetLastError();   /* reported here: not left with the thread */ \
       return fail(e, GTSG_EHIP, "%s failed: %s (%s:%d)", #call,               \
                   hipGetErrorString(_r), __FILE__, __LINE__);                 \
+    }                                                                         \
   } while (0)
 
 static hipEvent_t get_event(GtsgEngine *e)
@@ -264,9 +266,12 @@ static int pool_reserve(GtsgEngine *e, size_t bytes)
   e->pool = nullptr; e->pool_cap = 0;
   bytes += bytes / 8 + (1u << 20);
   hipError_t r = hipMalloc((void **)&e->pool, bytes);
-  if (r != hipSuccess)
+  if (r != hipSuccess) {
+    (void)hipGetLastError();   /* the error stays with the thread otherwise and fails the next, unrelated call */
+    e->pool = nullptr;
     return fail(e, GTSG_ENOMEM, "workspace of %zu bytes: %s", bytes,
                 hipGetErrorString(r));
+  }
   e->pool_cap = bytes;
   return 0;
 }
@@ -297,8 +302,11 @@ static int dev_alloc(GtsgEngine *e, T **p, size_t count)
   if (*p && it != e->alloc_bytes.end() && it->second >= bytes) return 0;
   if (*p) { e->alloc_bytes.erase((void *)*p); hipFree(*p); *p = nullptr; }
   hipError_t r = hipMalloc((void **)p, bytes + bytes / 16);
-  if (r != hipSuccess)
+  if (r != hipSuccess) {
+    (void)hipGetLastError();
+    *p = nullptr;
     return fail(e, GTSG_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(r));
+  }
   e->alloc_bytes[(void *)*p] = bytes + bytes / 16;
   return 0;
 }
