@@ -108,6 +108,24 @@ def test_walk_queue_retry():
     assert eng1.stat("walk_retries") == 0 and eng1.digest() == eng.digest()
 
 
+def test_out_of_memory_is_an_error_of_that_call_only():
+    """a workspace the device cannot hold (here: a walk-queue pool of 2^40 entries)
+    fails the call with GTSG_ENOMEM, leaves the states as they were, and does not
+    leave a HIP error behind for the next engine of the process"""
+    g = make_inputs(2000, 4)
+    og = oracle_from_inputs(g)
+    eng = engine_from_inputs(g, walk_pool_entries=1 << 40)
+    og.mark_repeats(); eng.mark_repeats()
+    og.filter(0.01, 1.5, 400); eng.filter(0.01, 1.5, 400)
+    with pytest.raises(pkg.engine.EngineError, match="out of memory"):
+        eng.makescaffold()
+    assert_same_states(eng, og, "after the failed call")
+    eng.set_option("walk_pool_entries", 1 << 20)
+    og.makescaffold(True); eng.makescaffold()
+    assert_same_states(eng, og, "makescaffold")
+    run_pipeline(make_inputs(500, 9))        # a fresh engine of the same process
+
+
 @pytest.mark.parametrize("seed", range(2))
 def test_reference_search_for_every_walk(seed):
     g = make_inputs(5000, 60 + seed, p_chimeric=0.05)
