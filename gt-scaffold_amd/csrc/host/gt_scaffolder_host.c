@@ -74,6 +74,9 @@ struct GtScaffolderGraph {
   GtsgEngine *eng;           /* NULL for hand-built graphs */
   GtsgDeParser *dp;          /* GPU parser of the distance file (holds the name table) */
   bool dp_names;             /* its name table is the sorted headers */
+  bool dp_parsed;            /* it holds the records of the distance file below (count_distances), */
+  dev_t dp_dev; ino_t dp_ino; off_t dp_size; struct timespec dp_mtime;   /* ... as that file was then */
+  GtsgDeParseResult dp_res;
   bool dup_names;            /* two contigs share a header: the GPU name table would pick either */
   bool sorted;               /* contigs in header order (ids are final) */
   char err[512];
@@ -540,6 +543,7 @@ static int scan_contigs(GtScaffolderGraph *g, const char *path, uint64_t min_len
     g->max_nof_vertices = cap;
     g->sorted = false;
     g->dp_names = false;   /* the GPU parser's name table is that of the old vertex set */
+    g->dp_parsed = false;
   } else if ((sc->doff[sc->n] + 16 * sc->n) >> 30 == 0)
     fascan_keep(sc);          /* (up to 1 GB: 15 M contigs with 50-byte headers) */
   else
@@ -798,7 +802,20 @@ static int gpu_parse_distances(GtScaffolderGraph *g, const char *path, GtsgDePar
   size_t len = 0;
   char *buf;
   int rc, have = 0;
+  struct stat st;
+  const bool have_stat = stat(path, &st) == 0;
   *used = 0;
+  if (g->dp && g->dp_names && g->dp_parsed && have_stat && g->dp_dev == st.st_dev && g->dp_ino == st.st_ino &&
+      g->dp_size == st.st_size && g->dp_mtime.tv_sec == st.st_mtim.tv_sec &&
+      g->dp_mtime.tv_nsec == st.st_mtim.tv_nsec) {
+    /* the integrity check (count_distances) has parsed this very file for this
+       contig set: its records are still on the device (the reference reads the
+       file twice, parser.c:150 and :295) */
+    *res = g->dp_res;
+    *used = 1;
+    return 0;
+  }
+  g->dp_parsed = false;
   if (ensure_parser(g, &have, err, errlen)) return -1;
   if (!have) return 0;
   buf = slurp(path, &len);
@@ -839,6 +856,10 @@ static int gpu_parse_distances(GtScaffolderGraph *g, const char *path, GtsgDePar
     return 0;
   }
   *used = 1;
+  if (have_stat && stat(path, &st) == 0) {
+    g->dp_parsed = true; g->dp_res = *res;
+    g->dp_dev = st.st_dev; g->dp_ino = st.st_ino; g->dp_size = st.st_size; g->dp_mtime = st.st_mtim;
+  }
   return 0;
 }
 
@@ -933,6 +954,7 @@ int gt_scaffolder_parser_read_distances(const char *filename, GtScaffolderGraph 
                                     ismatepair ? 1 : 0);
   free(seq); free(as); free(cn); rec_free(&r);
   if (g->dp) gtsg_deparser_trim(g->dp);   /* the name table stays for the A-statistic file */
+  g->dp_parsed = false;
   if (rc) {
     engine_err(g, rc, err, errlen);
     gtsg_destroy(g->eng);
@@ -1013,6 +1035,7 @@ int gt_scaffolder_graph_mark_repeats(const char *filename, GtScaffolderGraph *g,
       }
       free(as); free(cn);
       gtsg_deparser_trim(g->dp);
+      g->dp_parsed = false;
     }
     while (!on_gpu && pos < len) {
       size_t ls = pos, ll;

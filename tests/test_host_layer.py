@@ -187,3 +187,47 @@ def test_counting_pass_is_reused_only_for_the_same_file(tmp_path):
     write(other, 30, 400)
     assert L.gt_scaffolder_parser_count_contigs(str(fa).encode(), 200, C.byref(cnt), err, 256) == 0
     assert read(other) == 30
+
+
+@pytest.mark.gpu
+def test_distance_records_of_the_counting_pass_are_reused_only_for_the_same_file(tmp_path, golden_dir):
+    """gt_scaffolder_parser_count_distances leaves the parsed records on the
+    device for ..._read_distances (the reference reads the file twice,
+    parser.c:150 and :295); a file that changed in between is parsed again"""
+    import shutil
+    import time
+    L = engine.lib()
+    err = C.create_string_buffer(256)
+    fa = (golden_dir + "/primary-contigs.fa").encode()
+    lines = open(golden_dir + "/libPE.de").read().splitlines(True)
+
+    def edges(de_for_count, de_for_read, change=None):
+        cnt, nd = C.c_uint64(), C.c_uint64()
+        assert L.gt_scaffolder_parser_count_contigs(fa, 200, C.byref(cnt), err, 256) == 0
+        g = L.gt_scaffolder_graph_new(cnt.value, 0)
+        assert L.gt_scaffolder_parser_read_contigs(g, fa, 200, False, err, 256) == 0
+        assert L.gt_scaffolder_parser_count_distances(g, str(de_for_count).encode(), C.byref(nd), err, 256) == 0, err.value
+        if change:
+            change()
+        assert L.gt_scaffolder_parser_read_distances(str(de_for_read).encode(), g, False, err, 256) == 0, err.value
+        n = L.gt_scaffolder_graph_nof_edges(g)
+        L.gt_scaffolder_graph_delete(g)
+        return n
+
+    full = tmp_path / "full.de"
+    half = tmp_path / "half.de"
+    full.write_text("".join(lines))
+    # the file without its first pair (listed from both contigs)
+    few = [ln for ln in lines if "contig-4616" not in ln]
+    half.write_text("".join(few))
+    n_full, n_half = edges(full, full), edges(half, half)
+    assert 0 < n_half < n_full
+    work = tmp_path / "work.de"
+    shutil.copy(full, work)
+
+    def shrink():
+        time.sleep(0.01)
+        work.write_text("".join(few))
+
+    assert edges(work, work, shrink) == n_half     # counted on the full file, read after it shrank
+    assert edges(full, half) == n_half             # another file
