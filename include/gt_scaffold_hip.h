@@ -223,29 +223,59 @@ int gtsg_selftest_ambiguous(GtsgEngine *e, uint64_t n, const int64_t *d1,
 
 /* tuning */
 int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
-/*   "walk_queue_factor" (default 64: ring of a component's reference search =
-     factor x its live edges + 64 entries), "walk_pool_entries" (default 2^26,
-     the pool the rings are carved from; both are quadrupled and the call is
-     re-run from a snapshot if a ring or the pool overflows),
-     "max_walk_pops" (default 2^32),
-     "hub_degree" (default 32), "profile" (0, 1 = hipEvents around every kernel,
-     2 = also the per-component clocks: "us_sum_*" / "us_max_*", the slowest
-     components as "top<r>_*" and the size bands as "size_band<b>_*" statistics),
-     "fast_walks" (default 1; 0 forces the reference's label-correcting search
-     for every walk), "lds_components" (default 1; 0 runs every component
-     from global memory), "defer_min_contigs" (default 256; components with at
-     least that many contigs hand their walks to one workgroup per terminal,
-     0 = never) and "defer_min_work" (default 2^17: ... and with at least that
-     many terminals x contigs), "pool_components" (default 1: the LDS-resident
-     components run in ONE launch of a workgroup per CU whose "pool_waves"
-     (default and maximum 16) wavefronts claim components and share the CU's
-     LDS in 2 KB pages; 0: one launch per LDS size class on "class_streams"
-     (default 6) side streams), "mixed_task_limit" (default 256: a round with at most
-     that many pending walks is one launch for all classes), "walk_path_entries" (default 2^24, pool for the tasks' walks;
-     grows by itself like the walk queues), "defer_global_components" (default 0; 1: components
-     that run from global memory hand their walks out, too),
-     "global_task_pool_mb" (default 2048: scratch slabs of those walks; fewer
-     slabs than pending walks = several launches per round) */
+/*   Names and defaults (a name that is not known or a value out of range:
+     GTSG_EINVAL).  The results do not depend on any of them.
+     reference search:
+       "fast_walks" (1; 0 forces the reference's label-correcting search for
+         every walk), "walk_queue_factor" (8: ring of a search = factor x the
+         compact edges of its component to begin with; a search that overflows
+         its ring takes one eight times the size from the pool),
+       "walk_pool_entries" (2^26: the pool the rings are carved from; if it
+         runs out the call restores the states and runs again with eight times
+         the pool), "max_walk_pops" (2^32: a search that pops more nodes ends
+         the call with GTSG_EWALK, states restored)
+     where a component runs:
+       "lds_components" (1; 0 runs every component from global memory),
+       "pool_components" (1: the LDS-resident components run in ONE launch of a
+         workgroup per CU whose "pool_waves" (16, the maximum) wavefronts claim
+         components and share the CU's LDS in 1.5 KB pages; 0: one launch per
+         LDS size class on "class_streams" (6) side streams),
+       "pool_fill_kb" (4: the pool's second claim cursor starts at the components
+         of at most this footprint), "pool_wait_limit_us" (10^7: bound of every
+         wait inside that launch; a wait that gives up ends the call with
+         GTSG_EINTERNAL, states restored),
+       "lds_int16_distances" (1: int16 distances in LDS for components whose
+         distances all fit), "team_components" (1: a component too large for LDS
+         gets a workgroup of eight wavefronts, if there are at most
+         "team_max_components" (512) of them and their slabs fit "team_pool_mb"
+         (4096))
+     the walks of a component:
+       "batch_walks" (1: the walks of a cc of a clean component side by side,
+         eight lanes each), "batch_big_contigs" (64) / "batch_big_slots" (3):
+         LDS for that many walks from that many contigs on,
+       "small_masks" (1: sweep order and pending positions of components of at
+         most 64 contigs on 64-bit masks)
+     walks as tasks (one workgroup per walk, rounds with an in-order select pass):
+       "defer_min_contigs" (256) and "defer_min_work" (2^17 terminals x contigs):
+         a component that large hands out all its walks (0 = never),
+       "defer_ref_min_contigs" (48): a component of that many contigs hands out
+         the walks from the first one that needs the reference's search,
+       "defer_unclean_work" (2048 terminals x contigs): a component that is not
+         clean hands out its walks once another component of the launch has
+         deferred, "task_reference_walks" (1: tasks replay the reference's search
+         themselves; 0: the select pass does), "mixed_task_limit" (256: a round
+         with at most that many pending walks is one launch for all classes),
+       "walk_path_entries" (2^24, pool of the tasks' walks and bitmaps; grows by
+         itself like the walk queues), "defer_global_components" (0; 1: the
+         components in global memory hand their walks out, too, with
+         "global_task_pool_mb" (2048) of scratch slabs)
+     other:
+       "hub_degree" (32), "gather_unroll" (4: edges a thread of the gather-shaped
+       build kernels), "lds_poison" (-1; test aid: a byte to fill a component's
+       LDS pages with before staging), "profile" (0, 1 = hipEvents around every
+       kernel, 2 = also the per-component clocks: "us_sum_*" / "us_max_*", the
+       slowest components as "top<r>_*", the size bands as "size_band<b>_*" and
+       the rounds of walk tasks as "walk_round<r>_*" statistics) */
 
 /* ---- DistEst text on the GPU (gts_deparse.hip) --------------------------------
    Replaces the two passes of gt_scaffolder_parser.c over the .de file
