@@ -22,6 +22,19 @@ def params(seed):
               p_inversion=float(rng.choice([0.0, 0.3, 1.0])),
               p_relist=float(rng.choice([0.0, 0.05])),
               links_per_side=int(rng.choice([1, 2, 4])))
+    if seed >= 5000:
+        # second family: ties (few distinct distances, short contigs), flipped
+        # re-listings, larger graphs
+        if rng.random() < 0.5:
+            kw["dist_range_small"] = True
+            kw["contig_median"] = int(rng.choice([250, 900]))
+        if rng.random() < 0.3:
+            kw["p_relist_flip"] = 0.1
+        if rng.random() < 0.3:
+            kw["unique_pairs"] = True
+        if rng.random() < 0.2:
+            n = int(rng.integers(6000, 25000))
+            kw["p_chimeric"] = min(kw["p_chimeric"], 0.02)
     opts = {}
     if rng.random() < 0.3:
         opts["defer_min_contigs"] = int(rng.choice([0, 16, 64]))
