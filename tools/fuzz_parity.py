@@ -85,7 +85,7 @@ class Oracle:
     """oracle workers, all started up front: a process that has initialised the
     GPU must not start another program (fork + exec) on this pool"""
 
-    def __init__(self, spare=8):
+    def __init__(self, spare=40):
         import subprocess
         self.ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-worker"],
                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
