@@ -73,7 +73,7 @@ def one(seed, oracle, tmp):
                 ok = False
             seen[(int(a), int(b))] = int(s)
     ok = ok and np.array_equal(vs, og_v)
-    return (ok, seen, owner), n_, kw, world
+    return (ok, seen, og_e), n_, kw, world
 
 
 def main():
@@ -102,8 +102,7 @@ def main():
                 oe = og.edges()
                 ok = len(r[1]) == len(oe["start"])
                 if ok:
-                    want_e = oracle.get(seed, tmp)[1]
-                    for a, b, s in zip(oe["start"], oe["end"], want_e):
+                    for a, b, s in zip(oe["start"], oe["end"], r[2]):
                         if r[1].get((int(a), int(b))) != int(s):
                             ok = False
                             break
