@@ -88,8 +88,14 @@ def algorithmic_bytes(name, n, m, nrec, eng):
     # the launch handles, read once; states and marks written once
     if name == "k_components":
         return max(eng.stat("bytes_components_global_mem"), 0)
-    if name in ("k_components_lds", "k_components_pool"):   # all size classes: bytes of ONE step's launches
-        return sum(max(eng.stat("bytes_components_lds_class%d" % i), 0) for i in range(MAX_LDS_CLASSES))
+    if name in ("k_components_lds", "k_components_pool", "k_components_fast"):   # all size classes: bytes of ONE step's launches
+        total = sum(max(eng.stat("bytes_components_lds_class%d" % i), 0) for i in range(MAX_LDS_CLASSES))
+        if eng.stat("fast_kernel") > 0:
+            # the clean program stages every component of its slice once (the ones it
+            # hands over as well); the full program next to it stages the rest
+            done, handed = max(eng.stat("bytes_fast_finished"), 0), max(eng.stat("bytes_fast_handed_over"), 0)
+            return done + handed if name == "k_components_fast" else total - done
+        return total
     if name == "k_walk_tasks":            # every task stages its component once; one step's launches
         return max(eng.stat("bytes_walk_tasks"), 0)
     return table.get(name)
@@ -105,8 +111,11 @@ def kernel_groups(kt):
         if name.startswith("span_"):
             spans[name] = (calls, ms)
             continue
-        if name in ("components_makescaffold_pool", "components_removecycles_pool"):
+        if name in ("components_makescaffold_pool", "components_removecycles_pool",
+                    "components_makescaffold_cold", "components_removecycles_cold"):
             key = "k_components_pool"
+        elif name in ("components_makescaffold_fast", "components_removecycles_fast"):
+            key = "k_components_fast"
         elif name.startswith("components_makescaffold_lds") or name.startswith("components_removecycles_lds"):
             key = "k_components_lds"
         elif name == "components_walk_tasks":
@@ -144,7 +153,7 @@ def recorded_traffic(name):
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
-    if name in ("k_components_lds", "k_components_pool", "k_walk_tasks", "k_components"):
+    if name in ("k_components_lds", "k_components_pool", "k_components_fast", "k_walk_tasks", "k_components"):
         ks = [k for k in d if k.split("(")[0].split("<")[0].split("[")[0] == name]
         tot = sum((d[k]["fetch_bytes_per_launch_raw"] + d[k]["write_bytes_per_launch"]) * d[k]["launches"] for k in ks)
         n = sum(d[k]["launches"] for k in ks)
@@ -392,7 +401,7 @@ def main():
         # the dominant kernel: largest sum of launch durations, as rocprofv3 --stats ranks them
         dname = max(groups.items(), key=lambda kv: kv[1][1])[0]
         roof = roofline_of(dname)
-        if dname in ("k_components_lds", "k_components_pool"):
+        if dname in ("k_components_lds", "k_components_pool", "k_components_fast"):
             sp = spans.get("span_components_makescaffold")
             if sp and roof["algorithmic_bytes"]:
                 span_ms = sp[1] / max(sp[0], 1)
@@ -443,6 +452,10 @@ def main():
                        pool={k[5:]: eng.stat(k) for k in
                              ("pool_us_sum_run", "pool_us_sum_wait_pages", "pool_us_sum_wave_life",
                               "pool_us_first_exit", "pool_us_last_exit")},
+                       fast={k: eng.stat(k) for k in
+                             ("fast_kernel", "fast_wavefronts", "fast_components_done", "fast_components_handed_over",
+                              "fast_us_sum_run", "fast_us_sum_wait_pages", "fast_us_sum_wave_life",
+                              "fast_us_first_exit", "fast_us_last_exit", "cold_us_last_exit_after_fast_start")},
                        wave_us_per_lds_class={"%dk" % eng.stat("lds_class%d_kb" % i):
                                               dict(wave_us=eng.stat("lds_class%d_wave_us" % i),
                                                    walk_us=eng.stat("lds_class%d_walk_us" % i))

@@ -352,12 +352,18 @@ GTS_HD uint32_t gts_walk_slot_bytes(uint32_t nv)
    walks are independent (ref algorithms.c:809-832), so they are swept side by
    side (walks_clean_batch).  Smaller components use what their last page has
    left. */
+/* Second tier (round 4): from `huge_nv` contigs on, `huge_slots`.  The launch ends
+   with its longest programs, the few components of several hundred contigs whose
+   ccs hold 10 - 20 terminals each: with eight slots a wavefront sweeps a cc in two
+   or three batches instead of six (they are too few for their LDS to matter). */
 GTS_HD uint32_t gts_comp_lds_want(uint32_t nv, uint32_t ne, uint32_t big_nv, uint32_t big_slots,
-                                  uint32_t limit, bool d32 = true)
+                                  uint32_t limit, bool d32 = true, uint32_t huge_nv = 0,
+                                  uint32_t huge_slots = 0)
 {
   uint32_t need = gts_comp_lds_bytes(nv, ne, d32);
   if (big_nv && nv >= big_nv && need <= limit) {
     const uint32_t sb = gts_walk_slot_bytes(nv);
+    if (huge_nv && nv >= huge_nv && huge_slots > big_slots) big_slots = huge_slots;
     uint32_t extra = big_slots > 2 ? big_slots - 2 : 0;
     while (extra && need + extra * sb > limit) --extra;
     need += extra * sb;
@@ -658,6 +664,52 @@ struct GtsComponent {
     W::fence();
   }
 
+  /* the same on the working copy alone: every compact edge of the vertex and its
+     twin -- the one edge of the end vertex' list that comes back (an edge is in
+     the compact graph iff its twin is: k_live_union) -- turn CYCLIC.  Edges that
+     are not in the compact graph change nothing the program looks at; they are
+     marked in the global graph when the component is done (cyclic_marks_global) */
+  GTS_HD void mark_vertex_cyclic_lds(uint32_t s)
+  {
+    const uint32_t lane = W::lane();
+    M.vst[s] = GIS_CYCLIC;
+    const uint32_t le = M.coff[s + 1] - M.e0;
+    for (uint32_t ce = M.coff[s] - M.e0 + lane; ce < le; ce += W::WIDTH) {
+      M.cstate[ce] = GIS_CYCLIC;
+      M.cflags[ce] = (uint8_t)(M.cflags[ce] & ~GTS_F_TWINLIVE);
+      const uint32_t w = M.cend[ce];
+      const uint32_t we = M.coff[w + 1] - M.e0;
+      for (uint32_t t = M.coff[w] - M.e0; t < we; ++t)
+        if (M.cend[t] == s) {
+          M.cstate[t] = GIS_CYCLIC;
+          M.cflags[t] = (uint8_t)(M.cflags[t] & ~GTS_F_TWINLIVE);
+          break;
+        }
+    }
+    W::fence();
+  }
+  /* the global part of mark_vertex(v, GIS_CYCLIC), ref algorithms.c:61-87, for
+     every vertex the working copy holds as CYCLIC (a vertex that was CYCLIC before
+     the call is in no component) */
+  GTS_HD void cyclic_marks_global()
+  {
+    const uint32_t lane = W::lane();
+    for (uint32_t base = 0; base < nv; base += W::WIDTH) {
+      const uint32_t s = base + lane;
+      uint64_t cm = W::ballot(s < nv && M.vst[s < nv ? s : 0] == GIS_CYCLIC);
+      while (cm) {
+        const uint32_t l = W::ctz(cm);
+        cm &= cm - 1;
+        const uint32_t v = C.slot_v[s0 + base + l];
+        const uint32_t b = C.G.row[v], e = C.G.row[v + 1];
+        for (uint32_t p = b + lane; p < e; p += W::WIDTH) {
+          C.G.state[p] = GIS_CYCLIC;
+          C.G.state[C.G.twin[p]] = GIS_CYCLIC;
+        }
+      }
+    }
+  }
+
   /* ---- ref algorithms.c:495-578 ----
      keep_cc: the caller goes on with makescaffold, whose terminal search
      (algorithms.c:784) would repeat the one of the last pass.
@@ -666,7 +718,11 @@ struct GtsComponent {
      touched (algorithms.c:551-554) -- and is skipped; D is peeled again after
      every mark.  Once D is acyclic the pass ends there and the component is
      clean for the walks (topo / tpos are those of the last peeling). */
-  GTS_HD void removecycles(bool keep_cc)
+  GTS_HD void removecycles(bool keep_cc) { removecycles_t<false>(keep_cc); }
+  /* LOCAL: CYCLIC marks stay in the working copy (mark_vertex_cyclic_lds); the
+     caller writes them to the global graph when the component is done (run_fast) */
+  template <bool LOCAL>
+  GTS_HD void removecycles_t(bool keep_cc)
   {
     const uint32_t lane = W::lane();
     /* every compact edge live (no marked edge kept for its live twin): the first
@@ -725,8 +781,8 @@ struct GtsComponent {
         if (back != GTS_NONE) {
           found = true;
           const uint32_t a = W::uni(M.cstart[back]), b = W::uni(M.cend[back]);
-          mark_vertex_cyclic(a);
-          mark_vertex_cyclic(b);
+          if constexpr (LOCAL) { mark_vertex_cyclic_lds(a); mark_vertex_cyclic_lds(b); }
+          else { mark_vertex_cyclic(a); mark_vertex_cyclic(b); }
           if (oriented) peel();
         }
       }
@@ -2098,7 +2154,8 @@ struct GtsComponent {
   /* the walks of the cc with terminals [tb, te) in batches; false if a walk
      met a tie (nothing is kept then, the caller makes the walks one by one) */
   template <uint32_t L>
-  GTS_HD bool cc_walks_batched(uint32_t tb, uint32_t te, uint64_t &cc_len, uint32_t &cc_n)
+  GTS_HD bool cc_walks_batched(uint32_t tb, uint32_t te, uint64_t &cc_len, uint32_t &cc_n,
+                               uint32_t *best_start = nullptr)
   {
     typedef typename GtsCompMemT<LDS>::idx_t idx_t;
     const uint32_t G = W::WIDTH / L;
@@ -2140,6 +2197,7 @@ struct GtsComponent {
           cv = W::uni((uint32_t)par[cv]);
         }
         cc_n = n;
+        if (best_start) *best_start = start;
       }
       nfast += nb;
     }
@@ -2796,6 +2854,112 @@ struct GtsComponent {
     }
     W::fence();
     return i < ncc;
+  }
+
+  /* ---- the program of a clean component (round 4: k_components_fast) ----------
+     99.95 % of the components of a scaffold graph are clean (orient + peel): no
+     DFS of removecycles can close a cycle, every walk is one sweep of the
+     topological order and the walks of a cc are swept side by side.  This is
+     that program and nothing else: it touches LDS only until its last lines, so
+     when it meets something it does not hold -- a contradiction of strands, a
+     cycle of D, a tie in a batch, a component that wants to hand its walks to
+     tasks -- it returns false, nothing has left LDS, and the caller hands the
+     component to the full program (run(), k_components_pool's cold list).  Kept
+     apart from run() so that the kernel built around it holds none of the cycle
+     search, the walks one by one, the reference's search and the task tables:
+     half the registers, no scratch, twice the wavefronts per CU. */
+
+  /* mark_best() without the global graph: the twin of a walk edge u -> v is the
+     one edge of v's list that ends in u (a pair of contigs has one edge per
+     direction, ref gt_scaffolder_parser.c:357-378), and it is in the compact
+     graph because its twin is live (k_live_union).  best[] lists the walk from
+     its far end back to `start`, so the start vertex of best[k] is the end of
+     best[k + 1].  ref algorithms.c:835-848 */
+  GTS_HD void mark_best_lds(uint32_t cc_n, uint32_t start)
+  {
+    const uint32_t lane = W::lane();
+    for (uint32_t k = lane; k < cc_n; k += W::WIDTH) {
+      const uint32_t ce = M.cc_best[k];
+      const uint32_t v = M.cend[ce];
+      const uint32_t u = k + 1 < cc_n ? (uint32_t)M.cend[M.cc_best[k + 1]] : start;
+      M.cstate[ce] = GIS_SCAFFOLD;
+      const uint32_t le = M.coff[v + 1] - M.e0;
+      for (uint32_t t = M.coff[v] - M.e0; t < le; ++t)
+        if (M.cend[t] == u) { M.cstate[t] = GIS_SCAFFOLD; break; }
+      M.vst[v] = GIS_SCAFFOLD;
+      M.vst[u] = GIS_SCAFFOLD;
+    }
+    W::fence();
+  }
+
+  /* false: not a component for this program; nothing outside LDS has been
+     written.  walks: the walks it made (statistics) */
+  GTS_HD bool run_fast(int mode)
+  {
+    const uint32_t lane = W::lane();
+    if (nv < 2) return false;
+    const bool timed = C.tspan != nullptr;     /* detailed profile only: no clock reads otherwise */
+    uint64_t t0 = 0, t1 = 0;
+    if (timed) t0 = W::clock();
+    /* cycle removal with its marks kept in LDS (1 % of the components have a
+       cycle to remove; all but a few are clean afterwards) */
+    removecycles_t<true>(mode == GTS_MODE_MAKESCAFFOLD);
+    reuse_cc = clean;
+    if (timed) t1 = W::clock();
+    bool marks = false;
+    if (mode == GTS_MODE_MAKESCAFFOLD) {
+      if (!reuse_cc) calc_cc();
+      /* a component that would hand its walks to tasks (try_defer) */
+      if (C.defer_min_nv && nv >= C.defer_min_nv && nterm >= 2 &&
+          (uint64_t)nterm * nv >= C.defer_min_work) return false;
+      if (!clean && C.defer_unclean_work && (C.defer_min_nv || C.defer_ref_min_nv) && nterm >= 4 &&
+          (uint64_t)nterm * nv >= C.defer_unclean_work && W::peek(C.ndeferred) != 0) return false;
+      for (uint32_t s = lane; s < nv; s += W::WIDTH) { M.st_dir[s] = 0; M.tight[s] = 0; }   /* as makescaffold() */
+      W::fence();
+      auto ccoff = M.ccoff;
+      for (uint32_t i = 0; i < ncc; ++i) {
+        const uint32_t tb = W::uni(ccoff[i]), te = W::uni(ccoff[i + 1]);
+        if (te - tb == 1) lonesome(W::uni(M.term[tb]));
+        if (te - tb > 1) {
+          uint64_t cc_len = 0;
+          uint32_t cc_n = 0, cc_start = 0;
+          if (!clean || !cc_walks_batched<GTS_WALK_LANES>(tb, te, cc_len, cc_n, &cc_start)) {
+            /* a tie in the batch, or a component that is not clean: the walks of
+               this cc one by one (create_walk_clean / create_walk_fast: the
+               reference's tie-breaks in closed form); a walk that needs the
+               reference's search sends the component to the full program */
+            cc_len = 0; cc_n = 0;
+            for (uint32_t j = tb; j < te; ++j) {
+              if (cc_len == all_bases()) break;
+              const uint64_t len0 = cc_len;
+              const uint32_t start = W::uni(M.term[j]);
+              no_reference = true;
+              create_walk(start, cc_len, cc_n);
+              if (needs_reference) return false;
+              if (cc_len != len0) cc_start = start;
+            }
+          }
+          if (cc_n) { mark_best_lds(cc_n, cc_start); marks = true; }
+        }
+      }
+    }
+    /* (removecycles alone ends with every unmarked vertex UNVISITED: removecycles_t) */
+    cyclic_marks_global();
+#pragma unroll 1
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) C.G.vstate[C.slot_v[s0 + s]] = M.vst[s];
+    if (marks) {
+#pragma unroll 1
+      for (uint32_t k = lane; k < M.ne; k += W::WIDTH)
+        if ((uint8_t)M.cstate[k] == GIS_SCAFFOLD) C.G.state[C.cgpos[e0g + k]] = GIS_SCAFFOLD;
+    }
+    if (timed && lane == 0) {
+      const uint64_t t2 = W::clock();
+      C.stat_fast[c] = nfast; C.stat_ncc[c] = ncc; C.stat_clean[c] = (clean ? 1u : 0u) | (nterm << 8);
+      C.tstat[5 * (uint64_t)c] = t1 - t0;
+      C.tstat[5 * (uint64_t)c + 2] = t2 - t1;
+      C.tspan[2 * (uint64_t)c] = t0; C.tspan[2 * (uint64_t)c + 1] = t2;
+    }
+    return true;
   }
 
   GTS_HD void run(int mode)

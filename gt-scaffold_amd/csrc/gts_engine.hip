@@ -60,11 +60,14 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_S_TQCNT 352    /* u64 */
 #define GTS_S_NDEF 384     /* u64 */
 #define GTS_POOL_WAVES 16u /* wavefronts of a k_components_pool workgroup (one per CU) */
+#define GTS_FAST_WAVES 16u /* of a k_components_fast workgroup (two per CU), at most */
 #define GTS_S_POOLCUR 392  /* u64: claim counter of k_components_pool */
 #define GTS_S_POOLSTAT 400 /* 10 x u64: clocks, give-up and overrun counts of k_components_pool */
 #define GTS_S_TEAMUSED 424 /* u64: bytes of the team slab handed out */
 #define GTS_S_TEAMSTAT 432 /* 8 x u64: statistics of k_components_team */
 #define GTS_S_SMALLSTAT 448 /* 4 x u64: small components by "all edges live" */
+#define GTS_S_COLD 464      /* 8 x u64: the cold list's words (GTS_COLD_*) */
+#define GTS_S_FASTSTAT 480  /* 15 x u64: statistics of k_components_fast (as GTS_S_POOLSTAT, + [10..12]) */
 
 static const char *klass_event(int makescaffold, uint32_t bytes)
 {
@@ -144,6 +147,11 @@ struct GtsgEngine {
   int64_t pool_components = 1;        /* all LDS components in one launch (k_components_pool) */
   int64_t pool_waves = GTS_POOL_WAVES; /* wavefronts per workgroup of that launch */
   int64_t pool_fill_kb = 4;            /* the pool's fill cursor starts at the components of at most this footprint */
+  /* round 4: clean components on k_components_fast (two workgroups of fast_waves
+     wavefronts per CU), everything else -- and what that program hands over -- on
+     cold_cus workgroups of the full program next to it */
+  int64_t fast_components = 1, fast_waves = 12, cold_cus = 8;
+  int64_t fast_split = 0;   /* two workgroups with half a pool each per CU; 0: one with the whole pool */
   int64_t gather_unroll = 4;           /* edges a thread of the gather-shaped build kernels (1: A/B measurements) */
   int64_t lds_poison = -1;             /* test aid: fill a component's pages with this byte before staging */
   int64_t pool_wait_limit_us = 10000000; /* bound of every wait inside that launch (0: test aid, a wait gives up at once) */
@@ -153,6 +161,7 @@ struct GtsgEngine {
      (walks_clean_batch); from batch_big_contigs contigs on a component asks for
      LDS for batch_big_slots walk slots */
   int64_t batch_walks = 1, batch_big_contigs = 64, batch_big_slots = 3;
+  int64_t batch_huge_contigs = 256, batch_huge_slots = 8;   /* second tier: the launch's longest programs */
   int64_t lds_int16_distances = 1;   /* packed layout: int16 distances for components whose distances all fit */
   int64_t small_masks = 1;   /* topological order of components of at most 64 contigs on bit masks (peel_small) */
   /* walks of global-memory components fan out only on request: the components
@@ -1064,7 +1073,16 @@ struct GtsWave64 {
   {
     return (uint64_t)group8_or32((uint32_t)x) | (uint64_t)group8_or32((uint32_t)(x >> 32)) << 32;
   }
-  static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
+  /* opaque to the optimiser: everything a function derives from the lane number
+     (group masks, lane-indexed addresses into a dozen arrays) would otherwise be
+     hoisted out of the kernel's component loop and held in registers for the
+     whole launch -- twenty of them in k_components_fast */
+  static __device__ __forceinline__ uint32_t lane()
+  {
+    uint32_t l = threadIdx.x & 63u;
+    asm volatile("" : "+v"(l));
+    return l;
+  }
   static __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
   static __device__ __forceinline__ uint32_t popc(uint64_t m) { return (uint32_t)__popcll(m); }
   /* set bits of m below the calling lane (l is always lane()): v_mbcnt_lo/hi */
@@ -1236,7 +1254,7 @@ __device__ __forceinline__ void stage_component(const GtsCompView &C, uint32_t c
                                                 GtsCompMemT<true> &M, bool with_analysis, uint32_t avail)
 {
   const GtsCompMem G0 = GtsComponent<GtsWave64>::global_mem(C, c);
-  const uint32_t nv = G0.nv, ne = G0.ne, lane = threadIdx.x & (GTS_WAVE - 1u);
+  const uint32_t nv = G0.nv, ne = G0.ne, lane = GtsWave64::lane();
   gts_lds_cursor p = (gts_lds_cursor)smem;
   typedef GtsCompMemT<true>::idx_t idx_t;
   M.nv = nv; M.ne = ne; M.e0 = 0;
@@ -1357,7 +1375,15 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
 #define GTS_POOL_PAGES 104u                     /* 156 KB: one workgroup per CU (2 KB pages: 25 % more of a small component's last page wasted) */
 #define GTS_POOL_BYTES (GTS_POOL_PAGES * GTS_POOL_PAGE)
 #define GTS_POOL_BATCH 8u
+/* k_components_fast (round 4): TWO workgroups per CU, half the pages each */
+#define GTS_FAST_PAGES 52u
+#define GTS_FAST_BYTES (GTS_FAST_PAGES * GTS_POOL_PAGE)
+/* the cold list (device words, u64): components the fast program hands to the full one */
+enum { GTS_COLD_HEAD = 0, GTS_COLD_TAIL = 1, GTS_COLD_DONE = 2, GTS_COLD_PRODUCERS = 3, GTS_COLD_NSEED = 4,
+       GTS_COLD_WORDS = 8 };
 struct GtsPoolCtl {
+  uint32_t exited;         /* k_components_fast: wavefronts of the workgroup that have left */
+  uint32_t seed_round;     /* cold mode: seeded components this workgroup has taken */
   uint32_t lock;
   uint32_t front_busy;     /* a wavefront holds a front claim it has no pages for yet */
   uint32_t wait_pages;     /* pages that wavefront needs (0: it is not waiting) */
@@ -1365,6 +1391,12 @@ struct GtsPoolCtl {
   uint32_t f_next, f_end;  /* stock of front indices [f_next, f_end) */
   uint32_t b_next, b_cnt;  /* stock of fill indices b_next, b_next+1, ... (b_cnt of them) */
   uint32_t f_done, b_done; /* the cursor has nothing more to give */
+  /* statistics, summed here and added to the launch's words by the workgroup's last
+     wavefront (kept out of the wavefronts' registers: they would be live across
+     every component program) */
+  unsigned long long t_run, t_wait, t_life;
+  unsigned long long n_done, n_walks, n_cold, b_done_bytes, b_cold_bytes;
+  unsigned long long t_begin[GTS_POOL_WAVES];
 };
 /* the page bitmap as one integer (bit q = page q in use) */
 typedef unsigned __int128 gts_pool_bits;
@@ -1435,44 +1467,111 @@ __device__ __forceinline__ void pool_unlock(GtsPoolCtl *ctl)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   atomicExch(&ctl->lock, 0u);
 }
-__global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
-k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_key, uint32_t first,
-                  uint32_t count, int mode,
-                  unsigned long long *cursor, unsigned long long *pstat, uint32_t nbig, int poison,
-                  uint64_t wait_limit, uint32_t g0)
+/* The launch's arguments besides the view (one struct: the fast and the full
+   kernel take the same) */
+struct GtsPoolArgs {
+  const uint32_t *order, *order_key;   /* components by decreasing footprint; ~footprint */
+  uint32_t first, count;               /* the launch's slice of them */
+  int mode;
+  unsigned long long *cursor, *pstat;
+  uint32_t nbig, g0;
+  int poison;
+  uint64_t wait_limit;
+  /* cold list (or null): u64 words GTS_COLD_*, entries (footprint << 32 | component + 1).
+     The fast kernel appends; the full kernel in cold mode takes its components
+     from it, in order, until every producer has left and the list is empty */
+  unsigned long long *cold, *cold_list;
+};
+/* the leading components of the slice -- those whose footprint does not fit a
+   fast workgroup's pool -- go to the cold list before the launches; the fast
+   kernel's slice starts behind them */
+__global__ void k_cold_seed(const uint32_t *order, const uint32_t *order_key, uint32_t first, uint32_t count,
+                            unsigned long long *cold, unsigned long long *cold_list, uint32_t producers,
+                            uint32_t fast_bytes)
 {
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) {
+    uint32_t lo = 0, hi = count;     /* first index whose footprint fits (keys ascending = footprints descending) */
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (~order_key[first + mid] > fast_bytes - 16u) lo = mid + 1; else hi = mid;
+    }
+    s_n = lo;
+    cold[GTS_COLD_HEAD] = lo; cold[GTS_COLD_TAIL] = lo; cold[GTS_COLD_DONE] = 0;   /* (the seeds are dealt by position) */
+    cold[GTS_COLD_PRODUCERS] = producers; cold[GTS_COLD_NSEED] = lo;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < s_n; i += blockDim.x)
+    cold_list[i] = (unsigned long long)(~order_key[first + i]) << 32 | (unsigned long long)(order[first + i] + 1u);
+}
+
+/* The control block's address, opaque to the optimiser: its fields are then
+   reached as base + immediate offset.  With the address known (a static
+   __shared__ object) every field's address is a constant of its own in a vector
+   register, hoisted out of the kernel's loop: a dozen registers held for the
+   whole launch. */
+__device__ __forceinline__ GtsPoolCtl *pool_ctl_opaque(GtsPoolCtl *p)
+{
+  typedef GtsPoolCtl __attribute__((address_space(3))) *lds_ctl;
+  uint32_t a = (uint32_t)(uintptr_t)(lds_ctl)p;
+  asm volatile("" : "+v"(a));
+  return (GtsPoolCtl *)(lds_ctl)(uintptr_t)a;
+}
+
+/* FAST: the clean program on half a CU's pool (k_components_fast); else the full
+   program (k_components_pool), which in cold mode (A.cold) claims from the cold
+   list instead of the sorted one */
+template <bool FAST, uint32_t PAGES>
+__device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArgs &A, char *smem, GtsPoolCtl *ctl0)
+{
+  GtsPoolCtl *ctl = ctl0;
   /* pstat (100 MHz ticks, summed over the wavefronts): [0] staging + program,
      [1] waiting for pages, [2] whole life of the wavefront; [3] first exit,
      [4] last exit (since the first wavefront's start, [5]); [6..8] waits that
      ran into their bound (lock, claim, pages); [9] programs that wrote past
-     their footprint */
-  const uint64_t t_begin = GtsWave64::clock();
-  uint64_t t_run = 0, t_wait = 0;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ GtsPoolCtl ctl_s;
-  GtsPoolCtl *ctl = &ctl_s;
+     their footprint; fast kernel: [10] components it finished, [11] their walks,
+     [12] components it handed to the cold list, [13] / [14] bytes of the former /
+     the latter */
+  unsigned long long *const pstat = A.pstat;
+  const uint64_t wait_limit = A.wait_limit;
   if (threadIdx.x == 0) {
+    ctl->exited = 0; ctl->seed_round = 0;
+    ctl->t_run = ctl->t_wait = ctl->t_life = 0;
+    ctl->n_done = ctl->n_walks = ctl->n_cold = ctl->b_done_bytes = ctl->b_cold_bytes = 0;
     ctl->lock = 0; ctl->front_busy = 0; ctl->wait_pages = 0;
     ctl->used[0] = ctl->used[1] = ctl->used[2] = ctl->used[3] = 0;
     ctl->f_next = ctl->f_end = ctl->b_next = ctl->b_cnt = ctl->f_done = ctl->b_done = 0;
   }
   __syncthreads();
+  if ((threadIdx.x & (GTS_WAVE - 1u)) == 0) ctl->t_begin[threadIdx.x / GTS_WAVE] = GtsWave64::clock();
+  const bool cold_mode = !FAST && A.cold != nullptr;
+  /* the fast kernel's slice starts behind the components seeded to the cold list */
+  uint32_t first = A.first, count = A.count, nbig = A.nbig, g0 = A.g0;
+  if (A.cold) {
+    const uint32_t ns = (uint32_t)A.cold[GTS_COLD_NSEED];
+    first += ns; count -= ns;
+    nbig = nbig > ns ? nbig - ns : 0u;
+    g0 = g0 > ns ? g0 - ns : 0u;
+  }
   const uint32_t lane = threadIdx.x & (GTS_WAVE - 1u);
   for (;;) {
+    ctl = pool_ctl_opaque(ctl0);
     /* role, claim, pages: lane 0; the rest of the wavefront waits at the broadcast */
-    uint32_t idx = GTS_NONE, pos = 0, npages = 0, need = 0;
+    uint32_t idx = GTS_NONE, pos = 0, npages = 0, need = 0, comp = GTS_NONE;
     if (lane == 0) {
       bool front = false;
       const uint64_t tc0 = GtsWave64::clock();
-      for (uint32_t spins = 0;;) {
-        bool more;
-        if (!pool_lock(ctl, pstat, wait_limit)) break;      /* no claim: this wavefront leaves */
+      /* a claim from the sorted list.  0: idx; 1: nothing for this wavefront now, but
+         the front (held by the one that waits for pages) has; 2: nothing left;
+         3: the lock was not to be had (this wavefront leaves) */
+      auto claim_sorted = [&](bool may_front) -> int {
+        if (!pool_lock(ctl, pstat, wait_limit)) return 3;
         volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
-        front = v->front_busy == 0;
+        front = may_front && v->front_busy == 0;
         if (front) {
           if (v->f_next == v->f_end && !v->f_done) {
             const uint32_t want = v->f_end < nbig ? 1u : GTS_POOL_BATCH;
-            const unsigned long long old = atomicAdd(cursor, (unsigned long long)want);
+            const unsigned long long old = atomicAdd(A.cursor, (unsigned long long)want);
             const uint64_t h = old & 0xFFFFFFFFull;
             const uint64_t lim = g0;                                              /* the fill cursor holds [g0, count) */
             if (h < lim) { v->f_next = (uint32_t)h; v->f_end = (uint32_t)(h + want < lim ? h + want : lim); }
@@ -1483,7 +1582,7 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
         }
         if (!front) {
           if (v->b_cnt == 0 && !v->b_done) {
-            const unsigned long long old = atomicAdd(cursor, (unsigned long long)GTS_POOL_BATCH << 32);
+            const unsigned long long old = atomicAdd(A.cursor, (unsigned long long)GTS_POOL_BATCH << 32);
             const uint64_t t = old >> 32, at = (uint64_t)g0 + t;
             const uint64_t avail = at < (uint64_t)count ? (uint64_t)count - at : 0;
             if (avail) { v->b_next = (uint32_t)at; v->b_cnt = (uint32_t)(avail < GTS_POOL_BATCH ? avail : GTS_POOL_BATCH); }
@@ -1491,16 +1590,62 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
           }
           if (v->b_cnt) { idx = v->b_next; v->b_next = idx + 1u; v->b_cnt = v->b_cnt - 1u; }
         }
+        const int r = idx != GTS_NONE ? 0 : (may_front && !(v->f_done && v->f_next == v->f_end)) ? 1 : 2;
+        pool_unlock(ctl);
+        return r;
+      };
+      if (cold_mode) {
+        /* in this order: the workgroup's share of the seeded components (the
+           largest of the launch: dealt round-robin, so that every workgroup's LDS
+           starts with one of them), what the fast kernel has handed over, and --
+           rather than idle -- small components from the back of the sorted list */
+        const uint32_t nseed = (uint32_t)A.cold[GTS_COLD_NSEED];
+        for (uint32_t spins = 0;; ++spins) {
+          unsigned long long ent = 0;
+          if (pool_lock(ctl, pstat, wait_limit)) {
+            volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
+            const uint32_t s = blockIdx.x + v->seed_round * gridDim.x;
+            if (s < nseed) { v->seed_round = v->seed_round + 1u; ent = A.cold_list[s]; }
+            pool_unlock(ctl);
+          } else break;
+          if (!ent) {
+            const unsigned long long h = __hip_atomic_load(&A.cold[GTS_COLD_HEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t = __hip_atomic_load(&A.cold[GTS_COLD_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (h < t) {
+              if (atomicCAS(&A.cold[GTS_COLD_HEAD], h, h + 1ull) != h) continue;
+              /* the entry is stored right after the tail moved: a few polls at most */
+              for (uint32_t k = 0; !ent; ++k) {
+                ent = __hip_atomic_load(&A.cold_list[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!ent && (k & 255u) == 255u && GtsWave64::clock() - tc0 >= wait_limit) break;
+              }
+              if (!ent) { atomicAdd(pstat + 7, 1ull); break; }
+            }
+          }
+          if (ent) { comp = (uint32_t)ent - 1u; need = (uint32_t)(ent >> 32); idx = 0; break; }
+          const int r = claim_sorted(false);
+          if (r == 0) { need = ~A.order_key[first + idx]; comp = A.order[first + idx]; break; }
+          if (r == 3) break;
+          /* nothing anywhere: done when every producer has left and the list is empty */
+          if (atomicAdd(&A.cold[GTS_COLD_DONE], 0ull) >= A.cold[GTS_COLD_PRODUCERS] &&
+              atomicAdd(&A.cold[GTS_COLD_TAIL], 0ull) <= atomicAdd(&A.cold[GTS_COLD_HEAD], 0ull))
+            break;
+          if ((spins & 63u) == 63u && GtsWave64::clock() - tc0 >= wait_limit) { atomicAdd(pstat + 7, 1ull); break; }
+          __builtin_amdgcn_s_sleep(32);
+        }
+      } else
+      for (uint32_t spins = 0;;) {
+        const int r = claim_sorted(true);
+        if (r != 1) break;
         /* nothing for this wavefront now, but the front (held by the one that
            waits for pages) has: look again later */
-        more = idx == GTS_NONE && !(v->f_done && v->f_next == v->f_end);
-        pool_unlock(ctl);
-        if (!more) break;
         if ((spins++ & 63u) == 0 && GtsWave64::clock() - tc0 >= wait_limit) { atomicAdd(pstat + 7, 1ull); break; }
         __builtin_amdgcn_s_sleep(16);
       }
       if (idx != GTS_NONE) {
-        need = ~order_key[first + idx];   /* the sort key: one load instead of three dependent ones */
+        if (!cold_mode) {
+          need = ~A.order_key[first + idx];   /* the sort key: one load instead of three dependent ones */
+          comp = A.order[first + idx];
+        }
         npages = (need + GTS_POOL_PAGE - 1u) / GTS_POOL_PAGE;
         bool waiting = false;
         const uint64_t tw0 = GtsWave64::clock();
@@ -1510,19 +1655,31 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
              workgroup run into their own bounds: the launch ends */
           if (!pool_lock(ctl, pstat, wait_limit)) { idx = GTS_NONE; break; }
           volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
-          const uint32_t floor = front ? 0u : v->wait_pages;
           const gts_pool_bits bits = pool_bits_load(v->used);
-          pos = pool_find(bits, npages, front, floor, GTS_POOL_PAGES);
-          if (pos != GTS_NONE) {
-            pool_bits_set(ctl->used, pool_run_mask(pos, npages));
-            if (front) { v->front_busy = 0; v->wait_pages = 0; }
-          } else if (front && !waiting) {
-            v->wait_pages = npages; waiting = true;
+          if (cold_mode) {
+            /* no roles: a wavefront takes pages from above and stays clear of the
+               pages a waiting one needs; the first that finds no room becomes that
+               waiting one, takes from below, and what the others free stays free
+               for it */
+            pos = pool_find(bits, npages, waiting, waiting ? 0u : v->wait_pages, PAGES);
+            if (pos != GTS_NONE) {
+              pool_bits_set(ctl->used, pool_run_mask(pos, npages));
+              if (waiting) v->wait_pages = 0;
+            } else if (!waiting && v->wait_pages == 0) { v->wait_pages = npages; waiting = true; }
+          } else {
+            const uint32_t floor = front ? 0u : v->wait_pages;
+            pos = pool_find(bits, npages, front, floor, PAGES);
+            if (pos != GTS_NONE) {
+              pool_bits_set(ctl->used, pool_run_mask(pos, npages));
+              if (front) { v->front_busy = 0; v->wait_pages = 0; }
+            } else if (front && !waiting) {
+              v->wait_pages = npages; waiting = true;
+            }
           }
           if (pos == GTS_NONE && (spins++ & 63u) == 0 && GtsWave64::clock() - tw0 >= wait_limit) {
             /* give up: the component is not run, the host sees the count */
             atomicAdd(pstat + 8, 1ull);
-            if (front) { v->front_busy = 0; v->wait_pages = 0; }
+            if (cold_mode ? waiting : front) { v->front_busy = 0; v->wait_pages = 0; }
             pool_unlock(ctl);
             idx = GTS_NONE;
             break;
@@ -1531,35 +1688,53 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
           if (pos != GTS_NONE) break;
           __builtin_amdgcn_s_sleep(8);
         }
-        t_wait += GtsWave64::clock() - tw0;
+        atomicAdd(&ctl->t_wait, (unsigned long long)(GtsWave64::clock() - tw0));
       }
     }
     idx = GtsWave64::uni(idx);
     if (idx == GTS_NONE) break;
     pos = GtsWave64::uni(pos); npages = GtsWave64::uni(npages); need = GtsWave64::uni(need);
+    const uint32_t c = GtsWave64::uni(comp);
     /* the components of a workgroup are neighbours in LDS: a word at the end of
        the last page (when the footprint leaves room) shows a program that wrote
        past its pages' arrays */
     volatile uint32_t *canary = need + 16u <= npages * GTS_POOL_PAGE
                                     ? (volatile uint32_t *)(smem + (pos + npages) * GTS_POOL_PAGE - 4u) : nullptr;
-    if (poison >= 0) {
+    if (A.poison >= 0) {
       /* test aid: the pages hold this byte instead of what the last component
          left there -- a program that reads scratch it has not written shows */
       uint32_t *pw = (uint32_t *)(smem + pos * GTS_POOL_PAGE);
-      const uint32_t word = (uint32_t)(poison & 0xFF) * 0x01010101u;
+      const uint32_t word = (uint32_t)(A.poison & 0xFF) * 0x01010101u;
       for (uint32_t i = lane; i < npages * (GTS_POOL_PAGE / 4u); i += GTS_WAVE) pw[i] = word;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (lane == 0 && canary) *canary = 0x5CAFF01Du;
     {
       const uint64_t tr0 = GtsWave64::clock();
-      const uint32_t c = order[first + idx];
       GtsCompMemT<true> M;
       /* what the last page has left behind the footprint: more walk slots */
       stage_component(C, c, smem + pos * GTS_POOL_PAGE, M, false, npages * GTS_POOL_PAGE - (canary ? 16u : 0u));
       GtsComponent<GtsWave64, true> prog(C, M, c);
-      prog.run(mode);
-      t_run += GtsWave64::clock() - tr0;
+      if constexpr (FAST) {
+        const uint64_t cb = (uint64_t)M.ne * 19ull + (uint64_t)M.nv * 18ull;   /* as k_comp_lds_keys counts them */
+        if (prog.run_fast(A.mode)) {
+          if (lane == 0) {
+            atomicAdd(&ctl->n_done, prog.clean ? 0x100000001ull : 1ull);   /* finished | clean << 32 */
+            atomicAdd(&ctl->n_walks, (unsigned long long)prog.nfast);
+            atomicAdd(&ctl->b_done_bytes, (unsigned long long)cb);
+          }
+        } else {
+          /* not for this program (nothing has left LDS): to the cold list */
+          if (lane == 0) {
+            atomicAdd(&ctl->n_cold, 1ull); atomicAdd(&ctl->b_cold_bytes, (unsigned long long)cb);
+            const unsigned long long at = atomicAdd(&A.cold[GTS_COLD_TAIL], 1ull);
+            __hip_atomic_store(&A.cold_list[at], (unsigned long long)need << 32 | (unsigned long long)(c + 1u),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      } else
+        prog.run(A.mode);
+      if (lane == 0) atomicAdd(&ctl->t_run, (unsigned long long)(GtsWave64::clock() - tr0));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane == 0) {
@@ -1568,12 +1743,59 @@ k_components_pool(GtsCompView C, const uint32_t *order, const uint32_t *order_ke
       pool_bits_clear(ctl->used, pool_run_mask(pos, npages));
     }
   }
+  ctl = pool_ctl_opaque(ctl0);
   if (lane == 0) {
     const uint64_t t_end = GtsWave64::clock();
-    atomicAdd(pstat + 0, t_run); atomicAdd(pstat + 1, t_wait); atomicAdd(pstat + 2, t_end - t_begin);
+    const uint64_t t_begin = ctl->t_begin[threadIdx.x / GTS_WAVE];
+    atomicAdd(&ctl->t_life, (unsigned long long)(t_end - t_begin));
     atomicMin(pstat + 5, t_begin);
     atomicMin(pstat + 3, t_end); atomicMax(pstat + 4, t_end);
+    /* (its entries of the cold list are complete before the count below moves) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (atomicAdd(&ctl->exited, 1u) + 1u == blockDim.x / GTS_WAVE) {
+      /* the workgroup's last wavefront: its sums, and -- fast kernel -- the word
+         that tells the cold workgroups that this producer has left */
+      volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
+      atomicAdd(pstat + 0, v->t_run); atomicAdd(pstat + 1, v->t_wait); atomicAdd(pstat + 2, v->t_life);
+      if constexpr (FAST) {
+        if (v->n_done) { atomicAdd(pstat + 10, v->n_done); atomicAdd(pstat + 11, v->n_walks); atomicAdd(pstat + 13, v->b_done_bytes); }
+        if (v->n_cold) { atomicAdd(pstat + 12, v->n_cold); atomicAdd(pstat + 14, v->b_cold_bytes); }
+        if (A.cold) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          atomicAdd(&A.cold[GTS_COLD_DONE], 1ull);
+        }
+      }
+    }
   }
+}
+
+__global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
+k_components_pool(GtsCompView C, GtsPoolArgs A)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ GtsPoolCtl ctl_s;
+  pool_body<false, GTS_POOL_PAGES>(C, A, smem, &ctl_s);
+}
+/* two workgroups per CU (GTS_FAST_BYTES of dynamic LDS each) of WAVES wavefronts:
+   the register budget follows from the launch bounds (2 x WAVES / 4 wavefronts
+   per SIMD: 80 registers a lane for 12, 72 for 14, 64 for 16) */
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * GTS_WAVE, (2 * WAVES + 3) / 4)
+k_components_fast(GtsCompView C, GtsPoolArgs A)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ GtsPoolCtl ctl_s;
+  pool_body<true, GTS_FAST_PAGES>(C, A, smem, &ctl_s);
+}
+/* the same program on one workgroup per CU with the whole pool (the launch is
+   bound by LDS x time: one pool packs better than two halves) */
+__global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
+k_components_fast1(GtsCompView C, GtsPoolArgs A)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ GtsPoolCtl ctl_s;
+  pool_body<true, GTS_POOL_PAGES>(C, A, smem, &ctl_s);
 }
 
 /* one deferred walk per workgroup (gts_component.hpp, try_defer / walk_task);
@@ -1660,7 +1882,8 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
                                 const unsigned long long *comp_len,
                                 uint8_t *comp_klass, const uint32_t *klass, uint32_t nklass,
                                 uint32_t *klass_count, unsigned long long *klass_bytes,
-                                uint32_t *klass_slots, uint32_t big_nv, uint32_t big_slots)
+                                uint32_t *klass_slots, uint32_t big_nv, uint32_t big_slots,
+                                uint32_t huge_nv, uint32_t huge_slots, uint32_t fast_bytes)
 {
   /* counters are summed per workgroup in LDS first: seven global counters hit by
      every component serialise */
@@ -1673,7 +1896,12 @@ __global__ void k_comp_lds_keys(const uint32_t *comp_off, const uint32_t *coff,
     const uint32_t s0 = comp_off[c], s1 = comp_off[c + 1];
     const uint32_t cnv = s1 - s0, cne = coff[s1] - coff[s0];
     /* footprint, and room for walk slots from big_nv contigs on (gts_comp_lds_want) */
-    uint32_t need = gts_comp_lds_want(cnv, cne, big_nv, big_slots, GTS_POOL_BYTES - 16u, comp_d32[c] != 0);
+    uint32_t need = gts_comp_lds_want(cnv, cne, big_nv, big_slots, GTS_POOL_BYTES - 16u, comp_d32[c] != 0,
+                                      huge_nv, huge_slots);
+    /* k_components_fast on half pools: a component whose footprint fits one asks
+       for the slots that fit it too (the others run on the cold workgroups' pools) */
+    if (fast_bytes && need > fast_bytes - 16u && gts_comp_lds_bytes(cnv, cne, comp_d32[c] != 0) <= fast_bytes - 16u)
+      need = gts_comp_lds_want(cnv, cne, big_nv, big_slots, fast_bytes - 16u, comp_d32[c] != 0, huge_nv, huge_slots);
     /* not representable in the packed LDS layout: run from global memory */
     if (comp_wide[c] || cnv >= 4096u || cne > GTS_LDS_MAX_INDEX || comp_len[c] >= (1ull << 32))
       need = 0x7FFFFFFFu;
@@ -1856,7 +2084,10 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
   if (!rc && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
   const void *big_lds[] = {(const void *)k_walk_tasks_mixed, (const void *)k_walk_tasks,
                            (const void *)k_components_lds,
-                           (const void *)k_components_pool, (const void *)k_components_team};
+                           (const void *)k_components_pool, (const void *)k_components_fast<12>,
+                           (const void *)k_components_fast<14>, (const void *)k_components_fast<16>,
+                           (const void *)k_components_fast1,
+                           (const void *)k_components_team};
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
@@ -1919,6 +2150,8 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "lds_int16_distances")) e->lds_int16_distances = value != 0;
   else if (!strcmp(name, "batch_big_contigs") && value >= 0) e->batch_big_contigs = value;
   else if (!strcmp(name, "batch_big_slots") && value >= 2 && value <= GTS_WALK_SLOTS_MAX) e->batch_big_slots = value;
+  else if (!strcmp(name, "batch_huge_contigs") && value >= 0) e->batch_huge_contigs = value;
+  else if (!strcmp(name, "batch_huge_slots") && value >= 2 && value <= GTS_WALK_SLOTS_MAX) e->batch_huge_slots = value;
   else if (!strcmp(name, "defer_min_contigs") && value >= 0) e->defer_min_contigs = value;
   else if (!strcmp(name, "defer_min_work") && value >= 0) e->defer_min_work = value;
   else if (!strcmp(name, "defer_unclean_work") && value >= 0) e->defer_unclean_work = value;
@@ -1929,6 +2162,10 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "lds_poison") && value >= -1 && value <= 255) e->lds_poison = value;
   else if (!strcmp(name, "gather_unroll") && value >= 1) e->gather_unroll = value;
   else if (!strcmp(name, "pool_fill_kb") && value >= 0) e->pool_fill_kb = value;
+  else if (!strcmp(name, "fast_components")) e->fast_components = value != 0;
+  else if (!strcmp(name, "fast_split")) e->fast_split = value != 0;
+  else if (!strcmp(name, "fast_waves") && value >= 1 && value <= GTS_FAST_WAVES) e->fast_waves = value;
+  else if (!strcmp(name, "cold_cus") && value >= 1 && value <= 255) e->cold_cus = value;
   else if (!strcmp(name, "pool_wait_limit_us") && value >= 0) e->pool_wait_limit_us = value;
   else if (!strcmp(name, "class_streams") && value >= 1 && value <= GTS_NSTREAMS) e->class_streams = value;
   else if (!strcmp(name, "mixed_task_limit") && value >= 0) e->mixed_task_limit = value;
@@ -2613,7 +2850,7 @@ static int run_components(GtsgEngine *e, int mode)
                        (size_t)n + m + (16u << 20);
     /* upper bounds for phase B: slots <= n, compact edges <= m */
     const size_t wsB = (size_t)n * (4 * 16 + 8 + 2 + 4 + 8 + 64 + 64 + 8 + 16 + 48) + (size_t)path_entries * 4 + (size_t)n * 32 + (size_t)m * (4 * 3 + 8 + 2) +
-                       (size_t)pool_entries * 12 + (size_t)n * 24 + (16u << 20);
+                       (size_t)pool_entries * 12 + (size_t)n * 32 + (16u << 20);
     if (!e->pool || e->pool_cap < wsA + wsB) {
       if ((rc = pool_reserve(e, wsA + wsB))) return rc;
     } else
@@ -2729,6 +2966,8 @@ static int run_components(GtsgEngine *e, int mode)
     LAUNCH("fill", k_fill<float>, nblk(nslots), GTS_BLOCK, s_distmap, GTS_DIST_UNSET,
            (uint64_t)nslots);
     /* components by decreasing LDS footprint; size classes of the LDS launches */
+    const bool use_fast = e->fast_components && e->pool_components && e->lds_components && e->fast_walks &&
+                          e->batch_walks && e->n_cus > (int)e->cold_cus && e->cold_cus >= 1;
     const uint32_t *klass_h = gts_klass_bytes;
     const uint32_t nklass = GTS_NKLASS;
     uint32_t *klass_d = e->d_scalars + GTS_S_KSIZE, *klass_count = e->d_scalars + GTS_S_KCOUNT;
@@ -2739,7 +2978,8 @@ static int run_components(GtsgEngine *e, int mode)
            comp_len, comp_klass, klass_d, (uint32_t)(e->lds_components ? nklass : 0), klass_count,
            (unsigned long long *)(e->d_scalars + GTS_S_KBYTES), e->d_scalars + GTS_S_KSLOTS,
            (uint32_t)(e->batch_walks && mode == GTS_MODE_MAKESCAFFOLD ? e->batch_big_contigs : 0),
-           (uint32_t)e->batch_big_slots);
+           (uint32_t)e->batch_big_slots, (uint32_t)e->batch_huge_contigs, (uint32_t)e->batch_huge_slots,
+           (uint32_t)(use_fast && e->fast_split ? GTS_FAST_BYTES : 0u));
     LAUNCH("comp_lds_keys", k_task_queue_bases, 1, 1, e->d_scalars + GTS_S_KSLOTS, e->d_scalars + GTS_S_TQBASE);
     const uint32_t *order, *order_key;   /* order_key[i] = ~footprint of component order[i] */
     {
@@ -2763,7 +3003,10 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemsetAsync(e->d_scalars + 12, 0, 16, e->st));
     LAUNCH("comp_max_size", k_max_u32_diff, nblk(ncomp), GTS_BLOCK, comp_off, ncomp,
            e->d_scalars + 14);
-    bool pool_ran = false;
+    bool pool_ran = false, fast_ran = false;
+    /* an entry per component and one per ticket a cold wavefront can hold beyond them */
+    const size_t cold_entries = (size_t)ncomp + 1 + 256u * GTS_POOL_WAVES;
+    PALLOC(cold_list, unsigned long long, cold_entries);
     GtsCompView C;
     C.G = G; C.cmap = cmap; C.ncomp = ncomp; C.comp_off = comp_off; C.slot_v = slot_v;
     C.cseq = cseq; C.coff = coff; C.cstart = cstart; C.cend = cend; C.cdist = cdist;
@@ -2880,15 +3123,69 @@ static int run_components(GtsgEngine *e, int mode)
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
         const uint32_t pw = (uint32_t)e->pool_waves;
-        k_components_pool<<<e->n_cus, pw * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, order, order_key, first, pooled, mode,
-                                                                          cursor, pstat, nbig, (int)e->lds_poison,
-                                                                          (uint64_t)e->pool_wait_limit_us * 100ull, g0);
+        GtsPoolArgs PA;
+        PA.order = order; PA.order_key = order_key; PA.first = first; PA.count = pooled; PA.mode = mode;
+        PA.cursor = cursor; PA.pstat = pstat; PA.nbig = nbig; PA.g0 = g0; PA.poison = (int)e->lds_poison;
+        PA.wait_limit = (uint64_t)e->pool_wait_limit_us * 100ull; PA.cold = nullptr; PA.cold_list = nullptr;
+        /* the clean program on two workgroups per CU, the full program next to it on
+           `cold_cus` CUs for what the clean one hands over (k_components_fast) */
+        fast_ran = use_fast;
+        if (fast_ran) {
+          /* the fast program writes a component's statistics for the detailed
+             profile only; its totals come from its own counters */
+          HIPCHK(hipMemsetAsync(stat_fast, 0, (size_t)ncomp * 4, ss));
+          HIPCHK(hipMemsetAsync(stat_slow, 0, (size_t)ncomp * 4, ss));
+          HIPCHK(hipMemsetAsync(stat_clean, 0, (size_t)ncomp * 4, ss));
+          HIPCHK(hipMemsetAsync(stat_ncc, 0, (size_t)ncomp * 4, ss));
+          HIPCHK(hipMemsetAsync(tstat, 0, (size_t)ncomp * 40, ss));
+          hipStream_t cs = e->side[1];
+          const uint32_t cold_wgs = (uint32_t)e->cold_cus;
+          const uint32_t fast_wgs = (e->fast_split ? 2u : 1u) * (uint32_t)(e->n_cus - (int)e->cold_cus);
+          const uint32_t fast_bytes = e->fast_split ? GTS_FAST_BYTES : GTS_POOL_BYTES;
+          unsigned long long *cold = (unsigned long long *)(e->d_scalars + GTS_S_COLD);
+          unsigned long long *fstat = (unsigned long long *)(e->d_scalars + GTS_S_FASTSTAT);
+          HIPCHK(hipMemsetAsync(cold_list, 0, cold_entries * 8, ss));
+          HIPCHK(hipMemsetAsync(fstat, 0, 15 * 8, ss));
+          HIPCHK(hipMemsetAsync(fstat + 3, 0xFF, 8, ss));
+          HIPCHK(hipMemsetAsync(fstat + 5, 0xFF, 8, ss));
+          k_cold_seed<<<1, GTS_BLOCK, 0, ss>>>(order, order_key, first, pooled, cold, cold_list, fast_wgs, fast_bytes);
+          HIPCHK(hipEventRecord(e->ev_join[1], ss));
+          HIPCHK(hipStreamWaitEvent(cs, e->ev_join[1], 0));
+          /* the full program first: its workgroups take their CUs (a CU's whole LDS
+             each) before the fast ones fill the others */
+          GtsPoolArgs CA = PA;
+          CA.cold = cold; CA.cold_list = cold_list;
+          hipEvent_t _c = nullptr, _d = nullptr;
+          if (e->profile) { _c = get_event(e); _d = get_event(e); hipEventRecord(_c, cs); }
+          k_components_pool<<<cold_wgs, pw * GTS_WAVE, GTS_POOL_BYTES, cs>>>(C, CA);
+          if (e->profile) { hipEventRecord(_d, cs);
+                            e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_cold"
+                                                                                : "components_removecycles_cold",
+                                                  _c, _d}); }
+          HIPCHK(hipEventRecord(e->ev_join[2], cs));
+          GtsPoolArgs FA = CA;
+          FA.pstat = fstat;
+          if (e->profile) hipEventRecord(_a, ss);
+          if (!e->fast_split) k_components_fast1<<<fast_wgs, (uint32_t)e->pool_waves * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, FA);
+          else if (e->fast_waves >= 16) k_components_fast<16><<<fast_wgs, 16 * GTS_WAVE, GTS_FAST_BYTES, ss>>>(C, FA);
+          else if (e->fast_waves >= 14) k_components_fast<14><<<fast_wgs, 14 * GTS_WAVE, GTS_FAST_BYTES, ss>>>(C, FA);
+          else k_components_fast<12><<<fast_wgs, (uint32_t)e->fast_waves * GTS_WAVE, GTS_FAST_BYTES, ss>>>(C, FA);
+          if (e->profile) { hipEventRecord(_b, ss);
+                            e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_fast"
+                                                                                : "components_removecycles_fast",
+                                                  _a, _b}); }
+          HIPCHK(hipEventRecord(e->ev_join[0], ss));
+          HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[0], 0));
+          HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[2], 0));
+        } else {
+        k_components_pool<<<e->n_cus, pw * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, PA);
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_pool"
                                                                               : "components_removecycles_pool",
                                                 _a, _b}); }
         HIPCHK(hipEventRecord(e->ev_join[0], ss));
         HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[0], 0));
+        }
         first += pooled;
       }
       /* pool_components = 0: a launch per size class.  The classes are
@@ -3039,6 +3336,8 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 64, hipMemcpyDeviceToHost, e->st));
     uint64_t pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 80, hipMemcpyDeviceToHost, e->st));
+    uint64_t fst[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (fast_ran) HIPCHK(hipMemcpyAsync(fst, e->d_scalars + GTS_S_FASTSTAT, 120, hipMemcpyDeviceToHost, e->st));
     uint64_t tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (team_ran) HIPCHK(hipMemcpyAsync(tst, e->d_scalars + GTS_S_TEAMSTAT, 64, hipMemcpyDeviceToHost, e->st));
     uint32_t res[4] = {0, 0, 0, 0};
@@ -3046,6 +3345,7 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(res, e->d_scalars + 12, 16, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 32, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
+    for (int k = 6; k < 10; ++k) pst[k] += fst[k];   /* either kernel's waits and overruns */
     if (pst[6] | pst[7] | pst[8] | pst[9]) {
       /* some components have written their marks, others have not run: the graph
          goes back to its state before the call (as for GTSG_EWALK), the caller
@@ -3083,6 +3383,22 @@ static int run_components(GtsgEngine *e, int mode)
       e->stats["pool_us_sum_wave_life"] = (int64_t)(pst[2] / 100);
       e->stats["pool_us_first_exit"] = (int64_t)((pst[3] - pst[5]) / 100);
       e->stats["pool_us_last_exit"] = (int64_t)((pst[4] - pst[5]) / 100);
+    }
+    e->stats["fast_kernel"] = fast_ran ? 1 : 0;
+    if (fast_ran) {
+      e->stats["fast_us_sum_run"] = (int64_t)(fst[0] / 100);
+      e->stats["fast_us_sum_wait_pages"] = (int64_t)(fst[1] / 100);
+      e->stats["fast_us_sum_wave_life"] = (int64_t)(fst[2] / 100);
+      e->stats["fast_us_first_exit"] = (int64_t)((fst[3] - fst[5]) / 100);
+      e->stats["fast_us_last_exit"] = (int64_t)((fst[4] - fst[5]) / 100);
+      e->stats["fast_components_done"] = (int64_t)(fst[10] & 0xFFFFFFFFull);
+      e->stats["fast_components_handed_over"] = (int64_t)fst[12];
+      e->stats["bytes_fast_finished"] = (int64_t)fst[13];
+      e->stats["bytes_fast_handed_over"] = (int64_t)fst[14];
+      /* the cold workgroups start first; their clocks against the fast kernel's first start */
+      e->stats["cold_us_last_exit_after_fast_start"] = (int64_t)(((int64_t)pst[4] - (int64_t)fst[5]) / 100);
+      e->stats["fast_wavefronts"] = (int64_t)(e->n_cus - (int)e->cold_cus) *
+                                    (e->fast_split ? 2 * (e->fast_waves >= 16 ? 16 : e->fast_waves >= 14 ? 14 : e->fast_waves) : e->pool_waves);
     }
     {
       static const char *nm[4] = {"removecycles", "makescaffold_other", "walks_fast", "walks_reference"};
@@ -3195,6 +3511,9 @@ static int run_components(GtsgEngine *e, int mode)
                                   "why_cycle", "why_inexact_length_tie"};
       for (int k = 0; k < 8; ++k) e->stats[wn[k]] = (int64_t)why[k];
     }
+    /* (the fast program counts in its own words unless the detailed profile made
+       it write the per-component tables the sums above are taken from) */
+    if (fast_ran && e->profile < 2) { wstat[0] += fst[11]; wstat[2] += fst[10] >> 32; }
     e->stats["fast_walks"] = (int64_t)wstat[0];
     e->stats["slow_walks"] = (int64_t)wstat[1];
     e->stats["clean_components"] = (int64_t)wstat[2];
