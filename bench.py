@@ -454,7 +454,7 @@ def main():
                               "pool_us_first_exit", "pool_us_last_exit")},
                        fast={k: eng.stat(k) for k in
                              ("fast_kernel", "fast_wavefronts", "fast_components_done", "fast_components_handed_over",
-                              "fast_us_sum_run", "fast_us_sum_wait_pages", "fast_us_sum_wave_life",
+                              "fast_us_sum_run", "fast_us_sum_wait_pages", "fast_us_sum_claim", "fast_us_sum_wave_life",
                               "fast_us_first_exit", "fast_us_last_exit", "cold_us_last_exit_after_fast_start")},
                        wave_us_per_lds_class={"%dk" % eng.stat("lds_class%d_kb" % i):
                                               dict(wave_us=eng.stat("lds_class%d_wave_us" % i),

@@ -1924,6 +1924,24 @@ struct GtsComponent {
      then makes the walks of this cc one by one (create_walk), which resolves
      them (pushed_after) or runs the reference's search.
      Slots must be clean (labels unset) on entry; clear_walk_slots() after. */
+  /* pushed_after() on a walk slot, for the lanes that met a tie (round 4: a tie
+     used to end the batch, and the cc's walks were made one by one -- 7 of the
+     8.3 ms of a 716-contig component).  The slot keeps no depths: the generation
+     of a vertex is the length of its parent chain, so the two chains are climbed
+     in lock step -- the one that reaches the start first is the shallower --,
+     then, at equal depth, again up to the common parent (as pushed_after).  Only
+     valid while the labels are exact (the caller asks). */
+  template <class P>
+  static GTS_HD bool pushed_after_slot(P par, P emap, uint32_t a, uint32_t b, uint32_t start)
+  {
+    uint32_t xa = a, xb = b;
+    while (xa != start && xb != start) { xa = par[xa]; xb = par[xb]; }
+    if (xa != start || xb != start) return xb == start;
+    uint32_t ea = emap[a], eb = emap[b], pa = par[a], pb = par[b];
+    while (pa != pb) { ea = emap[pa]; eb = emap[pb]; pa = par[pa]; pb = par[pb]; }
+    return ea > eb;
+  }
+
   template <uint32_t L, bool D16>
   GTS_HD void walks_clean_batch(uint32_t j0, uint32_t nb, uint32_t &r_len, uint32_t &r_t, bool &r_bad)
   {
@@ -1967,6 +1985,7 @@ struct GtsComponent {
     int32_t pos = (int32_t)M.tpos[start];        /* the sweep has handled everything before pos */
     uint32_t pending = active ? 1u : 0u;
     uint32_t best_len = 0, best_t = GTS_NONE;
+    uint32_t inex = 0;       /* this lane has seen a label outside the range where floats are exact */
     W::fence();
     while (W::ballot(pending != 0)) {
       bool on = pending != 0;
@@ -1995,7 +2014,7 @@ struct GtsComponent {
       const int32_t ndu = (int32_t)dist[u];                 /* the integer the reference pushes with the node */
       const uint32_t plu = plen[u];
       uint32_t mine = 0;       /* vertices this lane labelled first */
-      uint32_t seen = 0;       /* 1: live sense edge, 2: live antisense edge, 4: tie */
+      uint32_t seen = 0;       /* 1: live sense edge, 2: live antisense edge, 4: a tie that has no closed form */
       for (uint32_t cur = ub; W::ballot(on && cur < ue); cur += L) {
         const uint32_t ce = cur + a;
         const bool in = on && ce < ue;
@@ -2010,6 +2029,7 @@ struct GtsComponent {
         const bool arc = live && sense == du;
         const bool unset = old == GTS_DIST_UNSET;
         const bool imp = arc && (unset || old > cand);
+        const bool tie = arc && !imp && old == cand;
         if (imp) {
           dist[v] = cand;
           emap[v] = (idx_t)ce;
@@ -2018,19 +2038,42 @@ struct GtsComponent {
         }
         mine += imp && unset ? 1u : 0u;
         seen |= live ? (sense ? 1u : 2u) : 0u;
-        seen |= arc && !imp && old == cand ? 4u : 0u;
+        inex |= arc && !(cand > -16777216.0f && cand < 16777216.0f) ? 1u : 0u;
         W::fence();
+        if (W::ballot(tie)) {
+          /* two in-arcs attain the label of v: edgemap keeps the one whose value
+             arrived first (create_walk_clean) */
+          const uint32_t gi = W::group8_or32(inex);
+          if (tie) {
+            if (gi) seen |= 4u;
+            else if (pushed_after_slot(par, emap, (uint32_t)par[v], u, start)) {
+              emap[v] = (idx_t)ce;
+              par[v] = (idx_t)u;
+              plen[v] = plu + sv;
+            }
+          }
+          W::fence();
+        }
       }
       mine = W::group8_add32(mine);
       seen = W::group8_or32(seen);
+      bool tie_t = false;
       if (on) {
         pending += mine - 1u;
         /* reached terminal (algorithms.c:694): candidate end of the walk */
         if (u != start && (seen & 3u) != 3u) {
           if (plu > best_len) { best_len = plu; best_t = u; }
-          else if (plu == best_len && best_t != GTS_NONE) bad = 1u;
+          else if (plu == best_len && best_t != GTS_NONE) tie_t = true;
         }
         bad |= seen >> 2;
+      }
+      if (W::ballot(tie_t)) {
+        /* two terminals with the longest walk: the reference keeps the one popped last */
+        const uint32_t gi = W::group8_or32(inex);
+        if (tie_t) {
+          if (gi) bad = 1u;
+          else if (pushed_after_slot(par, emap, u, best_t, start)) best_t = u;
+        }
       }
       if (bad) pending = 0;
     }
@@ -2086,6 +2129,7 @@ struct GtsComponent {
     if (active && a == 0) { dist[start] = 0.0f; plen[start] = (uint32_t)M.cseq[start]; }
     uint64_t pend = active ? 1ull << (uint32_t)M.tpos[start] : 0ull;
     uint32_t best_len = 0, best_t = GTS_NONE;
+    uint32_t inex = 0;
     W::fence();
     while (W::ballot(pend != 0)) {
       const bool on = pend != 0;
@@ -2113,6 +2157,7 @@ struct GtsComponent {
         const bool arc = live && sense == du;
         const bool unset = old == GTS_DIST_UNSET;
         const bool imp = arc && (unset || old > cand);
+        const bool tie = arc && !imp && old == cand;
         if (imp) {
           dist[v] = cand;
           emap[v] = (idx_t)ce;
@@ -2121,22 +2166,257 @@ struct GtsComponent {
         }
         if (imp && unset) mine |= 1ull << tv;
         seen |= live ? (sense ? 1u : 2u) : 0u;
-        seen |= arc && !imp && old == cand ? 4u : 0u;
+        inex |= arc && !(cand > -16777216.0f && cand < 16777216.0f) ? 1u : 0u;
         W::fence();
+        if (W::ballot(tie)) {      /* (as walks_clean_batch) */
+          const uint32_t gi = W::group8_or32(inex);
+          if (tie) {
+            if (gi) seen |= 4u;
+            else if (pushed_after_slot(par, emap, (uint32_t)par[v], u, start)) {
+              emap[v] = (idx_t)ce;
+              par[v] = (idx_t)u;
+              plen[v] = plu + sv;
+            }
+          }
+          W::fence();
+        }
       }
       pend |= W::group8_or(mine);
       seen = W::group8_or32(seen);
+      bool tie_t = false;
       if (on) {
         /* reached terminal (algorithms.c:694): candidate end of the walk */
         if (u != start && (seen & 3u) != 3u) {
           if (plu > best_len) { best_len = plu; best_t = u; }
-          else if (plu == best_len && best_t != GTS_NONE) bad = 1u;
+          else if (plu == best_len && best_t != GTS_NONE) tie_t = true;
         }
         bad |= seen >> 2;
+      }
+      if (W::ballot(tie_t)) {
+        const uint32_t gi = W::group8_or32(inex);
+        if (tie_t) {
+          if (gi) bad = 1u;
+          else if (pushed_after_slot(par, emap, u, best_t, start)) best_t = u;
+        }
       }
       if (bad) pend = 0;
     }
     r_len = best_len; r_t = best_t; r_bad = bad != 0;
+  }
+
+  /* ---- the walks of one cc of a component that is NOT clean, side by side (round 4) ----
+     Without a topological order of the whole component every walk needs its own:
+     create_walk_fast() collects the states reachable from the start (pass 1: strands,
+     in-degrees) and relaxes them in Kahn order (pass 2).  One by one that is ~0.2 us a
+     vertex step and walk -- the 45 walks of a 380-contig component took 8 of the
+     launch's 10.6 ms, an 80-contig one claimed late 2.2 ms.  Here a group of eight lanes
+     makes a walk, as in walks_clean_batch, with its own strands, in-degrees and queue
+     next to labels, tree lengths, edgemap and parents: a slot of 16 bytes a contig
+     (gts_uwalk_slot_bytes), as many as the component's walk scratch holds.  Anything
+     the closed form does not cover -- a clash of strands, a self arc or u-turn, a start
+     with edges in both senses, a cycle among the reachable states, an inexact tie --
+     sets `bad`; the caller then makes the walks of the cc one by one. */
+  static GTS_HD uint32_t gts_uwalk_slot_bytes(uint32_t nv)
+  {
+    const uint32_t p4 = ((nv * 4 + 15) / 16) * 16, p2 = ((nv * 2 + 15) / 16) * 16;
+    return 2 * p4 + 4 * p2;
+  }
+  template <bool D16>
+  GTS_HD void walks_fast_batch(uint32_t j0, uint32_t nb, uint32_t &r_len, uint32_t &r_t, bool &r_bad)
+  {
+    typedef typename GtsCompMemT<LDS>::idx_t idx_t;
+    constexpr uint32_t L = 8;
+    const uint32_t lane = W::lane(), g = lane / L, a = lane % L;
+    const uint32_t gsh = g * L;
+    const uint32_t below = (1u << a) - 1u;
+    const uint32_t p4 = ((nv * 4 + 15) / 16) * 16, p2 = ((nv * 2 + 15) / 16) * 16;
+    bool active = g < nb;
+    auto sbase = M.wbase + (active ? g : 0u) * (2 * p4 + 4 * p2);
+    auto dist = (GTS_P(float))sbase;
+    auto plen = (GTS_P(uint32_t))(sbase + p4);
+    auto emap = (GTS_P(idx_t))(sbase + 2 * p4);
+    auto par = (GTS_P(idx_t))(sbase + 2 * p4 + p2);
+    auto deg = (GTS_P(uint16_t))(sbase + 2 * p4 + 2 * p2);   /* in-degree | (strand + 1) << 14 */
+    auto Q = (GTS_P(idx_t))(sbase + 2 * p4 + 3 * p2);
+    const uint32_t start = active ? (uint32_t)M.term[j0 + g] : 0u;
+    const uint32_t sb0 = M.coff[start], se0 = M.coff[start + 1];
+    bool hs = false, ha = false;
+    for (uint32_t cur0 = sb0; W::ballot(active && cur0 < se0); cur0 += L) {
+      const uint32_t ce = cur0 + a;
+      const bool in = active && ce < se0;
+      const uint32_t fs = edge_bits(in ? ce : sb0);
+      const bool live = in && !bits_marked(fs);
+      const bool sense = (fs & GTS_F_SENSE) != 0;
+      const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
+      hs |= ((bs >> gsh) & 0xFFu) != 0;
+      ha |= ((ba >> gsh) & 0xFFu) != 0;
+    }
+    uint32_t bad = active && hs && ha ? 1u : 0u;
+    if (bad || !(hs || ha)) active = false;          /* (nothing reachable: empty walk) */
+    /* pass 1: the reachable states, their strands and in-degrees (create_walk_fast) */
+    uint32_t qh = 0, nr = active ? 1u : 0u;
+    if (active && a == 0) { Q[0] = (idx_t)start; deg[start] = (uint16_t)((hs ? 2u : 1u) << 14); }
+    W::fence();
+    while (W::ballot(active && qh < nr)) {
+      const bool on = active && qh < nr;
+      const uint32_t u = Q[on ? qh : 0u];
+      const bool du = ((uint32_t)deg[u] >> 14) == 2u;
+      const uint32_t ub = M.coff[u], ue = M.coff[u + 1];
+      uint32_t clash = 0;
+      for (uint32_t cur = ub; W::ballot(on && cur < ue); cur += L) {
+        const uint32_t ce = cur + a;
+        const bool in = on && ce < ue;
+        const uint32_t cec = in ? ce : ub;
+        const uint32_t fs = edge_bits(cec);
+        const uint32_t v = M.cend[cec];
+        const uint32_t dv = deg[v];
+        const bool arc = in && !bits_marked(fs) && ((fs & GTS_F_SENSE) != 0) == du;
+        const uint32_t od = gts_next_dir((uint8_t)fs) ? 2u : 1u, ov = dv >> 14;
+        clash |= arc && (v == u || v == start || gts_vertex_is_marked(M.vst[v]) || (ov != 0 && ov != od) ||
+                         (fs & GTS_F_UTURN)) ? 1u : 0u;
+        const bool fresh = arc && ov == 0;
+        const uint32_t fm = (uint32_t)(W::ballot(fresh) >> gsh) & 0xFFu;
+        if (arc) {
+          if (fresh) { deg[v] = (uint16_t)((od << 14) | 1u); Q[nr + W::popc((uint64_t)(fm & below))] = (idx_t)v; }
+          else deg[v] = (uint16_t)(dv + 1u);
+        }
+        nr += W::popc((uint64_t)fm);
+        W::fence();
+      }
+      if (W::group8_or32(clash)) { bad = 1u; active = false; }
+      if (on) ++qh;
+    }
+    /* pass 2: relaxation in Kahn order; the queue takes the place of pass 1's */
+    uint32_t qh2 = 0, nq = active ? 1u : 0u, best_len = 0, best_t = GTS_NONE, inex = 0;
+    if (active && a == 0) { Q[0] = (idx_t)start; dist[start] = 0.0f; plen[start] = (uint32_t)M.cseq[start]; }
+    W::fence();
+    while (W::ballot(active && qh2 < nq)) {
+      const bool on = active && qh2 < nq;
+      const uint32_t u = Q[on ? qh2 : 0u];
+      const bool du = ((uint32_t)deg[u] >> 14) == 2u;
+      const int32_t ndu = (int32_t)dist[u];
+      const uint32_t plu = plen[u];
+      const uint32_t ub = M.coff[u], ue = M.coff[u + 1];
+      uint32_t seen = 0;       /* 1: live sense edge, 2: live antisense edge, 4: a tie without closed form */
+      for (uint32_t cur = ub; W::ballot(on && cur < ue); cur += L) {
+        const uint32_t ce = cur + a;
+        const bool in = on && ce < ue;
+        const uint32_t cec = in ? ce : ub;
+        const uint32_t fs = edge_bits(cec);
+        const uint32_t v = M.cend[cec];
+        const float cand = (float)(ndu + dist_w<D16>(cec));
+        const float old = dist[v];
+        const uint32_t sv = (uint32_t)M.cseq[v];
+        const uint32_t dv = deg[v];
+        const bool live = in && !bits_marked(fs);
+        const bool sense = (fs & GTS_F_SENSE) != 0;
+        const bool arc = live && sense == du;
+        const bool unset = old == GTS_DIST_UNSET;
+        const bool imp = arc && (unset || old > cand);
+        const bool tie = arc && !imp && old == cand;
+        if (imp) {
+          dist[v] = cand;
+          emap[v] = (idx_t)ce;
+          par[v] = (idx_t)u;
+          plen[v] = plu + sv;
+        }
+        const bool ready = arc && ((dv - 1u) & 0x3FFFu) == 0;
+        const uint32_t rm = (uint32_t)(W::ballot(ready) >> gsh) & 0xFFu;
+        if (arc) deg[v] = (uint16_t)(dv - 1u);
+        if (ready) Q[nq + W::popc((uint64_t)(rm & below))] = (idx_t)v;
+        nq += W::popc((uint64_t)rm);
+        seen |= live ? (sense ? 1u : 2u) : 0u;
+        inex |= arc && !(cand > -16777216.0f && cand < 16777216.0f) ? 1u : 0u;
+        W::fence();
+        if (W::ballot(tie)) {      /* (as walks_clean_batch) */
+          const uint32_t gi = W::group8_or32(inex);
+          if (tie) {
+            if (gi) seen |= 4u;
+            else if (pushed_after_slot(par, emap, (uint32_t)par[v], u, start)) {
+              emap[v] = (idx_t)ce;
+              par[v] = (idx_t)u;
+              plen[v] = plu + sv;
+            }
+          }
+          W::fence();
+        }
+      }
+      seen = W::group8_or32(seen);
+      bool tie_t = false;
+      if (on) {
+        ++qh2;
+        if (u != start && (seen & 3u) != 3u) {
+          if (plu > best_len) { best_len = plu; best_t = u; }
+          else if (plu == best_len && best_t != GTS_NONE) tie_t = true;
+        }
+        bad |= seen >> 2;
+      }
+      if (W::ballot(tie_t)) {
+        const uint32_t gi = W::group8_or32(inex);
+        if (tie_t) {
+          if (gi) bad = 1u;
+          else if (pushed_after_slot(par, emap, u, best_t, start)) best_t = u;
+        }
+      }
+      if (bad) active = false;
+    }
+    /* a cycle among the reachable states (walk_cyclic's case): not here */
+    if (active && qh2 != nr) bad = 1u;
+    r_len = best_len; r_t = best_t; r_bad = bad != 0;
+  }
+
+  /* the walks of the cc [tb, te) of a component that is not clean in batches; false:
+     nothing is kept, the caller makes them one by one */
+  GTS_HD bool cc_walks_batched_unclean(uint32_t tb, uint32_t te, uint64_t &cc_len, uint32_t &cc_n,
+                                       uint32_t *best_start)
+  {
+    typedef typename GtsCompMemT<LDS>::idx_t idx_t;
+    const uint32_t lane = W::lane();
+    const uint32_t ubytes = gts_uwalk_slot_bytes(nv);
+    uint32_t per = (uint32_t)(((uint64_t)M.wslots * gts_walk_slot_bytes(nv)) / ubytes);
+    if (per > W::WIDTH / 8) per = W::WIDTH / 8;
+    if (per < 2) return false;
+    const uint32_t p4 = ((nv * 4 + 15) / 16) * 16, p2 = ((nv * 2 + 15) / 16) * 16;
+    bool ok = true;
+    const uint32_t nfast0 = nfast;
+    for (uint32_t j0 = tb; j0 < te && ok; j0 += per) {
+      if (cc_len == all_bases()) break;
+      const uint32_t nb = te - j0 < per ? te - j0 : per;
+      for (uint32_t k = 0; k < nb; ++k) {      /* labels unset, strands and in-degrees zero */
+        auto dist = (GTS_P(float))(M.wbase + k * ubytes);
+        auto deg = (GTS_P(uint16_t))(M.wbase + k * ubytes + 2 * p4 + 2 * p2);
+        for (uint32_t s = lane; s < nv; s += W::WIDTH) { dist[s] = GTS_DIST_UNSET; deg[s] = 0; }
+      }
+      W::fence();
+      uint32_t r_len, r_t;
+      bool r_bad;
+      if (LDS && M.d16) walks_fast_batch<true>(j0, nb, r_len, r_t, r_bad);
+      else walks_fast_batch<false>(j0, nb, r_len, r_t, r_bad);
+      if (W::ballot(r_bad)) { ok = false; break; }
+      uint32_t wg = GTS_NONE;
+      for (uint32_t k = 0; k < nb; ++k) {
+        const uint32_t len = W::bcast(r_len, k * 8);
+        if ((uint64_t)len > cc_len) { cc_len = len; wg = k; }
+      }
+      if (wg != GTS_NONE) {
+        auto sbase = M.wbase + wg * ubytes;
+        auto emap = (GTS_P(idx_t))(sbase + 2 * p4);
+        auto par = (GTS_P(idx_t))(sbase + 2 * p4 + p2);
+        const uint32_t start = W::uni((uint32_t)M.term[j0 + wg]);
+        uint32_t cv = W::bcast(r_t, wg * 8), n = 0;
+        while (cv != start) {
+          const uint32_t re = W::uni((uint32_t)emap[cv]);
+          M.cc_best[n++] = (idx_t)re;
+          cv = W::uni((uint32_t)par[cv]);
+        }
+        cc_n = n;
+        if (best_start) *best_start = start;
+      }
+      nfast += nb;
+    }
+    clear_walk_slots(1);   /* distmap: unset between walks */
+    if (!ok) nfast = nfast0;
+    return ok;
   }
 
   /* labels of the walk slots back to "unset" (slot 0's are distmap) */
@@ -2923,7 +3203,12 @@ struct GtsComponent {
         if (te - tb > 1) {
           uint64_t cc_len = 0;
           uint32_t cc_n = 0, cc_start = 0;
-          if (!clean || !cc_walks_batched<GTS_WALK_LANES>(tb, te, cc_len, cc_n, &cc_start)) {
+          bool batched = false;
+          if constexpr (LDS) {
+            batched = clean ? cc_walks_batched<GTS_WALK_LANES>(tb, te, cc_len, cc_n, &cc_start)
+                            : (C.batch_walks >= 2 && cc_walks_batched_unclean(tb, te, cc_len, cc_n, &cc_start));
+          }
+          if (!batched) {
             /* a tie in the batch, or a component that is not clean: the walks of
                this cc one by one (create_walk_clean / create_walk_fast: the
                reference's tie-breaks in closed form); a walk that needs the

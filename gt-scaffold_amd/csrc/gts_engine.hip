@@ -67,7 +67,7 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_S_TEAMSTAT 432 /* 8 x u64: statistics of k_components_team */
 #define GTS_S_SMALLSTAT 448 /* 4 x u64: small components by "all edges live" */
 #define GTS_S_COLD 464      /* 8 x u64: the cold list's words (GTS_COLD_*) */
-#define GTS_S_FASTSTAT 480  /* 15 x u64: statistics of k_components_fast (as GTS_S_POOLSTAT, + [10..12]) */
+#define GTS_S_FASTSTAT 480  /* 16 x u64: statistics of k_components_fast (as GTS_S_POOLSTAT, + [10..12]) */
 
 static const char *klass_event(int makescaffold, uint32_t bytes)
 {
@@ -160,7 +160,7 @@ struct GtsgEngine {
   /* clean LDS-resident components sweep the walks of a cc side by side
      (walks_clean_batch); from batch_big_contigs contigs on a component asks for
      LDS for batch_big_slots walk slots */
-  int64_t batch_walks = 1, batch_big_contigs = 64, batch_big_slots = 3;
+  int64_t batch_walks = 2, batch_big_contigs = 64, batch_big_slots = 3;
   int64_t batch_huge_contigs = 256, batch_huge_slots = 8;   /* second tier: the launch's longest programs */
   int64_t lds_int16_distances = 1;   /* packed layout: int16 distances for components whose distances all fit */
   int64_t small_masks = 1;   /* topological order of components of at most 64 contigs on bit masks (peel_small) */
@@ -1382,19 +1382,23 @@ k_components_lds(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t 
 enum { GTS_COLD_HEAD = 0, GTS_COLD_TAIL = 1, GTS_COLD_DONE = 2, GTS_COLD_PRODUCERS = 3, GTS_COLD_NSEED = 4,
        GTS_COLD_WORDS = 8 };
 struct GtsPoolCtl {
+  uint32_t used[4];        /* page bitmap (16-byte aligned: read in one piece) */
   uint32_t exited;         /* k_components_fast: wavefronts of the workgroup that have left */
   uint32_t seed_round;     /* cold mode: seeded components this workgroup has taken */
   uint32_t lock;
-  uint32_t front_busy;     /* a wavefront holds a front claim it has no pages for yet */
+  uint32_t front_busy;     /* a wavefront holds the front role: a front claim it has no pages for yet */
   uint32_t wait_pages;     /* pages that wavefront needs (0: it is not waiting) */
-  uint32_t used[4];        /* page bitmap */
-  uint32_t f_next, f_end;  /* stock of front indices [f_next, f_end) */
-  uint32_t b_next, b_cnt;  /* stock of fill indices b_next, b_next+1, ... (b_cnt of them) */
   uint32_t f_done, b_done; /* the cursor has nothing more to give */
+  uint32_t f_last_end;     /* end of the last front refill (claims among the nbig largest come one at a time) */
+  /* stock of indices: next | end << 32.  A claim is one returning 64-bit LDS add
+     (round 4: claims under the workgroup's lock -- a dozen dependent LDS round
+     trips each, twice per component -- kept the lock busy 80 % of the time and
+     cost a wavefront 11 us per component); the lock is taken to refill */
+  unsigned long long f_stock, b_stock;
   /* statistics, summed here and added to the launch's words by the workgroup's last
      wavefront (kept out of the wavefronts' registers: they would be live across
      every component program) */
-  unsigned long long t_run, t_wait, t_life;
+  unsigned long long t_run, t_wait, t_life, t_claim;
   unsigned long long n_done, n_walks, n_cold, b_done_bytes, b_cold_bytes;
   unsigned long long t_begin[GTS_POOL_WAVES];
 };
@@ -1402,8 +1406,9 @@ struct GtsPoolCtl {
 typedef unsigned __int128 gts_pool_bits;
 __device__ __forceinline__ gts_pool_bits pool_bits_load(const volatile uint32_t *used)
 {
-  return (gts_pool_bits)used[0] | (gts_pool_bits)used[1] << 32 | (gts_pool_bits)used[2] << 64 |
-         (gts_pool_bits)used[3] << 96;
+  typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+  const u32x4 w = *(const volatile u32x4 *)used;     /* first member of the control block: 16-byte aligned */
+  return (gts_pool_bits)w.x | (gts_pool_bits)w.y << 32 | (gts_pool_bits)w.z << 64 | (gts_pool_bits)w.w << 96;
 }
 /* pages are taken under the lock and given back without it: the bits of a run
    are set / cleared with LDS atomics, so a free never collides with the search
@@ -1536,11 +1541,11 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
   const uint64_t wait_limit = A.wait_limit;
   if (threadIdx.x == 0) {
     ctl->exited = 0; ctl->seed_round = 0;
-    ctl->t_run = ctl->t_wait = ctl->t_life = 0;
+    ctl->t_run = ctl->t_wait = ctl->t_life = ctl->t_claim = 0;
     ctl->n_done = ctl->n_walks = ctl->n_cold = ctl->b_done_bytes = ctl->b_cold_bytes = 0;
     ctl->lock = 0; ctl->front_busy = 0; ctl->wait_pages = 0;
     ctl->used[0] = ctl->used[1] = ctl->used[2] = ctl->used[3] = 0;
-    ctl->f_next = ctl->f_end = ctl->b_next = ctl->b_cnt = ctl->f_done = ctl->b_done = 0;
+    ctl->f_done = ctl->b_done = 0; ctl->f_last_end = 0; ctl->f_stock = 0; ctl->b_stock = 0;
   }
   __syncthreads();
   if ((threadIdx.x & (GTS_WAVE - 1u)) == 0) ctl->t_begin[threadIdx.x / GTS_WAVE] = GtsWave64::clock();
@@ -1565,34 +1570,58 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
          the front (held by the one that waits for pages) has; 2: nothing left;
          3: the lock was not to be had (this wavefront leaves) */
       auto claim_sorted = [&](bool may_front) -> int {
-        if (!pool_lock(ctl, pstat, wait_limit)) return 3;
         volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
-        front = may_front && v->front_busy == 0;
-        if (front) {
-          if (v->f_next == v->f_end && !v->f_done) {
-            const uint32_t want = v->f_end < nbig ? 1u : GTS_POOL_BATCH;
-            const unsigned long long old = atomicAdd(A.cursor, (unsigned long long)want);
-            const uint64_t h = old & 0xFFFFFFFFull;
-            const uint64_t lim = g0;                                              /* the fill cursor holds [g0, count) */
-            if (h < lim) { v->f_next = (uint32_t)h; v->f_end = (uint32_t)(h + want < lim ? h + want : lim); }
-            else v->f_done = 1;
+        /* one index off a stock, or GTS_NONE when it is empty */
+        auto pop = [&](unsigned long long *stock) -> uint32_t {
+          const unsigned long long old = atomicAdd(stock, 1ull);
+          const uint32_t next = (uint32_t)old, end = (uint32_t)(old >> 32);
+          return next < end ? next : GTS_NONE;
+        };
+        auto empty = [&](const unsigned long long *stock) -> bool {
+          const unsigned long long cur = *(volatile const unsigned long long *)stock;
+          return (uint32_t)cur >= (uint32_t)(cur >> 32);
+        };
+        /* the front role: one wavefront of the workgroup at a time, from its claim
+           until it has its pages */
+        if (may_front && !(v->f_done && empty(&ctl->f_stock)) && atomicCAS(&ctl->front_busy, 0u, 1u) == 0u) {
+          for (;;) {
+            idx = pop(&ctl->f_stock);
+            if (idx != GTS_NONE) { front = true; return 0; }
+            if (v->f_done) break;
+            if (!pool_lock(ctl, pstat, wait_limit)) { atomicExch(&ctl->front_busy, 0u); return 3; }
+            if (empty(&ctl->f_stock) && !v->f_done) {
+              const uint32_t want = v->f_last_end < nbig ? 1u : GTS_POOL_BATCH;
+              const unsigned long long old = atomicAdd(A.cursor, (unsigned long long)want);
+              const uint64_t h = old & 0xFFFFFFFFull;
+              const uint64_t lim = g0;                                              /* the fill cursor holds [g0, count) */
+              if (h < lim) {
+                const uint32_t fe = (uint32_t)(h + want < lim ? h + want : lim);
+                v->f_last_end = fe;
+                atomicExch(&ctl->f_stock, (unsigned long long)fe << 32 | (unsigned long long)h);
+              } else v->f_done = 1;
+            }
+            pool_unlock(ctl);
           }
-          if (v->f_next < v->f_end) { idx = v->f_next; v->f_next = idx + 1; v->front_busy = 1; }
-          else front = false;
+          atomicExch(&ctl->front_busy, 0u);   /* nothing left at the front */
         }
-        if (!front) {
-          if (v->b_cnt == 0 && !v->b_done) {
+        for (;;) {
+          idx = pop(&ctl->b_stock);
+          if (idx != GTS_NONE) return 0;
+          if (v->b_done) break;
+          if (!pool_lock(ctl, pstat, wait_limit)) return 3;
+          if (empty(&ctl->b_stock) && !v->b_done) {
             const unsigned long long old = atomicAdd(A.cursor, (unsigned long long)GTS_POOL_BATCH << 32);
             const uint64_t t = old >> 32, at = (uint64_t)g0 + t;
             const uint64_t avail = at < (uint64_t)count ? (uint64_t)count - at : 0;
-            if (avail) { v->b_next = (uint32_t)at; v->b_cnt = (uint32_t)(avail < GTS_POOL_BATCH ? avail : GTS_POOL_BATCH); }
-            else v->b_done = 1;
+            if (avail) {
+              const uint64_t be = at + (avail < GTS_POOL_BATCH ? avail : GTS_POOL_BATCH);
+              atomicExch(&ctl->b_stock, be << 32 | at);
+            } else v->b_done = 1;
           }
-          if (v->b_cnt) { idx = v->b_next; v->b_next = idx + 1u; v->b_cnt = v->b_cnt - 1u; }
+          pool_unlock(ctl);
         }
-        const int r = idx != GTS_NONE ? 0 : (may_front && !(v->f_done && v->f_next == v->f_end)) ? 1 : 2;
-        pool_unlock(ctl);
-        return r;
+        /* nothing for this wavefront now; 1: but the front (held by another one) has */
+        return (may_front && !(v->f_done && empty(&ctl->f_stock))) ? 1 : 2;
       };
       if (cold_mode) {
         /* in this order: the workgroup's share of the seeded components (the
@@ -1646,6 +1675,7 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
           need = ~A.order_key[first + idx];   /* the sort key: one load instead of three dependent ones */
           comp = A.order[first + idx];
         }
+        atomicAdd(&ctl->t_claim, (unsigned long long)(GtsWave64::clock() - tc0));
         npages = (need + GTS_POOL_PAGE - 1u) / GTS_POOL_PAGE;
         bool waiting = false;
         const uint64_t tw0 = GtsWave64::clock();
@@ -1757,6 +1787,7 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
          that tells the cold workgroups that this producer has left */
       volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
       atomicAdd(pstat + 0, v->t_run); atomicAdd(pstat + 1, v->t_wait); atomicAdd(pstat + 2, v->t_life);
+      if constexpr (FAST) atomicAdd(pstat + 15, v->t_claim);
       if constexpr (FAST) {
         if (v->n_done) { atomicAdd(pstat + 10, v->n_done); atomicAdd(pstat + 11, v->n_walks); atomicAdd(pstat + 13, v->b_done_bytes); }
         if (v->n_cold) { atomicAdd(pstat + 12, v->n_cold); atomicAdd(pstat + 14, v->b_cold_bytes); }
@@ -2145,7 +2176,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "hub_degree") && value >= 1) e->hub_degree = value;
   else if (!strcmp(name, "fast_walks")) e->fast_walks = value != 0;
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
-  else if (!strcmp(name, "batch_walks")) e->batch_walks = value != 0;
+  else if (!strcmp(name, "batch_walks") && value >= 0 && value <= 2) e->batch_walks = value;   /* 2: components that are not clean too */
   else if (!strcmp(name, "small_masks")) e->small_masks = value != 0;
   else if (!strcmp(name, "lds_int16_distances")) e->lds_int16_distances = value != 0;
   else if (!strcmp(name, "batch_big_contigs") && value >= 0) e->batch_big_contigs = value;
@@ -3145,7 +3176,7 @@ static int run_components(GtsgEngine *e, int mode)
           unsigned long long *cold = (unsigned long long *)(e->d_scalars + GTS_S_COLD);
           unsigned long long *fstat = (unsigned long long *)(e->d_scalars + GTS_S_FASTSTAT);
           HIPCHK(hipMemsetAsync(cold_list, 0, cold_entries * 8, ss));
-          HIPCHK(hipMemsetAsync(fstat, 0, 15 * 8, ss));
+          HIPCHK(hipMemsetAsync(fstat, 0, 16 * 8, ss));
           HIPCHK(hipMemsetAsync(fstat + 3, 0xFF, 8, ss));
           HIPCHK(hipMemsetAsync(fstat + 5, 0xFF, 8, ss));
           k_cold_seed<<<1, GTS_BLOCK, 0, ss>>>(order, order_key, first, pooled, cold, cold_list, fast_wgs, fast_bytes);
@@ -3336,8 +3367,8 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 64, hipMemcpyDeviceToHost, e->st));
     uint64_t pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 80, hipMemcpyDeviceToHost, e->st));
-    uint64_t fst[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (fast_ran) HIPCHK(hipMemcpyAsync(fst, e->d_scalars + GTS_S_FASTSTAT, 120, hipMemcpyDeviceToHost, e->st));
+    uint64_t fst[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (fast_ran) HIPCHK(hipMemcpyAsync(fst, e->d_scalars + GTS_S_FASTSTAT, 128, hipMemcpyDeviceToHost, e->st));
     uint64_t tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (team_ran) HIPCHK(hipMemcpyAsync(tst, e->d_scalars + GTS_S_TEAMSTAT, 64, hipMemcpyDeviceToHost, e->st));
     uint32_t res[4] = {0, 0, 0, 0};
@@ -3388,6 +3419,7 @@ static int run_components(GtsgEngine *e, int mode)
     if (fast_ran) {
       e->stats["fast_us_sum_run"] = (int64_t)(fst[0] / 100);
       e->stats["fast_us_sum_wait_pages"] = (int64_t)(fst[1] / 100);
+      e->stats["fast_us_sum_claim"] = (int64_t)(fst[15] / 100);
       e->stats["fast_us_sum_wave_life"] = (int64_t)(fst[2] / 100);
       e->stats["fast_us_first_exit"] = (int64_t)((fst[3] - fst[5]) / 100);
       e->stats["fast_us_last_exit"] = (int64_t)((fst[4] - fst[5]) / 100);
