@@ -6,10 +6,12 @@ metric : scaffold-graph edges processed/sec (build + mark_repeats + filter +
 step   : one pass of the hot path over one synthetic batch whose inputs
          (contig table + DistEst records in file order) are already resident
          in HBM when the timed region starts.
-N > 1  : one process per GPU (torch.distributed / RCCL only for the barrier
-         and the max-over-ranks of the time); every rank scaffolds its own
-         shard of independent connected components (its own synthetic genome
-         shard), no data-path collective -> weak scaling.
+N > 1  : one process per GPU.  Default (--mode partition, BASELINE configs[3]):
+         ONE graph, its connected components sharded over the ranks -- label /
+         plan / route over RCCL and one all-reduce inside the filter
+         (gt-scaffold_amd/dist.py) -> "scaling": "strong".  --mode shards: every
+         rank scaffolds its own graph, RCCL only for the barrier and the
+         max-over-ranks of the time -> "scaling": "weak".
 
 Prints ONE JSON line on rank 0.
 """
@@ -148,7 +150,8 @@ def recorded_traffic(name):
     in separate runs of this bench at the BASELINE configuration; FETCH_SIZE is
     taken as reported -- the guide's x2 correction is calibrated for 16 B/lane
     streams only, the engine's kernels read 1-8 B per lane -- so this is a lower
-    bound).  A recording, not a live measurement: null if the file is absent."""
+    bound; the second value of the pair applies the x2).  A recording, not a live
+    measurement: None if the file is absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
     if not os.path.exists(path):
         return None
@@ -156,13 +159,15 @@ def recorded_traffic(name):
     if name in ("k_components_lds", "k_components_pool", "k_components_fast", "k_walk_tasks", "k_components"):
         ks = [k for k in d if k.split("(")[0].split("<")[0].split("[")[0] == name]
         tot = sum((d[k]["fetch_bytes_per_launch_raw"] + d[k]["write_bytes_per_launch"]) * d[k]["launches"] for k in ks)
+        tot2 = sum((d[k]["fetch_bytes_per_launch_x2"] + d[k]["write_bytes_per_launch"]) * d[k]["launches"] for k in ks)
         n = sum(d[k]["launches"] for k in ks)
-        return tot / n if n else None      # average over the launches of the recorded step
+        return (tot / n, tot2 / n) if n else None      # average over the launches of the recorded step
     ks = [k for k in PMC_NAMES.get(name, []) if k in d]
     if not ks:
         return None
     per_step = sum((d[k]["fetch_bytes_per_launch_raw"] + d[k]["write_bytes_per_launch"]) * d[k]["launches"] for k in ks)
-    return per_step      # the PMC passes ran one step: bytes of the whole (composite) kernel
+    per_step2 = sum((d[k]["fetch_bytes_per_launch_x2"] + d[k]["write_bytes_per_launch"]) * d[k]["launches"] for k in ks)
+    return per_step, per_step2      # the PMC passes ran one step: bytes of the whole (composite) kernel
 
 
 def make_inputs(pkg, n_contigs, seed, device, gen):
@@ -179,6 +184,16 @@ def run_step(eng, g):
     return eng.ne
 
 
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(pkg, n_sample, gen, seed):
     """The oracle (a single-threaded port of the reference's algorithms) on a
     bounded sample of the same workload, on this host's cores."""
@@ -191,7 +206,8 @@ def cpu_baseline(pkg, n_sample, gen, seed):
     og.filter(CUTS["pcutoff"], CUTS["cncutoff"], CUTS["ocutoff"])
     og.makescaffold(True)
     dt = time.perf_counter() - t0
-    return dict(value=og.ne / dt, unit="edges/s", cores=1, kind="port",
+    return dict(value=og.ne / dt, unit="edges/s", cores=1, kind="port", host_cpu=host_cpu_model(),
+                host_cores=os.cpu_count(),
                 sample="%d-contig / %d-edge graph from the same generator, %.1f s; oracle with "
                        "epoch-stamped distance maps (the reference's per-walk O(|V|) map "
                        "initialisation, algorithms.c:648-650, would be slower still)"
@@ -259,6 +275,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option (gtsg_set_option), e.g. defer_min_contigs=256")
+    ap.add_argument("--gen", action="append", default=[], metavar="NAME=VALUE",
+                    help="generator option (synth.make_graph), e.g. permute_ids=0: a measurement aid, "
+                         "the line then names another workload")
     ap.add_argument("--inversions", type=float, default=None,
                     help="fraction of the chimeric links that are inversions (default 0: the "
                          "reference's walk search is exponential on components holding one)")
@@ -301,6 +320,10 @@ def main():
     pkg = load_package()
     dev = "cuda:%d" % local_rank
 
+    for kv in args.gen:
+        name, value = kv.split("=")
+        WORKLOAD["gen"][name] = float(value) if "." in value else int(value)
+        WORKLOAD["name"] += " [%s]" % kv
     if args.inversions is not None:
         WORKLOAD["gen"]["p_inversion"] = args.inversions
     if args.duplicate_pairs:
@@ -390,10 +413,15 @@ def main():
             avg_ms = ms / max(calls, 1)
             ab_step = algorithmic_bytes(name, n, m, nrec, eng)      # bytes of one step's launches
             per_launch = ab_step * steps / max(calls, 1) if ab_step else None
+            tr = recorded_traffic(name)
             r = dict(bound="hbm", kernel=name, launches=calls, launches_per_step=calls / steps,
                      avg_ms=avg_ms, algorithmic_bytes=per_launch,
                      achieved=(per_launch / (avg_ms * 1e-3) / 1e9) if per_launch and avg_ms else None,
-                     peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=recorded_traffic(name))
+                     peak=HBM_PEAK_GBS, unit="GB/s", frac=None,
+                     traffic=tr[0] if tr else None,
+                     traffic_is="raw FETCH_SIZE + WRITE_SIZE per launch, recorded (profiles/pmc_traffic_latest.json); "
+                                "a lower bound: gfx950 reports half the bytes of wide coalesced reads",
+                     traffic_with_fetch_x2=tr[1] if tr else None)
             if r["achieved"] is not None:
                 r["frac"] = r["achieved"] / HBM_PEAK_GBS
             return r
@@ -413,8 +441,26 @@ def main():
                             "counters in profiles/), not by HBM; span_ms = fork to join of the component "
                             "launches")
         sq = os.path.join(ROOT, "profiles", "sq_counters_latest.json")
+        roof_issue = None
         if os.path.exists(sq):
-            roof["sq_counters_recorded"] = json.load(open(sq)).get(dname)
+            rec = json.load(open(sq)).get(dname)
+            roof["sq_counters_recorded"] = rec
+            if rec and rec.get("SQ_WAVES") and rec.get("SQ_BUSY_CYCLES"):
+                # what does bound the component kernel: instructions issued per SIMD and
+                # cycle against one per cycle (MI355X_MICROARCH.md: a wave64 VALU instruction
+                # takes the SIMD two cycles, scalar and LDS issue beside it)
+                insts = sum(v for k, v in rec.items() if k.startswith("SQ_INSTS_"))
+                launches = max(rec.get("launches", 1), 1)
+                cyc = rec["SQ_WAVE_CYCLES"] * 4 / rec["SQ_WAVES"]          # cycles a wavefront lives
+                n_simd = 256 * 4
+                waves_per_simd = rec["SQ_WAVES"] / launches / n_simd
+                ipc = insts / rec["SQ_WAVES"] / cyc * waves_per_simd
+                roof_issue = dict(kernel=dname, insts_per_simd_cycle=ipc, peak=1.0, frac=ipc,
+                                  waves_per_simd=waves_per_simd, wave_executing_frac=rec.get("active_frac"),
+                                  wave_waiting_frac=rec.get("wait_any_frac"),
+                                  source="profiles/sq_counters_latest.json (rocprofv3 --pmc SQ passes, recorded)")
+                roof["limited_by"] = ("LDS capacity x time and the latency of dependent LDS reads at ~14 running "
+                                      "wavefronts per CU (DESIGN.md); HBM carries 2 % of its peak")
         # for reference, the largest HBM-streaming kernel of the step
         stream = [k for k in groups if not k.startswith("k_components") and k != "k_walk_tasks"
                   and algorithmic_bytes(k, n, m, nrec, eng)]
@@ -440,7 +486,7 @@ def main():
                                            ("%d independent graph(s), one per GPU, no data-path collective" % world),
                                mode=mode,
                                hip_hw_queues=int(os.environ["GPU_MAX_HW_QUEUES"])),
-                   roofline=roof, roofline_largest_streaming_kernel=roof_stream,
+                   roofline=roof, roofline_issue=roof_issue, roofline_largest_streaming_kernel=roof_stream,
                    component_kernel=dict(
                        walks_fast=eng.stat("fast_walks"), walks_reference=eng.stat("slow_walks"),
                        clean_components=eng.stat("clean_components"),
@@ -510,14 +556,8 @@ def main():
             if args.workload == "10M":
                 cb["full_size"] = cpu_baseline_full_size()
             out["cpu_baseline"] = cb
-        if (not args.no_secondary and world == 1 and mode == "shards" and args.workload == "10M"
-                and args.inversions is None and not args.duplicate_pairs):
-            # outside the timed region of the headline: its inputs are released first
-            g = None
-            torch.cuda.empty_cache()
-            eng.set_option("profile", 0)
-            out["secondary"] = [secondary_workload(pkg, eng, dev, torch, args.contigs)]
-        if args.verify:
+        if args.verify and mode == "shards":
+            # (before the secondary workload: the engine still holds the headline graph's states)
             from oracle.oracle_py import OracleGraph
             gn = pkg.synth.to_numpy(g)
             og = OracleGraph.from_records(gn["seq_len"], gn["astat"], gn["copy_num"], gn["root"],
@@ -528,6 +568,13 @@ def main():
             og.makescaffold(True)
             out["verified_against_oracle"] = (eng.digest() == pkg.engine.state_digest_host(
                 og.vertex_states(), og.edge_states()))
+        if (not args.no_secondary and world == 1 and mode == "shards" and args.workload == "10M"
+                and args.inversions is None and not args.duplicate_pairs and not args.gen):
+            # outside the timed region of the headline: its inputs are released first
+            g = None
+            torch.cuda.empty_cache()
+            eng.set_option("profile", 0)
+            out["secondary"] = [secondary_workload(pkg, eng, dev, torch, args.contigs)]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

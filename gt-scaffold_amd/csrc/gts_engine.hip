@@ -60,7 +60,7 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_S_TQCNT 352    /* u64 */
 #define GTS_S_NDEF 384     /* u64 */
 #define GTS_POOL_WAVES 16u /* wavefronts of a k_components_pool workgroup (one per CU) */
-#define GTS_FAST_WAVES 16u /* of a k_components_fast workgroup (two per CU), at most */
+#define GTS_FAST_WAVES 10 /* of a k_components_fast workgroup (two per CU: 20 wavefronts, 96 registers a lane) */
 #define GTS_S_POOLCUR 392  /* u64: claim counter of k_components_pool */
 #define GTS_S_POOLSTAT 400 /* 10 x u64: clocks, give-up and overrun counts of k_components_pool */
 #define GTS_S_TEAMUSED 424 /* u64: bytes of the team slab handed out */
@@ -150,7 +150,7 @@ struct GtsgEngine {
   /* round 4: clean components on k_components_fast (two workgroups of fast_waves
      wavefronts per CU), everything else -- and what that program hands over -- on
      cold_cus workgroups of the full program next to it */
-  int64_t fast_components = 1, fast_waves = 12, cold_cus = 8;
+  int64_t fast_components = 1, fast_waves = GTS_FAST_WAVES, cold_cus = 8;
   int64_t fast_split = 0;   /* two workgroups with half a pool each per CU; 0: one with the whole pool */
   int64_t gather_unroll = 4;           /* edges a thread of the gather-shaped build kernels (1: A/B measurements) */
   int64_t lds_poison = -1;             /* test aid: fill a component's pages with this byte before staging */
@@ -474,7 +474,7 @@ __global__ void k_row_offsets(const uint32_t *sorted_start, uint32_t *row,
 }
 
 #define GTS_GATHER_UNROLL 4
-template <int GTS_U>
+template <int GTS_U, bool INV = true>
 __global__ void k_gather_csr(const uint32_t *perm, const GtsEdgeRec *rec,
                              uint32_t *eend, int64_t *dist, int64_t *npairs,
                              float *sd, uint8_t *flags, uint8_t *state,
@@ -498,7 +498,7 @@ __global__ void k_gather_csr(const uint32_t *perm, const GtsEdgeRec *rec,
     if (p >= m) continue;
     eend[p] = r[k].end; dist[p] = r[k].dist; npairs[p] = r[k].npairs; sd[p] = r[k].sd;
     flags[p] = (uint8_t)r[k].flags; state[p] = GIS_UNVISITED;
-    pos_of_eid[id[k]] = (uint32_t)p;
+    if (INV) pos_of_eid[id[k]] = (uint32_t)p;   /* (INV = false: timing aid, gather_unroll = 101) */
   }
 }
 template <int GTS_U>
@@ -1768,6 +1768,9 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane == 0) {
+      /* test aid (lds_poison = 256): the word is overwritten as a program that ran
+         past its arrays would -- the report and the restore are what is tested */
+      if (A.poison == 256 && canary) *canary = 0u;
       if (canary && *canary != 0x5CAFF01Du) atomicAdd(pstat + 9, 1ull);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       pool_bits_clear(ctl->used, pool_run_mask(pos, npages));
@@ -1810,7 +1813,9 @@ k_components_pool(GtsCompView C, GtsPoolArgs A)
 }
 /* two workgroups per CU (GTS_FAST_BYTES of dynamic LDS each) of WAVES wavefronts:
    the register budget follows from the launch bounds (2 x WAVES / 4 wavefronts
-   per SIMD: 80 registers a lane for 12, 72 for 14, 64 for 16) */
+   per SIMD: 96 registers a lane for 10, 80 for 12, 64 for 16).  Measured in round 4
+   with 12 / 14 / 16 wavefronts: slower than one workgroup with the whole pool --
+   the launch is bound by LDS x time, the page waits triple */
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * GTS_WAVE, (2 * WAVES + 3) / 4)
 k_components_fast(GtsCompView C, GtsPoolArgs A)
@@ -1967,9 +1972,13 @@ __global__ void k_count_errors(const uint32_t *cerr, uint32_t ncomp,
 {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncomp) return;
-  if (cerr[c] == GTS_CERR_WALKQ_OVERFLOW) atomicAdd(&out[0], 1u);
-  else if (cerr[c] == GTS_CERR_PATH_OVERFLOW) atomicAdd(&out[3], 1u);
-  else if (cerr[c] != 0) atomicAdd(&out[1], 1u);
+  /* one atomic in the source: written as an if / else-if chain of three, hipcc 7.2
+     merged them and sent a wavefront's cerr == 2 lanes to out[0] whenever it held
+     no lane with cerr == 0 (profiles/r04_isa_k_count_errors_miscompiled.txt): a
+     walk error was taken for an exhausted ring pool */
+  const uint32_t ce = cerr[c];
+  const uint32_t k = ce == GTS_CERR_WALKQ_OVERFLOW ? 0u : ce == GTS_CERR_PATH_OVERFLOW ? 3u : 1u;
+  if (ce != 0) atomicAdd(out + k, 1u);
 }
 /* statistics: the lanes of a wave add up (or take the maximum) first, one
    atomic per wave */
@@ -2115,8 +2124,7 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
   if (!rc && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
   const void *big_lds[] = {(const void *)k_walk_tasks_mixed, (const void *)k_walk_tasks,
                            (const void *)k_components_lds,
-                           (const void *)k_components_pool, (const void *)k_components_fast<12>,
-                           (const void *)k_components_fast<14>, (const void *)k_components_fast<16>,
+                           (const void *)k_components_pool, (const void *)k_components_fast<GTS_FAST_WAVES>,
                            (const void *)k_components_fast1,
                            (const void *)k_components_team};
   {
@@ -2190,7 +2198,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "task_reference_walks")) e->task_reference_walks = value != 0;
   else if (!strcmp(name, "pool_components")) e->pool_components = value != 0;
   else if (!strcmp(name, "pool_waves") && value >= 1 && value <= GTS_POOL_WAVES) e->pool_waves = value;
-  else if (!strcmp(name, "lds_poison") && value >= -1 && value <= 255) e->lds_poison = value;
+  else if (!strcmp(name, "lds_poison") && value >= -1 && value <= 256) e->lds_poison = value;   /* 256: also clobbers the canaries */
   else if (!strcmp(name, "gather_unroll") && value >= 1) e->gather_unroll = value;
   else if (!strcmp(name, "pool_fill_kb") && value >= 0) e->pool_fill_kb = value;
   else if (!strcmp(name, "fast_components")) e->fast_components = value != 0;
@@ -2378,7 +2386,12 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
       return fail(e, GTSG_EHIP, "CSR sort ended in the wrong buffer");
     LAUNCH("build_row_offsets", k_row_offsets, nblk((uint64_t)m + 1), GTS_BLOCK, e->estart,
            e->row, n, m);
-    if (e->gather_unroll > 1) {
+    if (e->gather_unroll == 101) {   /* timing aid: the gather without the inverse permutation (results are wrong) */
+      LAUNCH("build_gather_csr", (k_gather_csr<GTS_GATHER_UNROLL, false>), nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK,
+             e->eid, rec, e->eend, e->dist, e->npairs, e->sd, e->flags, e->state, e->pos_of_eid, m);
+      LAUNCH("build_twins", k_twins<GTS_GATHER_UNROLL>, nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK, e->eid,
+             e->pos_of_eid, e->twin, m);
+    } else if (e->gather_unroll > 1) {
       LAUNCH("build_gather_csr", k_gather_csr<GTS_GATHER_UNROLL>, nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK,
              e->eid, rec, e->eend, e->dist, e->npairs, e->sd, e->flags, e->state, e->pos_of_eid, m);
       LAUNCH("build_twins", k_twins<GTS_GATHER_UNROLL>, nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK, e->eid,
@@ -2775,11 +2788,14 @@ __global__ void k_plan_fold(const uint32_t *cnt, const uint32_t *labels, int32_t
   if (v < n && cnt[v]) atomicAdd(&w[labels[v]], (int32_t)cnt[v]);
 }
 __global__ void k_plan_keys(const uint32_t *labels, const uint8_t *skip, const int32_t *w,
-                            uint32_t *key, uint32_t *val, uint32_t n)
+                            uint32_t *key, uint32_t *val, uint32_t n, uint32_t *bad)
 {
   uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
   const bool is_root = labels[v] == (uint32_t)v && !skip[v];
+  /* the weights are int32 sums over the ranks: a component of 2^31 records or
+     more wrapped on the way, and its key would collide with the sentinel */
+  if (is_root && w[v] < 0) atomicAdd(bad, 1u);
   key[v] = is_root ? 0xFFFFFFFEu - (uint32_t)w[v] : 0xFFFFFFFFu;   /* ascending = heaviest first, then by id */
   val[v] = (uint32_t)v;
 }
@@ -2848,7 +2864,13 @@ int gtsg_plan_deal(GtsgEngine *e, uint64_t n, const uint8_t *skip, const uint32_
   PALLOC(k0, uint32_t, n); PALLOC(k1, uint32_t, n); PALLOC(v0, uint32_t, n); PALLOC(v1, uint32_t, n);
   PALLOC(oor, int8_t, n);
   PALLOC(stmp, uint32_t, gts_sort_tmp_elems(n));
-  LAUNCH("plan_keys", k_plan_keys, nblk(n), GTS_BLOCK, labels, skip, weights, k0, v0, (uint32_t)n);
+  HIPCHK(hipMemsetAsync(e->d_scalars + 6, 0, 4, e->st));
+  LAUNCH("plan_keys", k_plan_keys, nblk(n), GTS_BLOCK, labels, skip, weights, k0, v0, (uint32_t)n, e->d_scalars + 6);
+  {
+    uint32_t bad = 0;
+    if ((rc = read_u32(e, e->d_scalars + 6, &bad))) return rc;
+    if (bad) return fail(e, GTSG_ELIMIT, "%u component(s) of 2^31 records or more: the plan's weights are 32 bit", bad);
+  }
   int shifts[4] = {0, 8, 16, 24};
   int where;
   { ProfScope ps(e, "plan_sort");
@@ -3198,9 +3220,7 @@ static int run_components(GtsgEngine *e, int mode)
           FA.pstat = fstat;
           if (e->profile) hipEventRecord(_a, ss);
           if (!e->fast_split) k_components_fast1<<<fast_wgs, (uint32_t)e->pool_waves * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, FA);
-          else if (e->fast_waves >= 16) k_components_fast<16><<<fast_wgs, 16 * GTS_WAVE, GTS_FAST_BYTES, ss>>>(C, FA);
-          else if (e->fast_waves >= 14) k_components_fast<14><<<fast_wgs, 14 * GTS_WAVE, GTS_FAST_BYTES, ss>>>(C, FA);
-          else k_components_fast<12><<<fast_wgs, (uint32_t)e->fast_waves * GTS_WAVE, GTS_FAST_BYTES, ss>>>(C, FA);
+          else k_components_fast<GTS_FAST_WAVES><<<fast_wgs, (uint32_t)e->fast_waves * GTS_WAVE, GTS_FAST_BYTES, ss>>>(C, FA);
           if (e->profile) { hipEventRecord(_b, ss);
                             e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_fast"
                                                                                 : "components_removecycles_fast",
@@ -3377,6 +3397,9 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(wstat, e->d_scalars + 16, 32, hipMemcpyDeviceToHost, e->st));
     if ((rc = sync_stream(e))) return rc;
     for (int k = 6; k < 10; ++k) pst[k] += fst[k];   /* either kernel's waits and overruns */
+    e->stats["components_ring_overflow"] = res[0];
+    e->stats["components_walk_error"] = res[1];
+    e->stats["components_path_overflow"] = res[3];
     if (pst[6] | pst[7] | pst[8] | pst[9]) {
       /* some components have written their marks, others have not run: the graph
          goes back to its state before the call (as for GTSG_EWALK), the caller
@@ -3430,7 +3453,7 @@ static int run_components(GtsgEngine *e, int mode)
       /* the cold workgroups start first; their clocks against the fast kernel's first start */
       e->stats["cold_us_last_exit_after_fast_start"] = (int64_t)(((int64_t)pst[4] - (int64_t)fst[5]) / 100);
       e->stats["fast_wavefronts"] = (int64_t)(e->n_cus - (int)e->cold_cus) *
-                                    (e->fast_split ? 2 * (e->fast_waves >= 16 ? 16 : e->fast_waves >= 14 ? 14 : e->fast_waves) : e->pool_waves);
+                                    (e->fast_split ? 2 * e->fast_waves : e->pool_waves);
     }
     {
       static const char *nm[4] = {"removecycles", "makescaffold_other", "walks_fast", "walks_reference"};
@@ -3785,6 +3808,8 @@ static int format_dot_edges(GtsgEngine *e, uint64_t first, uint64_t count, char 
   if (count > (1u << 25)) return fail(e, GTSG_ELIMIT, "at most 2^25 edges a call (32-bit text offsets)");
   int rc;
   const uint32_t cnt = (uint32_t)count;
+  /* (the workspace is the open filter call's too: pool_reserve would drop it) */
+  if (e->filter_open) return fail(e, GTSG_EINVAL, "gtsg_filter_begin without gtsg_filter_end");
   if ((rc = pool_reserve(e, (size_t)cnt * 8 + gts_scan_tmp_elems((uint64_t)cnt + 16) * 4 + (1u << 20)))) return rc;
   PALLOC(len, uint32_t, (size_t)cnt + 1); PALLOC(off, uint32_t, (size_t)cnt + 2);
   PALLOC(sctmp, uint32_t, gts_scan_tmp_elems((uint64_t)cnt + 16));
@@ -3848,6 +3873,7 @@ int gtsg_get_scaffold_edges(GtsgEngine *e, uint64_t *count, uint32_t *row, uint3
   const uint32_t n = e->n, m = e->m;
   int rc;
   const size_t need = (size_t)m * 5 + (size_t)n * 4 + gts_scan_tmp_elems((uint64_t)m + 16) * 4 + (1u << 20);
+  if (e->filter_open) return fail(e, GTSG_EINVAL, "gtsg_filter_begin without gtsg_filter_end");
   if ((rc = pool_reserve(e, need))) return rc;
   PALLOC(flag, uint8_t, (size_t)m + 1); PALLOC(ipos, uint32_t, (size_t)m + 2);
   PALLOC(srow, uint32_t, (size_t)n + 1);

@@ -232,10 +232,12 @@ GtScaffolderGraph *gt_scaffolder_graph_new(uint64_t max_v, uint64_t max_e)
   return g;
 }
 
+static void fascan_drop(void);
 void gt_scaffolder_graph_delete(GtScaffolderGraph *g)
 {
   uint64_t i;
   if (!g) return;
+  fascan_drop();   /* a scan count_contigs kept for a read_contigs that never came (up to the file's size) */
   for (i = 0; i < g->nof_vertices; i++) free(g->ctg[i].name);
   free(g->ctg); free(g->edges); free(g->vstate); free(g->estate);
   if (g->eng) gtsg_destroy(g->eng);
@@ -301,22 +303,15 @@ uint64_t gt_scaffolder_graph_get_vertex_id(const GtScaffolderGraph *g, uint64_t 
   return g && vertex < g->nof_vertices ? vertex : GT_SCAFFOLDER_NO_VERTEX;
 }
 
+static bool find_contig64(const GtScaffolderGraph *g, const char *name, uint64_t *id);
 /* ref gt_scaffolder_graph.c:196-216: binary search over the vertices, which
    are in header order once the distance file has been counted or read
    (parser.c:172); like the reference it assumes that order */
 bool gt_scaffolder_graph_get_vertex(const GtScaffolderGraph *g, uint64_t *vertex,
                                     const char *header_seq)
 {
-  uint64_t lo = 0, hi;
   if (!g || !vertex || !header_seq) return false;
-  hi = g->nof_vertices;
-  while (lo < hi) {
-    uint64_t mid = lo + (hi - lo) / 2;
-    int c = strcmp(g->ctg[mid].name, header_seq);
-    if (c == 0) { *vertex = mid; return true; }
-    if (c < 0) lo = mid + 1; else hi = mid;
-  }
-  return false;
+  return find_contig64(g, header_seq, vertex);
 }
 
 /* ref gt_scaffolder_graph.c:219-235 */
@@ -347,16 +342,26 @@ static int contig_cmp(const void *a, const void *b)
   return strcmp(((const Contig *)a)->name, ((const Contig *)b)->name);
 }
 
-static bool find_contig(const GtScaffolderGraph *g, const char *name, uint32_t *id)
+/* the reference's probing sequence (gt_scaffolder_graph.c:196-216: inclusive
+   bounds, mid = min + (max - min) / 2): with equal headers it decides which of
+   them is found -- sorted [A, A] gives the first there */
+static bool find_contig64(const GtScaffolderGraph *g, const char *name, uint64_t *id)
 {
-  uint64_t lo = 0, hi = g->nof_vertices;
-  while (lo < hi) {
-    uint64_t mid = lo + (hi - lo) / 2;
-    int c = strcmp(g->ctg[mid].name, name);
-    if (c == 0) { *id = (uint32_t)mid; return true; }
-    if (c < 0) lo = mid + 1; else hi = mid;
+  int64_t lo = 0, hi = (int64_t)g->nof_vertices - 1;
+  while (hi >= lo) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    const int c = strcmp(g->ctg[mid].name, name);
+    if (c == 0) { *id = (uint64_t)mid; return true; }
+    if (c < 0) lo = mid + 1; else hi = mid - 1;
   }
   return false;
+}
+static bool find_contig(const GtScaffolderGraph *g, const char *name, uint32_t *id)
+{
+  uint64_t v;
+  if (!find_contig64(g, name, &v)) return false;
+  *id = (uint32_t)v;
+  return true;
 }
 
 /* the records of a FASTA text: description [ds, de) (after the '>', up to the
@@ -490,6 +495,8 @@ static void fascan_keep(FaScan *sc)
   pthread_mutex_unlock(&g_fa_lock);
   fascan_free(old);
 }
+
+static void fascan_drop(void) { fascan_keep(NULL); }
 
 /* FASTA: '>' description newline, then sequence characters up to the next
    '>' (blanks and line ends do not count).  With a graph: keeps contigs longer
@@ -805,6 +812,10 @@ static int gpu_parse_distances(GtScaffolderGraph *g, const char *path, GtsgDePar
   struct stat st;
   const bool have_stat = stat(path, &st) == 0;
   *used = 0;
+  /* (the file is taken to be the same if device, inode, size and modification time
+     agree: a file rewritten in place with the same size inside one tick of the
+     clock would not be seen; host-parser mode never takes the kept records) */
+  if (g_host_parser == 1) g->dp_parsed = false;
   if (g->dp && g->dp_names && g->dp_parsed && have_stat && g->dp_dev == st.st_dev && g->dp_ino == st.st_ino &&
       g->dp_size == st.st_size && g->dp_mtime.tv_sec == st.st_mtim.tv_sec &&
       g->dp_mtime.tv_nsec == st.st_mtim.tv_nsec) {
@@ -1165,26 +1176,40 @@ int gt_scaffolder_graph_get_edges(GtScaffolderGraph *g, uint32_t *start, uint32_
   return 0;
 }
 
-/* ref gt_scaffolder_graph.c:269-307 */
+/* ref gt_scaffolder_graph.c:247-266: opens the file and prints into it */
 int gt_scaffolder_graph_print(const GtScaffolderGraph *cg, const char *filename,
                               char *err, size_t errlen)
+{
+  GtScaffolderGraph *g = (GtScaffolderGraph *)cg;
+  FILE *f = fopen(filename, "w");
+  int rc;
+  if (!f) return seterr(err, errlen, "cannot open %s for writing", filename);
+  g->err[0] = 0;
+  rc = gt_scaffolder_graph_print_generic(cg, f);
+  if (fclose(f) != 0) rc = rc ? rc : -1;
+  if (rc) return seterr(err, errlen, g->err[0] ? "%s" : "cannot write %s", g->err[0] ? g->err : filename);
+  return 0;
+}
+
+/* ref gt_scaffolder_graph.c:269-307 (the reference takes a GtFile and returns
+   nothing: a failed write ends the program there; here it is the return value,
+   the message is left in the graph: gt_scaffolder_graph_last_error) */
+int gt_scaffolder_graph_print_generic(const GtScaffolderGraph *cg, FILE *f)
 {
   static const char *const color[] = {"black", "gray80", "gainsboro", "ivory3",
                                       "red", "green", "magenta", "blue"};
   GtScaffolderGraph *g = (GtScaffolderGraph *)cg;
-  FILE *f;
   OutBuf ob;
   uint64_t i;
   double t0 = now_s();
+  if (!g || !f) return -1;
   if (g->eng && !g_host_dot) {
     /* a graph on the GPU: its edge lines (all but a few per cent of the file)
        are formatted there, 2^23 edges at a time; only the vertex states cross
        the bus besides the text */
     const uint64_t chunk = 1ull << 23;
     int rc = gtsg_get_vertex_states(g->eng, g->vstate);
-    if (rc) { engine_err(g, rc, NULL, 0); return seterr(err, errlen, "%s", g->err); }
-    f = fopen(filename, "w");
-    if (!f) return seterr(err, errlen, "cannot open %s for writing", filename);
+    if (rc) { engine_err(g, rc, NULL, 0); return -1; }
     ob_init(&ob, f);
     ob_str(&ob, "digraph {\n");
     for (i = 0; i < g->nof_vertices; i++) {
@@ -1204,23 +1229,22 @@ int gt_scaffolder_graph_print(const GtScaffolderGraph *cg, const char *filename,
       if (rc) { engine_err(g, rc, NULL, 0); break; }
       lap("dot: chunk formatted", &t0);
       {
-        /* past stdio: the chunk (half a gigabyte) goes out in parallel pieces */
+        /* past stdio: the chunk (half a gigabyte) goes out in parallel pieces; a
+           stream that cannot seek (a pipe) gets it through stdio */
         off_t at;
-        if (fflush(f) != 0 || (at = ftello(f)) < 0 ||
-            io_parallel(fileno(f), (char *)(uintptr_t)text, nb, at, 1) ||
-            fseeko(f, at + (off_t)nb, SEEK_SET) != 0)
+        if (fflush(f) != 0) rc = -1;
+        else if ((at = ftello(f)) < 0) { if (fwrite(text, 1, nb, f) != nb) rc = -1; }
+        else if (io_parallel(fileno(f), (char *)(uintptr_t)text, nb, at, 1) ||
+                 fseeko(f, at + (off_t)nb, SEEK_SET) != 0)
           rc = -1;
       }
       lap("dot: chunk written", &t0);
     }
     if (!rc && fwrite("}\n", 1, 2, f) != 2) rc = -1;
-    if (fclose(f) != 0) rc = rc ? rc : -1;
-    if (rc) return seterr(err, errlen, g->err[0] ? "%s" : "cannot write %s", g->err[0] ? g->err : filename);
-    return 0;
+    if (!rc && fflush(f) != 0) rc = -1;
+    return rc ? -1 : 0;
   }
-  if (refresh(g)) return seterr(err, errlen, "%s", g->err);
-  f = fopen(filename, "w");
-  if (!f) return seterr(err, errlen, "cannot open %s for writing", filename);
+  if (refresh(g)) return -1;
   /* the lines of gt_scaffolder_graph_print_generic (graph.c:269-307), put
      together by hand: fprintf costs more than everything the GPU does */
   ob_init(&ob, f);
@@ -1241,8 +1265,7 @@ int gt_scaffolder_graph_print(const GtScaffolderGraph *cg, const char *filename,
     ob_str(&ob, (e->flags & 1) ? "\" arrowhead=\"normal\"];\n" : "\" arrowhead=\"inv\"];\n");
   }
   ob_str(&ob, "}\n");
-  if (ob_close(&ob)) { fclose(f); return seterr(err, errlen, "cannot write %s", filename); }
-  fclose(f);
+  if (ob_close(&ob) || fflush(f) != 0) return -1;
   return 0;
 }
 

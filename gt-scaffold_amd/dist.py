@@ -140,7 +140,7 @@ def unpack_records(rows):
 
 
 # ---- the three steps --------------------------------------------------------
-def component_labels(comm, n, root, ctg, skip, label_fn, device):
+def component_labels(comm, n, root, ctg, skip, label_fn, device, force_collectives=False):
     """Step 1.  root / ctg: this shard's records, skip: bool[n] (repeat
     contigs).  Returns labels[n] (int32): smallest contig of the component,
     identical on every rank.
@@ -155,12 +155,13 @@ def component_labels(comm, n, root, ctg, skip, label_fn, device):
     torch.arange(n, dtype=torch.int32, device=device, out=labels)
     rounds = 0
     while True:
-        prev = labels.clone() if comm.world > 1 else None
+        many = comm.world > 1 or force_collectives
+        prev = labels.clone() if many else None
         out = label_fn(labels, root, ctg, skip)
         if out.data_ptr() != labels.data_ptr():
             labels.copy_(out)
         rounds += 1
-        if comm.world == 1:
+        if not many:
             return labels, rounds
         buf[n] = -(labels != prev).any().to(torch.int32)
         comm.all_reduce(buf, "min")
@@ -263,7 +264,7 @@ def engine_label_fn(eng):
     return fn
 
 
-def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None, timers=None):
+def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None, timers=None, force_collectives=False):
     """The whole hot path for one graph whose records are split over the
     ranks.  contigs: seq_len / astat / copy_num of ALL contigs (tensors on the
     engine's device); rec: this rank's slice of the records with global index
@@ -272,7 +273,9 @@ def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None, timers=None):
     of local vertex v (owned contigs and all repeat contigs, ascending); vertex
     states are valid for owned and repeat contigs, every edge lives on exactly
     one rank.  timers: optional dict that receives the wall time (s) of the
-    stages, each closed by a device synchronisation (measurement only)."""
+    stages, each closed by a device synchronisation (measurement only).
+    force_collectives: run the collectives a single rank would skip (the MIN of
+    the labels, the MAX of the latest hits) -- the one-rank RCCL test."""
     import time
     t_last = [time.perf_counter()]
 
@@ -294,12 +297,13 @@ def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None, timers=None):
         skip8 = skip.to(torch.uint8)
         labels, rounds = component_labels(comm, n, root.contiguous(), ctg.contiguous(), skip8,
                                           lambda lab, r, c, s: (eng.label_components(lab.numel(), r, c, s, lab), lab)[1],
-                                          dev)
+                                          dev, force_collectives)
         lap("label")
         owner, load = plan_owners_engine(comm, eng, labels, skip8, root, ctg)
     else:
         root, ctg = rec["root"].to(torch.int64), rec["ctg"].to(torch.int64)
-        labels, rounds = component_labels(comm, n, root, ctg, skip, label_fn or engine_label_fn(eng), dev)
+        labels, rounds = component_labels(comm, n, root, ctg, skip, label_fn or engine_label_fn(eng), dev,
+                                          force_collectives)
         lap("label")
         owner, load = plan_owners(comm, n, labels, skip, root, ctg)
     lap("plan")
@@ -330,10 +334,10 @@ def scaffold_sharded(comm, eng, contigs, rec, cuts, label_fn=None, timers=None):
     rep_loc = loc_of[torch.nonzero(skip).flatten()].to(torch.int64)
     if local.numel():
         eng.filter_begin(cuts["pcutoff"], cuts["cncutoff"], cuts["ocutoff"])
-        if comm.world > 1:
+        if comm.world > 1 or force_collectives:
             lasthit = torch.empty(2 * local.numel(), dtype=torch.int32, device=dev)
             eng.filter_get_lasthit(lasthit)
-    if rep_loc.numel() and comm.world > 1:     # (one shard has nobody to agree with)
+    if rep_loc.numel() and (comm.world > 1 or force_collectives):     # (one shard has nobody to agree with)
         tab = lasthit.view(-1, 2)[rep_loc].contiguous()
         comm.all_reduce(tab, "max")
         lasthit.view(-1, 2)[rep_loc] = tab

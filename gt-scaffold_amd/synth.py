@@ -45,7 +45,7 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
                p_bubble=0.02, p_chimeric=0.01, p_missing_astat=0.01, p_relist=0.01,
                p_link=0.97, contig_median=900, dist_range_small=False, scaffold_max=20000,
                p_relist_flip=0.0, min_dist=-99, p_inversion=1.0, unique_pairs=False,
-               p_repeat_unmarked=0.0, portable=False):
+               p_repeat_unmarked=0.0, portable=False, permute_ids=True, permute_lines=True):
     """Returns a dict of tensors:
       seq_len[u64 as i64], astat[f32], copy_num[f32]          (per contig)
       root[i32], ctg[i32], dist[i64], std_dev[f32], num_pairs[i64], flags[u8]
@@ -76,6 +76,8 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
     pos = torch.arange(n, device=dev)
     sc_id = torch.searchsorted(sc_end, pos, right=True)
     vid = torch.randperm(n, device=dev, generator=gen)  # position -> vertex id
+    if not permute_ids:   # measurement aid: contig ids in genome order (what a locality-preserving renumbering would give)
+        vid = torch.arange(n, device=dev)
 
     clen = _lognormal_int(gen, n, contig_median, 0.8, 201, 60000, dev, portable)
     orient = randint(0, 2, n).to(torch.bool)            # True = reverse strand
@@ -220,6 +222,8 @@ def make_graph(n_contigs, seed=0, device="cpu", links_per_side=5, reach=6000,
         rnp = torch.cat([rnp, randint(5, 600, n_re)])
     # file order: line order of the root (a random contig order), sense first
     line_of = torch.randperm(n, device=dev, generator=gen)
+    if not permute_lines:   # measurement aid: the roots' lines in contig-id order
+        line_of = torch.arange(n, device=dev)
     key = line_of[root].to(torch.int64) * 2 + (~rsense).to(torch.int64)
     key = key * (1 << 22) + randint(0, 1 << 22, key.numel())
     order = torch.argsort(key, stable=True) if portable else torch.argsort(key)

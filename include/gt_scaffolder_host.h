@@ -19,6 +19,7 @@
 #include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -95,6 +96,11 @@ int gt_scaffolder_parser_read_distances(const char *filename,
 /* ref gt_scaffolder_graph.c:247 */
 int gt_scaffolder_graph_print(const GtScaffolderGraph *g, const char *filename,
                               char *err, size_t errlen);
+/* ref gt_scaffolder_graph.h:151-153, gt_scaffolder_graph.c:269-307: the dot
+   representation into an open stream (the reference's GtFile is a stdio stream
+   here; it returns nothing there -- a failed write ends the program --, here
+   0 / -1, the message is gt_scaffolder_graph_last_error's) */
+int gt_scaffolder_graph_print_generic(const GtScaffolderGraph *g, FILE *f);
 /* ref gt_scaffolder_graph.c:421 */
 int gt_scaffolder_graph_test(uint64_t max_nof_vertices, uint64_t max_nof_edges,
                              bool init_vertices, uint64_t nof_vertices,

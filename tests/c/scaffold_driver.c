@@ -174,6 +174,14 @@ int main(int argc, char **argv)
     if (!had_err) had_err = gt_scaffolder_makescaffold(graph);
     if (!had_err) had_err = gt_scaffolder_graph_print(graph,
                                "gt_scaffolder_algorithms_test_makescaffold.dot", err, sizeof err);
+    if (!had_err && argc > 4 && strcmp(argv[4], "api") == 0) {
+      /* the stream variant (ref gt_scaffolder_graph.h:151-153) writes the same bytes */
+      FILE *f = fopen("gt_scaffolder_print_generic.dot", "w");
+      had_err = f ? gt_scaffolder_graph_print_generic(graph, f) : -1;
+      if (f && fclose(f) != 0) had_err = -1;
+      if (had_err) snprintf(err, sizeof err, "print_generic failed");
+      else printf("print_generic ok\n");
+    }
     if (had_err && !err[0]) snprintf(err, sizeof err, "%s", gt_scaffolder_graph_last_error(graph));
   }
   if (had_err == 0) {

@@ -62,6 +62,10 @@ def test_c_driver_reproduces_reference_dot_files(tmp_path, golden_dir, mode):
     assert (tmp_path / "gt_scaffolder_new_write.scaf").stat().st_size > 0
     if mode == ("api",):
         assert "api ok" in r.stdout, r.stdout + r.stderr
+        # gt_scaffolder_graph_print_generic (stream) = gt_scaffolder_graph_print (file name)
+        assert "print_generic ok" in r.stdout
+        assert filecmp.cmp(tmp_path / "gt_scaffolder_print_generic.dot",
+                           tmp_path / "gt_scaffolder_algorithms_test_makescaffold.dot", shallow=False)
     if mode == ("stepwise",):
         # count_contigs tests >= min_ctg_len, read_contigs > (ref parser.c:408, :481)
         assert "contigs counted 50, distances counted" in r.stdout, r.stdout

@@ -930,6 +930,47 @@ def test_pool_wait_bound_leaves_a_graph_that_can_be_scaffolded_again():
     assert_same_states(eng, og, "makescaffold after a failed call")
 
 
+def test_lds_overrun_is_reported_and_leaves_a_graph_that_can_be_scaffolded_again():
+    """the canary path: a word behind a component's arrays that a
+    program overwrote is counted, the call returns GTSG_EINTERNAL and the states are
+    those before the call.  lds_poison = 256 overwrites the word as an overrun would."""
+    g = make_inputs(20000, 9, p_chimeric=0.02)
+    og = oracle_from_inputs(g)
+    eng = engine_from_inputs(g)
+    og.mark_repeats(); eng.mark_repeats()
+    og.filter(); eng.filter()
+    eng.set_option("lds_poison", 256)
+    with pytest.raises(pkg.engine.EngineError) as ei:
+        eng.makescaffold()
+    assert "(code -6)" in str(ei.value) and "wrote past their LDS arrays" in str(ei.value)
+    assert eng.stat("pool_lds_overruns") > 0
+    assert_same_states(eng, og, "after the failed call")
+    eng.set_option("lds_poison", -1)
+    og.makescaffold(True); eng.makescaffold()
+    assert_same_states(eng, og, "makescaffold after a failed call")
+
+
+def test_walk_error_after_marks_restores_the_states():
+    """GTSG_EWALK after a partial mark: with the reference's search bounded to a few
+    pops the small components finish and write their marks, the larger ones give up;
+    the call reports the walk error and the graph is as before, so the same call with
+    the default bound gives the oracle's result."""
+    g = make_inputs(6000, 13, p_chimeric=0.05)
+    og = oracle_from_inputs(g)
+    eng = engine_from_inputs(g, fast_walks=0)
+    og.mark_repeats(); eng.mark_repeats()
+    og.filter(); eng.filter()
+    before_v, before_e = eng.vertex_states().copy(), eng.edge_states().copy()
+    eng.set_option("max_walk_pops", 6)
+    with pytest.raises(pkg.engine.EngineError) as ei:
+        eng.makescaffold()
+    assert "max_walk_pops" in str(ei.value) and "states restored" in str(ei.value)
+    assert np.array_equal(eng.vertex_states(), before_v) and np.array_equal(eng.edge_states(), before_e)
+    eng.set_option("max_walk_pops", 1 << 32)
+    og.makescaffold(True); eng.makescaffold()
+    assert_same_states(eng, og, "makescaffold after a walk error")
+
+
 @pytest.mark.parametrize("case", range(4))
 def test_team_kernel_for_global_memory_components(case):
     """components that run from global memory get a workgroup each when there
@@ -949,3 +990,30 @@ def test_team_kernel_for_global_memory_components(case):
     eng0, _ = run_pipeline(g, lds_components=0, team_components=0)
     assert eng0.stat("team_components") == 0
     assert eng.digest() == eng0.digest()
+
+
+def test_bench_verify_small():
+    """bench.py --verify at a small size: the headline line with the secondary workload
+    behind it, the digest compared with the oracle's on the headline graph (ADVICE r03:
+    the block ran after the secondary workload had released the inputs)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--contigs", "60000", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline", "--verify"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["verified_against_oracle"] is True
+    assert out["roofline"]["bound"] == "hbm" and "traffic_is" in out["roofline"]
+
+
+def test_sharded_pipeline_over_rccl_one_rank():
+    """the nccl branch of TorchComm had never executed.  A fresh child
+    process initialises the process group (backend nccl = RCCL, one rank) before it touches
+    the GPU and runs scaffold_sharded with every collective forced: all_reduce MIN / SUM /
+    MAX on int32 and the all_to_all of the packed int64 rows, against the oracle."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(here, "rccl_child.py"), "29531"], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl one rank ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -1,0 +1,55 @@
+"""The component kernels hold no scratch and no spilled vector registers, and the
+dominant one stays under the register count that the launch geometry needs
+(one build of k_components_pool lost vertex states next to 52
+spilled VGPRs and 164 B of scratch per lane; the cause of the spills -- lane-derived
+values hoisted out of the kernel's component loop -- is gone since GtsWave64::lane()
+is opaque, and this test keeps it that way).  Reads the code object's metadata, no GPU."""
+import os
+import re
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+
+
+@pytest.fixture(scope="module")
+def res(tmp_path_factory):
+    from kernel_resources import resources
+    return resources(str(tmp_path_factory.mktemp("isa") / "gts_engine_dev.s"))
+
+
+def kernels(res, pattern):
+    ks = {k: v for k, v in res.items() if re.search(pattern, k)}
+    assert ks, pattern
+    return ks
+
+
+def test_component_kernels_have_no_scratch(res):
+    for name, r in kernels(res, r"k_components(_pool|_fast1|_lds|_team)?11GtsCompView|k_components_fastILi10E|"
+                                r"k_walk_tasks|k_select_walks").items():
+        assert r["vspill"] == 0 and r["scratch"] == 0, (name, r)
+
+
+def test_dominant_kernel_register_budget(res):
+    # one workgroup of 16 wavefronts per CU needs <= 128; the lean program is held to 96
+    # (five wavefronts per SIMD) so that the geometry can change without a rewrite
+    for name, r in kernels(res, r"k_components_fast1").items():
+        assert r["vgpr"] <= 96, (name, r)
+    for name, r in kernels(res, r"k_components_fastILi10E").items():
+        assert r["vgpr"] <= 96, (name, r)
+    for name, r in kernels(res, r"k_components_pool").items():
+        assert r["vgpr"] <= 128, (name, r)
+
+
+def test_write_back_loops_are_not_unrolled():
+    src = open(os.path.join(ROOT, "gt-scaffold_amd", "csrc", "gts_component.hpp")).read()
+    # run(): the loop that writes the vertex states back
+    m = re.search(r"#pragma unroll 1\s*\n\s*for \(uint32_t s = lane; s < nv; s \+= W::WIDTH\) \{\s*\n\s*const uint8_t st = M\.vst\[s\];", src)
+    assert m, "run(): the write-back loop lost its '#pragma unroll 1'"
+    # run_fast(): both write-back loops
+    assert len(re.findall(r"#pragma unroll 1\s*\n\s*for \(uint32_t (s|k) = lane;", src)) >= 3
