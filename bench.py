@@ -516,6 +516,8 @@ def main():
                                                   "why_marked_end", "why_two_directions",
                                                   "why_inexact_tie", "why_cycle",
                                                   "why_inexact_length_tie")},
+                       unclean_batches={k[14:]: eng.stat(k) for k in
+                                        ("unclean_batch_walks", "unclean_batch_given_up", "unclean_batch_cycle")},
                        small={k[6:]: eng.stat(k) for k in
                               ("small_all_live_components", "small_other_components",
                                "small_all_live_removecycles_us", "small_other_removecycles_us")},

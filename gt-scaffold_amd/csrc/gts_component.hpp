@@ -81,6 +81,8 @@ struct GtsCompView {
   int fast_walks;            /* 0: always run the reference's search */
   int batch_walks;           /* LDS-resident clean components: the walks of a cc side by side */
   int small_masks;           /* LDS-resident components of at most 64 contigs: peel_small() */
+  int timing_skip_writeback; /* timing aid: run_fast() does not write its results to the global graph */
+  int local_marks;           /* the LDS programs keep their marks in the working copy (GtsComponent::local_marks) */
   char *team_slab;           /* k_components_team: walk slots and path buffers of the workgroups */
   unsigned long long *team_used;   /* bytes handed out */
   uint64_t *tspan;           /* per component x2 (or null): clock at the start and the end of its program */
@@ -400,6 +402,11 @@ struct GtsComponent {
   bool needs_reference;
   bool deferred_late;   /* makescaffold stopped at a cc and published the rest as tasks */
   bool was_all_live;    /* statistics */
+  /* round 4: the CYCLIC and SCAFFOLD marks of the program stay in the working copy
+     (mark_vertex_cyclic_lds, mark_best_lds) and reach the global graph in one go
+     (flush_local_marks) when the component is done or hands its walks to tasks:
+     no chain of dependent global reads per marked edge in the middle of the program */
+  bool local_marks, any_scaffold_marks;
   /* k_components_team */
   GtsTeamCtl *team;     /* null: no team */
   char *team_base;      /* this workgroup's slab */
@@ -408,7 +415,7 @@ struct GtsComponent {
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), local_marks(false), any_scaffold_marks(false), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -708,6 +715,20 @@ struct GtsComponent {
         }
       }
     }
+  }
+
+  /* the working copy's CYCLIC and SCAFFOLD marks into the global graph (vertex states
+     go with run()'s write-back).  Only ever adds marks: calling it twice is harmless */
+  GTS_HD void flush_local_marks()
+  {
+    const uint32_t lane = W::lane();
+    cyclic_marks_global();
+    if (any_scaffold_marks) {
+#pragma unroll 1
+      for (uint32_t k = lane; k < M.ne; k += W::WIDTH)
+        if ((uint8_t)M.cstate[k] == GIS_SCAFFOLD) C.G.state[C.cgpos[e0g + k]] = GIS_SCAFFOLD;
+    }
+    W::fence();
   }
 
   /* ---- ref algorithms.c:495-578 ----
@@ -2361,7 +2382,14 @@ struct GtsComponent {
       if (bad) active = false;
     }
     /* a cycle among the reachable states (walk_cyclic's case): not here */
-    if (active && qh2 != nr) bad = 1u;
+    const bool cyc = active && qh2 != nr;
+    if (cyc) bad = 1u;
+    if (C.why) {   /* statistics: walks of the batch by outcome */
+      const uint32_t ncyc = W::popc(W::ballot(cyc && a == 0)), nbad = W::popc(W::ballot(bad != 0 && a == 0 && g < nb));
+      if (lane == 0) {
+        W::add64((uint64_t *)C.why + 8, nb); W::add64((uint64_t *)C.why + 9, nbad); W::add64((uint64_t *)C.why + 10, ncyc);
+      }
+    }
     r_len = best_len; r_t = best_t; r_bad = bad != 0;
   }
 
@@ -2792,12 +2820,13 @@ struct GtsComponent {
         if (te - tb == 1) lonesome(W::uni(M.term[tb]));
         if (te - tb > 1) {
           uint64_t cc_len = 0;
-          uint32_t cc_n = 0;
+          uint32_t cc_n = 0, cc_start = 0;
           bool batched = false;
           if constexpr (LDS) {
-            if (clean && C.fast_walks && C.batch_walks && M.wslots >= 2) {
+            if (C.fast_walks && C.batch_walks && M.wslots >= 2 && (clean || C.batch_walks >= 2)) {
               const uint64_t tw0 = W::clock();
-              batched = cc_walks_batched<GTS_WALK_LANES>(tb, te, cc_len, cc_n);
+              batched = clean ? cc_walks_batched<GTS_WALK_LANES>(tb, te, cc_len, cc_n, &cc_start)
+                              : cc_walks_batched_unclean(tb, te, cc_len, cc_n, &cc_start);
               tfast += W::clock() - tw0;
               if (!batched) { cc_len = 0; cc_n = 0; }
             }
@@ -2816,7 +2845,10 @@ struct GtsComponent {
                the usual outcome on a clean chain, whose other end needs no walk */
             if (cc_len == all_bases()) break;
             no_reference = may_late;
-            if (!create_walk(W::uni(M.term[j]), cc_len, cc_n)) break;
+            const uint64_t len0 = cc_len;
+            const uint32_t wstart = W::uni(M.term[j]);
+            if (!create_walk(wstart, cc_len, cc_n)) break;
+            if (cc_len != len0) cc_start = wstart;
             no_reference = false;
             if (needs_reference) {
               /* this walk needs the reference's search: the walks of this cc and
@@ -2827,7 +2859,8 @@ struct GtsComponent {
             }
           }
           if (err || want_defer) break;
-          mark_best(M.cc_best, cc_n);
+          if (local_marks) { if (cc_n) { mark_best_lds(cc_n, cc_start); any_scaffold_marks = true; } }
+          else mark_best(M.cc_best, cc_n);
         }
       }
       if (!want_defer) break;
@@ -2936,6 +2969,8 @@ struct GtsComponent {
       }
       if (!skip) npend += te - tb;
     }
+    /* the tasks and the select pass work on the global graph */
+    if (local_marks) flush_local_marks();
     /* what the tasks and the select pass read (no-op copies when M already
        points into the global arrays) */
     for (uint32_t s = lane; s < nv; s += W::WIDTH) {
@@ -3229,14 +3264,11 @@ struct GtsComponent {
       }
     }
     /* (removecycles alone ends with every unmarked vertex UNVISITED: removecycles_t) */
-    cyclic_marks_global();
+    if (C.timing_skip_writeback) return true;
+    any_scaffold_marks = marks;
+    flush_local_marks();
 #pragma unroll 1
     for (uint32_t s = lane; s < nv; s += W::WIDTH) C.G.vstate[C.slot_v[s0 + s]] = M.vst[s];
-    if (marks) {
-#pragma unroll 1
-      for (uint32_t k = lane; k < M.ne; k += W::WIDTH)
-        if ((uint8_t)M.cstate[k] == GIS_SCAFFOLD) C.G.state[C.cgpos[e0g + k]] = GIS_SCAFFOLD;
-    }
     if (timed && lane == 0) {
       const uint64_t t2 = W::clock();
       C.stat_fast[c] = nfast; C.stat_ncc[c] = ncc; C.stat_clean[c] = (clean ? 1u : 0u) | (nterm << 8);
@@ -3251,7 +3283,8 @@ struct GtsComponent {
   {
     const uint32_t lane = W::lane();
     const uint64_t t0 = W::clock();
-    removecycles(mode == GTS_MODE_MAKESCAFFOLD);
+    if (local_marks) removecycles_t<true>(mode == GTS_MODE_MAKESCAFFOLD);
+    else removecycles(mode == GTS_MODE_MAKESCAFFOLD);
     reuse_cc = clean;   /* the terminal search of the last pass is makescaffold's */
     const uint64_t t1 = W::clock();
     if (C.small_stat && nv <= 64 && lane == 0) {
@@ -3265,6 +3298,7 @@ struct GtsComponent {
       deferred = deferred_late;
     }
     const uint64_t t2 = W::clock();
+    if (local_marks) flush_local_marks();
     /* (not unrolled: an eight-fold copy hipcc 7.2 made of this loop inside
        k_components_pool -- lane-dependent trip count, address registers spilled
        around it -- left the states of the slots past the first 64 of a large

@@ -147,11 +147,19 @@ struct GtsgEngine {
   int64_t pool_components = 1;        /* all LDS components in one launch (k_components_pool) */
   int64_t pool_waves = GTS_POOL_WAVES; /* wavefronts per workgroup of that launch */
   int64_t pool_fill_kb = 4;            /* the pool's fill cursor starts at the components of at most this footprint */
-  /* round 4: clean components on k_components_fast (two workgroups of fast_waves
-     wavefronts per CU), everything else -- and what that program hands over -- on
-     cold_cus workgroups of the full program next to it */
-  int64_t fast_components = 1, fast_waves = GTS_FAST_WAVES, cold_cus = 8;
-  int64_t fast_split = 0;   /* two workgroups with half a pool each per CU; 0: one with the whole pool */
+  /* round 4, measured and not the default: a lean program (no reference search, no
+     task tables: 89 VGPRs, or 96 on two workgroups of fast_waves wavefronts per CU
+     with half a pool each -- fast_split) on k_components_fast, and what it cannot
+     finish handed to cold_cus workgroups of the full program next to it.  With the
+     same walk code the full program on one workgroup per CU is as fast on the
+     headline graph (10.2 ms either way: the launch is bound by LDS x time, not by
+     registers or wavefronts) and faster wherever components are handed over (a
+     component that needs the reference's search is found out late and starts
+     again: 124 against 117 ms on the inversions workload) */
+  int64_t fast_components = 0, fast_waves = GTS_FAST_WAVES, cold_cus = 8;
+  int64_t fast_split = 0;
+  int64_t local_marks = 1;   /* LDS programs keep their CYCLIC / SCAFFOLD marks in the working copy until they are done */
+  int64_t timing_skip_writeback = 0;   /* timing aid (results are wrong): what the scattered write-back of the fast program costs */   /* two workgroups with half a pool each per CU; 0: one with the whole pool */
   int64_t gather_unroll = 4;           /* edges a thread of the gather-shaped build kernels (1: A/B measurements) */
   int64_t lds_poison = -1;             /* test aid: fill a component's pages with this byte before staging */
   int64_t pool_wait_limit_us = 10000000; /* bound of every wait inside that launch (0: test aid, a wait gives up at once) */
@@ -161,7 +169,7 @@ struct GtsgEngine {
      (walks_clean_batch); from batch_big_contigs contigs on a component asks for
      LDS for batch_big_slots walk slots */
   int64_t batch_walks = 2, batch_big_contigs = 64, batch_big_slots = 3;
-  int64_t batch_huge_contigs = 256, batch_huge_slots = 8;   /* second tier: the launch's longest programs */
+  int64_t batch_huge_contigs = 256, batch_huge_slots = 5;   /* second tier: the launch's longest programs */
   int64_t lds_int16_distances = 1;   /* packed layout: int16 distances for components whose distances all fit */
   int64_t small_masks = 1;   /* topological order of components of at most 64 contigs on bit masks (peel_small) */
   /* walks of global-memory components fan out only on request: the components
@@ -879,7 +887,11 @@ __global__ void k_live_union(GtsGraphView G, const uint32_t *estart,
   const bool lv = !gts_edge_is_marked(G.state[p]);
   /* an edge enters the compact graph if it or its twin is live: marking a walk
      edge's twin SCAFFOLD (algorithms.c:842-845) revives a marked twin.  The
-     twin is looked up only for an edge that is not live itself. */
+     twin is looked up only for an edge that is not live itself.  (Round 4, tried
+     the other way round -- a live edge sets its own flag and its twin's, no
+     look-up by the others: 2.31 -> 3.1 ms; a random byte store costs a sector
+     read and a write-back, and the live edges' stores cost more than the dead
+     edges' reads.) */
   incl[p] = lv ? 1 : !gts_edge_is_marked(G.state[G.twin[p]]) ? 1 : 0;
   if (!lv) return;
   /* (which vertices have a live edge at either end is read off the forest
@@ -1762,8 +1774,10 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-      } else
+      } else {
+        prog.local_marks = C.local_marks != 0;
         prog.run(A.mode);
+      }
       if (lane == 0) atomicAdd(&ctl->t_run, (unsigned long long)(GtsWave64::clock() - tr0));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1818,7 +1832,7 @@ k_components_pool(GtsCompView C, GtsPoolArgs A)
    the launch is bound by LDS x time, the page waits triple */
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * GTS_WAVE, (2 * WAVES + 3) / 4)
-k_components_fast(GtsCompView C, GtsPoolArgs A)
+k_components_fast2(GtsCompView C, GtsPoolArgs A)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ GtsPoolCtl ctl_s;
@@ -1827,7 +1841,7 @@ k_components_fast(GtsCompView C, GtsPoolArgs A)
 /* the same program on one workgroup per CU with the whole pool (the launch is
    bound by LDS x time: one pool packs better than two halves) */
 __global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
-k_components_fast1(GtsCompView C, GtsPoolArgs A)
+k_components_fast(GtsCompView C, GtsPoolArgs A)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ GtsPoolCtl ctl_s;
@@ -2124,8 +2138,8 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
   if (!rc && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
   const void *big_lds[] = {(const void *)k_walk_tasks_mixed, (const void *)k_walk_tasks,
                            (const void *)k_components_lds,
-                           (const void *)k_components_pool, (const void *)k_components_fast<GTS_FAST_WAVES>,
-                           (const void *)k_components_fast1,
+                           (const void *)k_components_pool, (const void *)k_components_fast2<GTS_FAST_WAVES>,
+                           (const void *)k_components_fast,
                            (const void *)k_components_team};
   {
     int cus = 0;
@@ -2203,6 +2217,8 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "pool_fill_kb") && value >= 0) e->pool_fill_kb = value;
   else if (!strcmp(name, "fast_components")) e->fast_components = value != 0;
   else if (!strcmp(name, "fast_split")) e->fast_split = value != 0;
+  else if (!strcmp(name, "local_marks")) e->local_marks = value != 0;
+  else if (!strcmp(name, "timing_skip_writeback")) e->timing_skip_writeback = value != 0;
   else if (!strcmp(name, "fast_waves") && value >= 1 && value <= GTS_FAST_WAVES) e->fast_waves = value;
   else if (!strcmp(name, "cold_cus") && value >= 1 && value <= 255) e->cold_cus = value;
   else if (!strcmp(name, "pool_wait_limit_us") && value >= 0) e->pool_wait_limit_us = value;
@@ -3071,6 +3087,7 @@ static int run_components(GtsgEngine *e, int mode)
     C.wq_pool = wq_pool; C.wq_factor = (uint64_t)factor;
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
     C.fast_walks = (int)e->fast_walks; C.batch_walks = (int)e->batch_walks; C.small_masks = (int)e->small_masks;
+    C.timing_skip_writeback = (int)e->timing_skip_writeback; C.local_marks = (int)e->local_marks;
     C.nd = s_nd;
     C.team_slab = nullptr; C.team_used = nullptr; C.team_cap = 0; C.team_stat = nullptr;
     C.small_stat = nullptr; C.tspan = nullptr;
@@ -3101,7 +3118,7 @@ static int run_components(GtsgEngine *e, int mode)
     C.tq_base = e->d_scalars + GTS_S_TQBASE; C.tq_cnt = (unsigned long long *)(e->d_scalars + GTS_S_TQCNT);
     C.defer_list = defer_list; C.ndeferred = (unsigned long long *)(e->d_scalars + GTS_S_NDEF);
     C.why = (unsigned long long *)(e->d_scalars + 96);
-    HIPCHK(hipMemsetAsync(C.why, 0, 64, e->st));
+    HIPCHK(hipMemsetAsync(C.why, 0, 96, e->st));   /* [8..10]: walks_fast_batch: walks, given up, of them for a cycle */
     {
       /* order[] is sorted by decreasing footprint: the global-memory class
          (larger than every LDS class, or all if LDS is disabled) comes first,
@@ -3219,8 +3236,8 @@ static int run_components(GtsgEngine *e, int mode)
           GtsPoolArgs FA = CA;
           FA.pstat = fstat;
           if (e->profile) hipEventRecord(_a, ss);
-          if (!e->fast_split) k_components_fast1<<<fast_wgs, (uint32_t)e->pool_waves * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, FA);
-          else k_components_fast<GTS_FAST_WAVES><<<fast_wgs, (uint32_t)e->fast_waves * GTS_WAVE, GTS_FAST_BYTES, ss>>>(C, FA);
+          if (!e->fast_split) k_components_fast<<<fast_wgs, (uint32_t)e->pool_waves * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, FA);
+          else k_components_fast2<GTS_FAST_WAVES><<<fast_wgs, (uint32_t)e->fast_waves * GTS_WAVE, GTS_FAST_BYTES, ss>>>(C, FA);
           if (e->profile) { hipEventRecord(_b, ss);
                             e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_fast"
                                                                                 : "components_removecycles_fast",
@@ -3383,8 +3400,8 @@ static int run_components(GtsgEngine *e, int mode)
              (unsigned long long *)(e->d_scalars + 32));
     uint64_t ts[8];
     HIPCHK(hipMemcpyAsync(ts, e->d_scalars + 32, 64, hipMemcpyDeviceToHost, e->st));
-    uint64_t why[8];
-    HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 64, hipMemcpyDeviceToHost, e->st));
+    uint64_t why[12];
+    HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 96, hipMemcpyDeviceToHost, e->st));
     uint64_t pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 80, hipMemcpyDeviceToHost, e->st));
     uint64_t fst[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -3565,6 +3582,9 @@ static int run_components(GtsgEngine *e, int mode)
                                   "why_marked_end", "why_two_directions", "why_inexact_tie",
                                   "why_cycle", "why_inexact_length_tie"};
       for (int k = 0; k < 8; ++k) e->stats[wn[k]] = (int64_t)why[k];
+      e->stats["unclean_batch_walks"] = (int64_t)why[8];
+      e->stats["unclean_batch_given_up"] = (int64_t)why[9];
+      e->stats["unclean_batch_cycle"] = (int64_t)why[10];
     }
     /* (the fast program counts in its own words unless the detailed profile made
        it write the per-component tables the sums above are taken from) */

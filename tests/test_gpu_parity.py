@@ -1017,3 +1017,13 @@ def test_sharded_pipeline_over_rccl_one_rank():
     r = subprocess.run([sys.executable, os.path.join(here, "rccl_child.py"), "29531"], capture_output=True,
                        text=True, timeout=600, env=env)
     assert r.returncode == 0 and "rccl one rank ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_lean_program_with_cold_list(split):
+    """the alternative launch geometry of round 4 (not the default): k_components_fast runs the
+    lean program, components that need the reference's search or task deferral go through the
+    cold list to workgroups of the full program; with fast_split two half-pool workgroups per CU"""
+    g = make_inputs(6000, 33, p_chimeric=0.1, p_bubble=0.05, p_relist_flip=0.1)
+    eng, _ = run_pipeline(g, fast_components=1, fast_split=split, cold_cus=4)
+    assert eng.stat("fast_kernel") == 1 and eng.stat("fast_components_done") > 0
