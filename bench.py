@@ -497,7 +497,7 @@ def main():
                        components_global_mem=eng.stat("components_global_mem"),
                        pool={k[5:]: eng.stat(k) for k in
                              ("pool_us_sum_run", "pool_us_sum_wait_pages", "pool_us_sum_wave_life",
-                              "pool_us_first_exit", "pool_us_last_exit")},
+                              "pool_us_first_exit", "pool_us_last_exit", "pool_helper_joins", "pool_us_sum_helping")},
                        fast={k: eng.stat(k) for k in
                              ("fast_kernel", "fast_wavefronts", "fast_components_done", "fast_components_handed_over",
                               "fast_us_sum_run", "fast_us_sum_wait_pages", "fast_us_sum_claim", "fast_us_sum_wave_life",

@@ -83,6 +83,7 @@ struct GtsCompView {
   int small_masks;           /* LDS-resident components of at most 64 contigs: peel_small() */
   int timing_skip_writeback; /* timing aid: run_fast() does not write its results to the global graph */
   int local_marks;           /* the LDS programs keep their marks in the working copy (GtsComponent::local_marks) */
+  int help_walks;            /* k_components_pool: jobs for the walks that are made one by one (GtsHelpJob) */
   char *team_slab;           /* k_components_team: walk slots and path buffers of the workgroups */
   unsigned long long *team_used;   /* bytes handed out */
   uint64_t *tspan;           /* per component x2 (or null): clock at the start and the end of its program */
@@ -315,6 +316,44 @@ struct GtsCompMemT {
 };
 typedef GtsCompMemT<false> GtsCompMem;
 
+/* ---- walks of a cc over the wavefronts of the workgroup (round 4) ------------------
+   The walks of a cc are independent (ref algorithms.c:809-832).  Where they cannot be
+   swept side by side on one wavefront -- a component that is not clean and whose
+   reachable states hold a cycle (walk_cyclic: four traversals a walk), a tie without a
+   closed form -- they were made one after the other: 45 walks of a 380-contig component
+   took 8 of the launch's 10.4 ms, a few components of 50 - 170 contigs claimed late set
+   its last millisecond.  In k_components_pool the wavefronts of a workgroup share the
+   component's LDS, so the owner opens a JOB in the workgroup's control block: wavefronts
+   that are between components (or have none left to claim) take terminals off a counter,
+   walk with scratch of their own (pages of the pool) on the owner's graph, and leave
+   their best walk; the owner takes the first strictly longest in terminal order
+   (algorithms.c:826-832), copies its path and closes the job.  One job per workgroup at a
+   time; an owner that finds the slot taken, or nobody to help, walks alone as before. */
+#define GTS_HUB_WAVES 16
+#if defined(__HIPCC__)
+struct GtsHelpJob {
+  uint32_t seq;            /* odd: a job is open; changes when it closes */
+  uint32_t ready;          /* = seq once the fields below are filled */
+  uint32_t comp, tb, te, clean, nv;
+  uint32_t next;           /* next terminal (index into term[]) */
+  uint32_t active;         /* participants that may still write results */
+  uint32_t need_ref;       /* a walk needs the reference's search: the owner starts over, alone */
+  uint32_t walks;          /* statistics */
+  uint32_t n_running;      /* wavefronts of the workgroup inside a component program (they may open jobs) */
+  unsigned long long best_len[GTS_HUB_WAVES];
+  uint32_t best_j[GTS_HUB_WAVES], best_n[GTS_HUB_WAVES], best_start[GTS_HUB_WAVES];
+  uint32_t best_path[GTS_HUB_WAVES];   /* LDS address of the participant's cc_best */
+  GtsCompMemT<true> M;     /* the owner's view of the component */
+};
+#else
+struct GtsHelpJob {      /* (host harness: never used, the fields are there for the parser) */
+  uint32_t seq, ready, comp, tb, te, clean, nv, next, active, need_ref, walks, n_running;
+  unsigned long long best_len[GTS_HUB_WAVES];
+  uint32_t best_j[GTS_HUB_WAVES], best_n[GTS_HUB_WAVES], best_start[GTS_HUB_WAVES], best_path[GTS_HUB_WAVES];
+  int M;
+};
+#endif
+
 /* LDS bytes needed to stage a component in the packed layout (every array
    16-byte aligned) */
 GTS_HD uint32_t gts_comp_lds_bytes(uint32_t nv, uint32_t ne, bool d32 = true)
@@ -407,6 +446,8 @@ struct GtsComponent {
      (flush_local_marks) when the component is done or hands its walks to tasks:
      no chain of dependent global reads per marked edge in the middle of the program */
   bool local_marks, any_scaffold_marks;
+  GtsHelpJob *hub;      /* k_components_pool: the workgroup's job slot (or null) */
+  uint32_t hub_me;      /* this wavefront's index in the workgroup (its result entry of the job) */
   /* k_components_team */
   GtsTeamCtl *team;     /* null: no team */
   char *team_base;      /* this workgroup's slab */
@@ -415,7 +456,7 @@ struct GtsComponent {
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), local_marks(false), any_scaffold_marks(false), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), local_marks(false), any_scaffold_marks(false), hub(nullptr), hub_me(0), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1) {}
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -2758,6 +2799,99 @@ struct GtsComponent {
     return true;
   }
 
+  /* a participant's share of the open job: terminals off the counter, walked one by one
+     on this program's scratch; its best walk (first strictly longest of its own, in the
+     order it took them = terminal order) into the job */
+  GTS_HD void hub_take_walks(GtsHelpJob *J, uint32_t te)
+  {
+    if constexpr (LDS && W::WIDTH == 64) {
+      const uint32_t lane = W::lane(), me = hub_me;
+      uint64_t my_len = 0;
+      uint32_t my_n = 0, my_j = GTS_NONE, my_start = 0, made = 0;
+      for (;;) {
+        uint32_t j = 0;
+        if (lane == 0) j = W::hub_add(&J->next, 1u);
+        j = W::uni(j);
+        if (j >= te) break;
+        if (my_len == all_bases()) continue;        /* nothing can be strictly longer */
+        const uint64_t len0 = my_len;
+        const uint32_t start = W::uni(M.term[j]);
+        no_reference = true;
+        create_walk(start, my_len, my_n);
+        ++made;
+        if (needs_reference) { needs_reference = false; if (lane == 0) W::hub_store(&J->need_ref, 1u); break; }
+        if (my_len != len0) { my_j = j; my_start = start; }
+      }
+      if (lane == 0) {
+        J->best_len[me] = my_len; J->best_j[me] = my_j; J->best_n[me] = my_n; J->best_start[me] = my_start;
+        J->best_path[me] = W::lds_addr(&M.cc_best[0]);
+        if (made) W::hub_add(&J->walks, made);
+      }
+      W::fence();
+    }
+  }
+
+  /* the owner's side: opens a job for the cc [tb, te) if the slot is free (0: it is not) */
+  GTS_HD uint32_t hub_open(uint32_t tb, uint32_t te)
+  {
+    if constexpr (LDS && W::WIDTH == 64) {
+      GtsHelpJob *J = hub;
+      uint32_t s = 0;
+      if (W::lane() == 0) {
+        s = W::hub_load(&J->seq);
+        if (!(s & 1u) && W::hub_cas(&J->seq, s, s + 1u) == s) {
+          J->comp = c; J->tb = tb; J->te = te; J->clean = clean ? 1u : 0u; J->nv = nv;
+          J->next = tb; J->active = 0; J->need_ref = 0;
+          for (uint32_t w = 0; w < GTS_HUB_WAVES; ++w) { J->best_j[w] = GTS_NONE; J->best_len[w] = 0; J->best_n[w] = 0; }
+          J->M = M;
+          W::hub_release();
+          W::hub_store(&J->ready, s + 1u);
+          s = s + 1u;
+        } else
+          s = 0;
+      }
+      return W::uni(s);
+    } else
+      return 0;
+  }
+  /* ... and closes it: waits for the participants (they finish: a walk waits for
+     nothing), takes the first strictly longest walk in terminal order over its own
+     (cc_len, cc_n, cc_start, cc_j: in M.cc_best) and theirs, copies a helper's path.
+     False: a walk needs the reference's search -- nothing is kept, the caller starts the
+     cc over, alone */
+  GTS_HD bool hub_finish(uint32_t s, uint64_t &cc_len, uint32_t &cc_n, uint32_t &cc_start, uint32_t cc_j)
+  {
+    if constexpr (LDS && W::WIDTH == 64) {
+      typedef typename GtsCompMemT<LDS>::idx_t idx_t;
+      GtsHelpJob *J = hub;
+      const uint32_t lane = W::lane();
+      if (lane == 0) while (W::hub_load(&J->active) != 0) W::nap();
+      W::hub_acquire();
+      W::fence();
+      uint64_t best = cc_len;
+      uint32_t bj = cc_n ? cc_j : GTS_NONE, bw = GTS_NONE;
+      for (uint32_t w = 0; w < GTS_HUB_WAVES; ++w) {
+        const uint32_t j = W::uni(W::hub_load(&J->best_j[w]));
+        const uint64_t len = (uint64_t)W::uni64((int64_t)J->best_len[w]);
+        if (j != GTS_NONE && len != 0 && (len > best || (len == best && j < bj))) { best = len; bj = j; bw = w; }
+      }
+      const bool redo = W::uni(W::hub_load(&J->need_ref)) != 0;
+      if (!redo && bw != GTS_NONE) {
+        const uint32_t n = W::uni(W::hub_load(&J->best_n[bw]));
+        const idx_t __attribute__((address_space(3))) *src =
+            (const idx_t __attribute__((address_space(3))) *)(uintptr_t)W::uni(W::hub_load(&J->best_path[bw]));
+        for (uint32_t k = lane; k < n; k += W::WIDTH) M.cc_best[k] = src[k];
+        cc_len = best; cc_n = n; cc_start = W::uni(W::hub_load(&J->best_start[bw]));
+      }
+      nfast += W::uni(W::hub_load(&J->walks));
+      W::fence();
+      /* close: the helpers give their pages back (the winner's path has been copied) */
+      if (lane == 0) { W::hub_store(&J->walks, 0u); W::hub_release(); W::hub_store(&J->seq, s + 1u); }
+      return !redo;
+    } else
+      return true;
+  }
+
   GTS_HD bool create_walk(uint32_t start, uint64_t &cc_len, uint32_t &cc_n)
   {
     /* (the reference's test for a start without any edge, algorithms.c:655,
@@ -2839,23 +2973,49 @@ struct GtsComponent {
               if (!batched) { cc_len = 0; cc_n = 0; }
             }
           }
-          for (uint32_t j = tb; j < te && !batched; ++j) {
-            /* a walk is a simple path inside the component: none can be STRICTLY
-               longer (algorithms.c:826) than one that holds every contig of it --
-               the usual outcome on a clean chain, whose other end needs no walk */
-            if (cc_len == all_bases()) break;
-            no_reference = may_late;
-            const uint64_t len0 = cc_len;
-            const uint32_t wstart = W::uni(M.term[j]);
-            if (!create_walk(wstart, cc_len, cc_n)) break;
-            if (cc_len != len0) cc_start = wstart;
-            no_reference = false;
-            if (needs_reference) {
-              /* this walk needs the reference's search: the walks of this cc and
-                 of the ccs after it become tasks */
-              needs_reference = false;
-              want_defer = true; forced = true; i0 = i;
-              break;
+          /* the walks one by one; over the workgroup's wavefronts when there is a job slot
+             (GtsHelpJob): the terminals then come off the job's counter, whoever passes
+             by takes some, and hub_finish picks the cc's walk over all of them.  (One
+             call of create_walk for both ways: its body is the bulk of the kernel.) */
+          uint32_t job = 0;
+          if constexpr (LDS && W::WIDTH == 64) {
+            if (!batched && hub && C.fast_walks && local_marks && te - tb >= 3) job = hub_open(tb, te);
+          }
+          for (int attempt = 0; attempt < 2 && !batched; ++attempt) {
+            uint32_t jn = tb, cc_j = GTS_NONE;
+            bool job_ref = false;
+            for (;;) {
+              uint32_t j = jn++;
+              if constexpr (LDS && W::WIDTH == 64) {
+                if (job) { j = 0; if (W::lane() == 0) j = W::hub_add(&hub->next, 1u); j = W::uni(j); }
+              }
+              if (j >= te) break;
+              /* a walk is a simple path inside the component: none can be STRICTLY
+                 longer (algorithms.c:826) than one that holds every contig of it --
+                 the usual outcome on a clean chain, whose other end needs no walk */
+              if (cc_len == all_bases()) { if (job) continue; break; }
+              no_reference = may_late || job != 0;
+              const uint64_t len0 = cc_len;
+              const uint32_t wstart = W::uni(M.term[j]);
+              if (!create_walk(wstart, cc_len, cc_n)) break;
+              if (cc_len != len0) { cc_start = wstart; cc_j = j; }
+              no_reference = false;
+              if (needs_reference) {
+                needs_reference = false;
+                if (job) { job_ref = true; break; }
+                /* this walk needs the reference's search: the walks of this cc and
+                   of the ccs after it become tasks */
+                want_defer = true; forced = true; i0 = i;
+                break;
+              }
+            }
+            if (!job) break;
+            if constexpr (LDS && W::WIDTH == 64) {
+              if (job_ref && W::lane() == 0) W::hub_store(&hub->need_ref, 1u);
+              const bool kept = hub_finish(job, cc_len, cc_n, cc_start, cc_j);
+              job = 0;
+              if (kept) break;
+              cc_len = 0; cc_n = 0;      /* once more, alone: the second pass handles the reference search */
             }
           }
           if (err || want_defer) break;
@@ -2992,7 +3152,7 @@ struct GtsComponent {
       C.comp_ncc[c] = ncc;
       C.comp_nterm[c] = nterm;
       C.comp_next_cc[c] = first_cc;
-      C.comp_ring[2 * (uint64_t)c] = 0; C.comp_ring[2 * (uint64_t)c + 1] = 0;
+      /* (comp_ring[2c], [2c + 1] are zero: the host clears the table before the launch) */
     }
     const uint64_t dl = W::alloc(C.ndeferred, 1);
     if (lane == 0) C.defer_list[dl] = c;

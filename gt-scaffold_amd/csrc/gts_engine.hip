@@ -67,6 +67,7 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_S_TEAMSTAT 432 /* 8 x u64: statistics of k_components_team */
 #define GTS_S_SMALLSTAT 448 /* 4 x u64: small components by "all edges live" */
 #define GTS_S_COLD 464      /* 8 x u64: the cold list's words (GTS_COLD_*) */
+#define GTS_S_VIEW 2048     /* byte offset 8192: the GtsCompView of the pool kernels (d_scalars holds 16 KB) */
 #define GTS_S_FASTSTAT 480  /* 16 x u64: statistics of k_components_fast (as GTS_S_POOLSTAT, + [10..12]) */
 
 static const char *klass_event(int makescaffold, uint32_t bytes)
@@ -158,6 +159,7 @@ struct GtsgEngine {
      again: 124 against 117 ms on the inversions workload) */
   int64_t fast_components = 0, fast_waves = GTS_FAST_WAVES, cold_cus = 8;
   int64_t fast_split = 0;
+  int64_t help_walks = 1;    /* k_components_pool: walks of a cc that have to be made one by one go over the workgroup's wavefronts (GtsHelpJob) */
   int64_t local_marks = 1;   /* LDS programs keep their CYCLIC / SCAFFOLD marks in the working copy until they are done */
   int64_t timing_skip_writeback = 0;   /* timing aid (results are wrong): what the scattered write-back of the fast program costs */   /* two workgroups with half a pool each per CU; 0: one with the whole pool */
   int64_t gather_unroll = 4;           /* edges a thread of the gather-shaped build kernels (1: A/B measurements) */
@@ -1091,7 +1093,9 @@ struct GtsWave64 {
      whole launch -- twenty of them in k_components_fast */
   static __device__ __forceinline__ uint32_t lane()
   {
-    uint32_t l = threadIdx.x & 63u;
+    /* from the hardware (set bits of an all-ones mask below this lane), not from
+       threadIdx.x: that register would have to stay live for the whole kernel */
+    uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(l));
     return l;
   }
@@ -1151,6 +1155,21 @@ struct GtsWave64 {
   }
   template <class P> static __device__ __forceinline__ uint32_t atomic_max(P p, uint32_t v)
   { return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  /* the workgroup's job slot (GtsHelpJob, in LDS): words other wavefronts of the
+     workgroup read and write */
+  static __device__ __forceinline__ uint32_t hub_add(uint32_t *p, uint32_t v)
+  { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  static __device__ __forceinline__ uint32_t hub_cas(uint32_t *p, uint32_t expect, uint32_t v)
+  { __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return expect; }
+  static __device__ __forceinline__ uint32_t hub_load(const uint32_t *p)
+  { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  static __device__ __forceinline__ void hub_store(uint32_t *p, uint32_t v)
+  { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+  static __device__ __forceinline__ void hub_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+  static __device__ __forceinline__ void hub_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+  static __device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(8); }
+  template <class T> static __device__ __forceinline__ uint32_t lds_addr(T __attribute__((address_space(3))) *p)
+  { return (uint32_t)(uintptr_t)p; }
   /* lane 0 takes n entries from the pool, every lane gets the offset */
   static __device__ __forceinline__ uint64_t alloc(unsigned long long *used, uint64_t n)
   {
@@ -1413,6 +1432,8 @@ struct GtsPoolCtl {
   unsigned long long t_run, t_wait, t_life, t_claim;
   unsigned long long n_done, n_walks, n_cold, b_done_bytes, b_cold_bytes;
   unsigned long long t_begin[GTS_POOL_WAVES];
+  unsigned long long n_helped, t_helping;   /* statistics: joins of an open job, ticks spent there */
+  GtsHelpJob job;          /* walks of a cc over the workgroup's wavefronts (gts_component.hpp) */
 };
 /* the page bitmap as one integer (bit q = page q in use) */
 typedef unsigned __int128 gts_pool_bits;
@@ -1535,13 +1556,74 @@ __device__ __forceinline__ GtsPoolCtl *pool_ctl_opaque(GtsPoolCtl *p)
   return (GtsPoolCtl *)(lds_ctl)(uintptr_t)a;
 }
 
+/* scratch of a wavefront that walks for another one's component (GtsHelpJob): what
+   create_walk_clean / create_walk_fast / walk_cyclic write -- labels, tree lengths,
+   edgemap, parents, integer labels, three queues, degrees, depths, the best path,
+   strands and dirty flags: 30 bytes a contig */
+__device__ __forceinline__ uint32_t help_scratch_bytes(uint32_t nv)
+{
+  const uint32_t p4 = ((nv * 4u + 15u) / 16u) * 16u, p2 = ((nv * 2u + 15u) / 16u) * 16u, p1 = ((nv + 15u) / 16u) * 16u;
+  return 3u * p4 + 8u * p2 + 2u * p1;
+}
+/* the owner's view with the scratch arrays replaced by the helper's own */
+__device__ __forceinline__ void help_view(const GtsHelpJob *J, char *scratch, GtsCompMemT<true> &M)
+{
+  typedef GtsCompMemT<true>::idx_t idx_t;
+  M = J->M;
+  /* wave-uniform again (the copy came through vector loads) */
+#define GTS_UNI_PTR(f) M.f = (decltype(M.f))(uintptr_t)GtsWave64::uni((uint32_t)(uintptr_t)M.f)
+  GTS_UNI_PTR(coff); GTS_UNI_PTR(cend); GTS_UNI_PTR(cdist); GTS_UNI_PTR(cdist16); GTS_UNI_PTR(cseq); GTS_UNI_PTR(vst);
+  GTS_UNI_PTR(term); GTS_UNI_PTR(ccoff); GTS_UNI_PTR(gorient); GTS_UNI_PTR(topo); GTS_UNI_PTR(tpos);
+  GTS_UNI_PTR(cflags.b); GTS_UNI_PTR(cstate.b); GTS_UNI_PTR(cstart.coff);
+#undef GTS_UNI_PTR
+  M.nv = GtsWave64::uni(M.nv); M.ne = GtsWave64::uni(M.ne); M.e0 = GtsWave64::uni(M.e0);
+  M.cstart.nv = M.nv; M.d16 = GtsWave64::uni((uint32_t)M.d16) != 0;
+  const uint32_t nv = M.nv;
+  gts_lds_cursor p = (gts_lds_cursor)scratch;
+  M.distmap = lds_carve<float>(p, nv); M.plen = lds_carve<uint32_t>(p, nv); M.nd = lds_carve<int32_t>(p, nv);
+  M.edgemap = lds_carve<idx_t>(p, nv); M.par = lds_carve<idx_t>(p, nv); M.queue = lds_carve<idx_t>(p, nv);
+  M.visited = lds_carve<idx_t>(p, nv); M.st_v = lds_carve<idx_t>(p, nv); M.wterm = lds_carve<idx_t>(p, nv);
+  M.st_par = lds_carve<idx_t>(p, nv); M.cc_best = lds_carve<idx_t>(p, nv);
+  M.st_dir = lds_carve<uint8_t>(p, nv); M.tight = lds_carve<uint8_t>(p, nv);
+  M.st_cur = M.cc_best; M.touched = M.visited;
+  M.lastpop = (uint32_t __attribute__((address_space(3))) *)M.nd;
+  M.wbase = nullptr; M.wslots = 0; M.sarc = nullptr; M.smid = nullptr;
+  const uint32_t lane = GtsWave64::lane();
+  for (uint32_t i = lane; i < nv; i += GTS_WAVE) { M.distmap[i] = GTS_DIST_UNSET; M.st_dir[i] = 0; M.tight[i] = 0; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+/* The pool kernels take their view as a pointer to a copy in device memory, and read it
+   through a pointer the optimiser cannot see through: the ~100 pointers of a GtsCompView
+   are then loaded where they are used (scalar loads, the scalar cache holds them).  As
+   a by-value kernel argument they are loop invariants of the component loop:
+   they are all loaded at the kernel's entry and kept for the whole launch -- 200 scalar
+   registers more than there are, spilled into the lanes of nine vector registers that
+   every wavefront then carries through every component program. */
+template <class T>
+__device__ __forceinline__ const T &opaque_const(const T *q)
+{
+  typedef const T __attribute__((address_space(4))) *const_ptr;
+  const_ptr p = (const_ptr)q;
+  asm volatile("" : "+s"(p));
+  return *(const T *)p;
+}
+__device__ __forceinline__ const GtsCompView &opaque_view(const GtsCompView *C)
+{
+  typedef const GtsCompView __attribute__((address_space(4))) *const_ptr;   /* not written during the launch */
+  const_ptr p = (const_ptr)C;
+  asm volatile("" : "+s"(p));
+  return *(const GtsCompView *)p;
+}
+
 /* FAST: the clean program on half a CU's pool (k_components_fast); else the full
    program (k_components_pool), which in cold mode (A.cold) claims from the cold
    list instead of the sorted one */
 template <bool FAST, uint32_t PAGES>
-__device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArgs &A, char *smem, GtsPoolCtl *ctl0)
+__device__ __forceinline__ void pool_body(const GtsCompView *C0, const GtsPoolArgs *A0, char *smem, GtsPoolCtl *ctl0)
 {
   GtsPoolCtl *ctl = ctl0;
+  const GtsPoolArgs &A = opaque_const(A0);
   /* pstat (100 MHz ticks, summed over the wavefronts): [0] staging + program,
      [1] waiting for pages, [2] whole life of the wavefront; [3] first exit,
      [4] last exit (since the first wavefront's start, [5]); [6..8] waits that
@@ -1558,21 +1640,89 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
     ctl->lock = 0; ctl->front_busy = 0; ctl->wait_pages = 0;
     ctl->used[0] = ctl->used[1] = ctl->used[2] = ctl->used[3] = 0;
     ctl->f_done = ctl->b_done = 0; ctl->f_last_end = 0; ctl->f_stock = 0; ctl->b_stock = 0;
+    ctl->n_helped = ctl->t_helping = 0;
+    ctl->job.seq = 0; ctl->job.ready = 0; ctl->job.active = 0; ctl->job.n_running = 0; ctl->job.walks = 0;
   }
   __syncthreads();
-  if ((threadIdx.x & (GTS_WAVE - 1u)) == 0) ctl->t_begin[threadIdx.x / GTS_WAVE] = GtsWave64::clock();
+  const uint32_t my_wave = GtsWave64::uni(threadIdx.x / GTS_WAVE);   /* (scalar: threadIdx.x itself is not needed again) */
+  if (GtsWave64::lane() == 0) ctl->t_begin[my_wave] = GtsWave64::clock();
   const bool cold_mode = !FAST && A.cold != nullptr;
   /* the fast kernel's slice starts behind the components seeded to the cold list */
   uint32_t first = A.first, count = A.count, nbig = A.nbig, g0 = A.g0;
   if (A.cold) {
-    const uint32_t ns = (uint32_t)A.cold[GTS_COLD_NSEED];
+    const uint32_t ns = GtsWave64::uni((uint32_t)A.cold[GTS_COLD_NSEED]);   /* (uniform: kept in scalar registers) */
     first += ns; count -= ns;
     nbig = nbig > ns ? nbig - ns : 0u;
     g0 = g0 > ns ? g0 - ns : 0u;
   }
-  const uint32_t lane = threadIdx.x & (GTS_WAVE - 1u);
+  /* joins the workgroup's open job, if there is one with terminals left and the pool has
+     pages for this wavefront's scratch: walks for it, leaves its result, waits for the
+     owner to close (it may copy the path out of these pages) and gives the pages back */
+  auto try_help = [&]() -> bool {
+    if constexpr (FAST) return false;
+    else {
+      const GtsCompView &C = opaque_view(C0);
+      GtsPoolCtl *const ctl = pool_ctl_opaque(ctl0);   /* (its own: through the captured one the accesses turn generic) */
+      GtsHelpJob *J = &ctl->job;
+      /* (the slot's words as LDS words: through the generic pointer every look at them
+         would go through the flat aperture, whose base the compiler then keeps in a
+         vector register for the whole kernel) */
+      typedef GtsHelpJob __attribute__((address_space(3))) *lds_job;
+      const lds_job J3 = (lds_job)J;
+      auto ld = [](const uint32_t __attribute__((address_space(3))) *p) -> uint32_t {
+        return GtsWave64::uni(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); };
+      const uint32_t s = ld(&J3->seq);
+      if (!(s & 1u) || ld(&J3->ready) != s) return false;
+      GtsWave64::hub_acquire();
+      const uint32_t te = ld(&J3->te);
+      if (ld(&J3->next) >= te) return false;
+      const uint32_t hl = GtsWave64::lane();
+      const uint64_t th0 = GtsWave64::clock();
+      const uint32_t hp = (help_scratch_bytes(ld(&J3->nv)) + GTS_POOL_PAGE - 1u) / GTS_POOL_PAGE;
+      uint32_t hpos = GTS_NONE;
+      if (hl == 0 && pool_lock(ctl, pstat, wait_limit)) {      /* one try: no waiting for pages */
+        volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
+        hpos = pool_find(pool_bits_load(v->used), hp, false, v->wait_pages, PAGES);
+        if (hpos != GTS_NONE) pool_bits_set(ctl->used, pool_run_mask(hpos, hp));
+        pool_unlock(ctl);
+        if (hpos != GTS_NONE) {
+          __hip_atomic_fetch_add(&J3->active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          /* (closed, or closed and opened again, meanwhile: not this one) */
+          if (__hip_atomic_load(&J3->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != s) {
+            __hip_atomic_fetch_add(&J3->active, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pool_bits_clear(ctl->used, pool_run_mask(hpos, hp));
+            hpos = GTS_NONE;
+          }
+        }
+      }
+      hpos = GtsWave64::uni(hpos);
+      if (hpos == GTS_NONE) return false;
+      {
+        GtsCompMemT<true> Mh;
+        help_view(J, smem + hpos * GTS_POOL_PAGE, Mh);
+        GtsComponent<GtsWave64, true> hprog(C, Mh, ld(&J3->comp));
+        hprog.clean = ld(&J3->clean) != 0;
+        hprog.hub_me = my_wave;
+        hprog.hub_take_walks(J, te);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (hl == 0) {
+        GtsWave64::hub_release();
+        __hip_atomic_fetch_add(&J3->active, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&J3->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == s) GtsWave64::nap();
+        pool_bits_clear(ctl->used, pool_run_mask(hpos, hp));
+        atomicAdd(&ctl->n_helped, 1ull); atomicAdd(&ctl->t_helping, (unsigned long long)(GtsWave64::clock() - th0));
+      }
+      return true;
+    }
+  };
+  uint32_t lingered = 0;
   for (;;) {
     ctl = pool_ctl_opaque(ctl0);
+    const uint32_t lane = GtsWave64::lane();   /* (inside the loop: nothing derived from it is held across components) */
+    const GtsCompView &C = opaque_view(C0);
+    const GtsPoolArgs &A = opaque_const(A0);   /* (shadows the one the set-up above read) */
+    if (C.help_walks) try_help();
     /* role, claim, pages: lane 0; the rest of the wavefront waits at the broadcast */
     uint32_t idx = GTS_NONE, pos = 0, npages = 0, need = 0, comp = GTS_NONE;
     if (lane == 0) {
@@ -1734,7 +1884,20 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
       }
     }
     idx = GtsWave64::uni(idx);
-    if (idx == GTS_NONE) break;
+    if (idx == GTS_NONE) {
+      /* nothing left to claim: while a wavefront of the workgroup is still inside a
+         program it may open a job -- stay for those (the launch used to end with a few
+         components walking their terminals one by one next to 4000 idle wavefronts).
+         Round the loop again: try_help() is at its top */
+      if constexpr (!FAST) {
+        if (C.help_walks && GtsWave64::uni(GtsWave64::hub_load(&ctl->job.n_running)) != 0 &&
+            (uint64_t)(++lingered) * 64ull < wait_limit) {
+          __builtin_amdgcn_s_sleep(32);
+          continue;
+        }
+      }
+      break;
+    }
     pos = GtsWave64::uni(pos); npages = GtsWave64::uni(npages); need = GtsWave64::uni(need);
     const uint32_t c = GtsWave64::uni(comp);
     /* the components of a workgroup are neighbours in LDS: a word at the end of
@@ -1776,7 +1939,10 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
         }
       } else {
         prog.local_marks = C.local_marks != 0;
+        if (C.help_walks) { prog.hub = &ctl->job; prog.hub_me = my_wave; }
+        if (lane == 0) GtsWave64::hub_add(&ctl->job.n_running, 1u);
         prog.run(A.mode);
+        if (lane == 0) GtsWave64::hub_add(&ctl->job.n_running, 0xFFFFFFFFu);
       }
       if (lane == 0) atomicAdd(&ctl->t_run, (unsigned long long)(GtsWave64::clock() - tr0));
     }
@@ -1791,9 +1957,9 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
     }
   }
   ctl = pool_ctl_opaque(ctl0);
-  if (lane == 0) {
+  if (GtsWave64::lane() == 0) {
     const uint64_t t_end = GtsWave64::clock();
-    const uint64_t t_begin = ctl->t_begin[threadIdx.x / GTS_WAVE];
+    const uint64_t t_begin = ctl->t_begin[my_wave];
     atomicAdd(&ctl->t_life, (unsigned long long)(t_end - t_begin));
     atomicMin(pstat + 5, t_begin);
     atomicMin(pstat + 3, t_end); atomicMax(pstat + 4, t_end);
@@ -1805,6 +1971,7 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
       volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
       atomicAdd(pstat + 0, v->t_run); atomicAdd(pstat + 1, v->t_wait); atomicAdd(pstat + 2, v->t_life);
       if constexpr (FAST) atomicAdd(pstat + 15, v->t_claim);
+      else if (v->n_helped) { atomicAdd(pstat + 10, v->n_helped); atomicAdd(pstat + 11, v->t_helping); }
       if constexpr (FAST) {
         if (v->n_done) { atomicAdd(pstat + 10, v->n_done); atomicAdd(pstat + 11, v->n_walks); atomicAdd(pstat + 13, v->b_done_bytes); }
         if (v->n_cold) { atomicAdd(pstat + 12, v->n_cold); atomicAdd(pstat + 14, v->b_cold_bytes); }
@@ -1819,7 +1986,7 @@ __device__ __forceinline__ void pool_body(const GtsCompView &C, const GtsPoolArg
 }
 
 __global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
-k_components_pool(GtsCompView C, GtsPoolArgs A)
+k_components_pool(const GtsCompView *C, const GtsPoolArgs *A)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ GtsPoolCtl ctl_s;
@@ -1832,7 +1999,7 @@ k_components_pool(GtsCompView C, GtsPoolArgs A)
    the launch is bound by LDS x time, the page waits triple */
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * GTS_WAVE, (2 * WAVES + 3) / 4)
-k_components_fast2(GtsCompView C, GtsPoolArgs A)
+k_components_fast2(const GtsCompView *C, const GtsPoolArgs *A)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ GtsPoolCtl ctl_s;
@@ -1841,7 +2008,7 @@ k_components_fast2(GtsCompView C, GtsPoolArgs A)
 /* the same program on one workgroup per CU with the whole pool (the launch is
    bound by LDS x time: one pool packs better than two halves) */
 __global__ void __launch_bounds__(GTS_POOL_WAVES * GTS_WAVE)
-k_components_fast(GtsCompView C, GtsPoolArgs A)
+k_components_fast(const GtsCompView *C, const GtsPoolArgs *A)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ GtsPoolCtl ctl_s;
@@ -2130,7 +2297,7 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
     e->own_stream = true;
   }
   int rc = 0;
-  if (hipMalloc((void **)&e->d_scalars, 4096) != hipSuccess) rc = GTSG_ENOMEM;
+  if (hipMalloc((void **)&e->d_scalars, 16384) != hipSuccess) rc = GTSG_ENOMEM;
   for (int k = 0; k < GTS_NSTREAMS && !rc; ++k)
     if (hipStreamCreateWithFlags(&e->side[k], hipStreamNonBlocking) != hipSuccess) rc = GTSG_EHIP;
   for (int k = 0; k < GTS_NKLASS && !rc; ++k)
@@ -2218,6 +2385,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "fast_components")) e->fast_components = value != 0;
   else if (!strcmp(name, "fast_split")) e->fast_split = value != 0;
   else if (!strcmp(name, "local_marks")) e->local_marks = value != 0;
+  else if (!strcmp(name, "help_walks")) e->help_walks = value != 0;
   else if (!strcmp(name, "timing_skip_writeback")) e->timing_skip_writeback = value != 0;
   else if (!strcmp(name, "fast_waves") && value >= 1 && value <= GTS_FAST_WAVES) e->fast_waves = value;
   else if (!strcmp(name, "cold_cus") && value >= 1 && value <= 255) e->cold_cus = value;
@@ -3024,6 +3192,7 @@ static int run_components(GtsgEngine *e, int mode)
     PALLOC(task_roff, uint64_t, task_cap); PALLOC(comp_ring, uint64_t, 2 * (size_t)ncomp);
     PALLOC(tq, uint32_t, task_cap + 1); PALLOC(defer_list, uint32_t, (size_t)ncomp + 1);
     HIPCHK(hipMemsetAsync(defer_flag, 0, (size_t)ncomp + 1, e->st));
+    HIPCHK(hipMemsetAsync(comp_ring, 0, 16 * (size_t)ncomp, e->st));   /* no ring yet (try_defer used to store the zeros) */
     HIPCHK(hipMemsetAsync(e->d_scalars + 128, 0, 16, e->st));
     PALLOC(s_gorient, uint8_t, nslots); PALLOC(s_topo, uint32_t, nslots); PALLOC(s_tpos, uint32_t, nslots);
     PALLOC(tstat, uint64_t, 5 * (size_t)ncomp);
@@ -3088,6 +3257,7 @@ static int run_components(GtsgEngine *e, int mode)
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
     C.fast_walks = (int)e->fast_walks; C.batch_walks = (int)e->batch_walks; C.small_masks = (int)e->small_masks;
     C.timing_skip_writeback = (int)e->timing_skip_writeback; C.local_marks = (int)e->local_marks;
+    C.help_walks = (int)e->help_walks;
     C.nd = s_nd;
     C.team_slab = nullptr; C.team_used = nullptr; C.team_cap = 0; C.team_stat = nullptr;
     C.small_stat = nullptr; C.tspan = nullptr;
@@ -3187,12 +3357,16 @@ static int run_components(GtsgEngine *e, int mode)
         HIPCHK(hipStreamWaitEvent(ss, e->ev_fork, 0));
         HIPCHK(hipMemsetAsync(cursor, 0, 8, ss));
         unsigned long long *pstat = (unsigned long long *)(e->d_scalars + GTS_S_POOLSTAT);
-        HIPCHK(hipMemsetAsync(pstat, 0, 80, ss));
+        HIPCHK(hipMemsetAsync(pstat, 0, 96, ss));
         HIPCHK(hipMemsetAsync(pstat + 3, 0xFF, 8, ss));
         HIPCHK(hipMemsetAsync(pstat + 5, 0xFF, 8, ss));
         hipEvent_t _a = nullptr, _b = nullptr;
         if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ss); }
         const uint32_t pw = (uint32_t)e->pool_waves;
+        /* the view as the pool kernels read it: a copy in device memory (opaque_view) */
+        GtsCompView *Cdev = (GtsCompView *)(e->d_scalars + GTS_S_VIEW);
+        HIPCHK(hipMemcpyAsync(Cdev, &C, sizeof(GtsCompView), hipMemcpyHostToDevice, ss));
+        GtsPoolArgs *PAdev = (GtsPoolArgs *)(e->d_scalars + GTS_S_VIEW + 256), *CAdev = PAdev + 1, *FAdev = PAdev + 2;
         GtsPoolArgs PA;
         PA.order = order; PA.order_key = order_key; PA.first = first; PA.count = pooled; PA.mode = mode;
         PA.cursor = cursor; PA.pstat = pstat; PA.nbig = nbig; PA.g0 = g0; PA.poison = (int)e->lds_poison;
@@ -3227,7 +3401,8 @@ static int run_components(GtsgEngine *e, int mode)
           CA.cold = cold; CA.cold_list = cold_list;
           hipEvent_t _c = nullptr, _d = nullptr;
           if (e->profile) { _c = get_event(e); _d = get_event(e); hipEventRecord(_c, cs); }
-          k_components_pool<<<cold_wgs, pw * GTS_WAVE, GTS_POOL_BYTES, cs>>>(C, CA);
+          HIPCHK(hipMemcpyAsync(CAdev, &CA, sizeof CA, hipMemcpyHostToDevice, cs));
+          k_components_pool<<<cold_wgs, pw * GTS_WAVE, GTS_POOL_BYTES, cs>>>(Cdev, CAdev);
           if (e->profile) { hipEventRecord(_d, cs);
                             e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_cold"
                                                                                 : "components_removecycles_cold",
@@ -3236,8 +3411,9 @@ static int run_components(GtsgEngine *e, int mode)
           GtsPoolArgs FA = CA;
           FA.pstat = fstat;
           if (e->profile) hipEventRecord(_a, ss);
-          if (!e->fast_split) k_components_fast<<<fast_wgs, (uint32_t)e->pool_waves * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, FA);
-          else k_components_fast2<GTS_FAST_WAVES><<<fast_wgs, (uint32_t)e->fast_waves * GTS_WAVE, GTS_FAST_BYTES, ss>>>(C, FA);
+          HIPCHK(hipMemcpyAsync(FAdev, &FA, sizeof FA, hipMemcpyHostToDevice, ss));
+          if (!e->fast_split) k_components_fast<<<fast_wgs, (uint32_t)e->pool_waves * GTS_WAVE, GTS_POOL_BYTES, ss>>>(Cdev, FAdev);
+          else k_components_fast2<GTS_FAST_WAVES><<<fast_wgs, (uint32_t)e->fast_waves * GTS_WAVE, GTS_FAST_BYTES, ss>>>(Cdev, FAdev);
           if (e->profile) { hipEventRecord(_b, ss);
                             e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_fast"
                                                                                 : "components_removecycles_fast",
@@ -3246,7 +3422,8 @@ static int run_components(GtsgEngine *e, int mode)
           HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[0], 0));
           HIPCHK(hipStreamWaitEvent(e->st, e->ev_join[2], 0));
         } else {
-        k_components_pool<<<e->n_cus, pw * GTS_WAVE, GTS_POOL_BYTES, ss>>>(C, PA);
+        HIPCHK(hipMemcpyAsync(PAdev, &PA, sizeof PA, hipMemcpyHostToDevice, ss));
+        k_components_pool<<<e->n_cus, pw * GTS_WAVE, GTS_POOL_BYTES, ss>>>(Cdev, PAdev);
         if (e->profile) { hipEventRecord(_b, ss);
                           e->pending.push_back({mode == GTS_MODE_MAKESCAFFOLD ? "components_makescaffold_pool"
                                                                               : "components_removecycles_pool",
@@ -3402,8 +3579,8 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(ts, e->d_scalars + 32, 64, hipMemcpyDeviceToHost, e->st));
     uint64_t why[12];
     HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 96, hipMemcpyDeviceToHost, e->st));
-    uint64_t pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 80, hipMemcpyDeviceToHost, e->st));
+    uint64_t pst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 96, hipMemcpyDeviceToHost, e->st));
     uint64_t fst[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (fast_ran) HIPCHK(hipMemcpyAsync(fst, e->d_scalars + GTS_S_FASTSTAT, 128, hipMemcpyDeviceToHost, e->st));
     uint64_t tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3454,6 +3631,8 @@ static int run_components(GtsgEngine *e, int mode)
       e->stats["pool_us_sum_wave_life"] = (int64_t)(pst[2] / 100);
       e->stats["pool_us_first_exit"] = (int64_t)((pst[3] - pst[5]) / 100);
       e->stats["pool_us_last_exit"] = (int64_t)((pst[4] - pst[5]) / 100);
+      e->stats["pool_helper_joins"] = (int64_t)pst[10];
+      e->stats["pool_us_sum_helping"] = (int64_t)(pst[11] / 100);
     }
     e->stats["fast_kernel"] = fast_ran ? 1 : 0;
     if (fast_ran) {

@@ -228,7 +228,7 @@ uint32_t hs_components(uint32_t n, uint32_t m, const uint32_t *row,
   C.cerr = cerr.data(); C.max_pops = max_pops;
   std::vector<int64_t> nd(S); std::vector<uint64_t> plen(S); std::vector<uint8_t> tight(S, 0);
   std::vector<uint32_t> sf(ncomp ? ncomp : 1, 0), ss(ncomp ? ncomp : 1, 0);
-  C.fast_walks = fast_walks; C.batch_walks = 0; C.small_masks = 0; C.timing_skip_writeback = 0; C.local_marks = 0; C.comp_d32 = nullptr; C.team_slab = nullptr; C.team_used = nullptr; C.team_cap = 0; C.team_stat = nullptr; C.small_stat = nullptr; C.tspan = nullptr; C.nd = nd.data(); C.plen = plen.data(); C.tight = tight.data();
+  C.fast_walks = fast_walks; C.batch_walks = 0; C.small_masks = 0; C.timing_skip_writeback = 0; C.local_marks = 0; C.help_walks = 0; C.comp_d32 = nullptr; C.team_slab = nullptr; C.team_used = nullptr; C.team_cap = 0; C.team_stat = nullptr; C.small_stat = nullptr; C.tspan = nullptr; C.nd = nd.data(); C.plen = plen.data(); C.tight = tight.data();
   std::vector<uint64_t> tstat(5 * (size_t)(ncomp ? ncomp : 1), 0);
   unsigned long long why[8] = {0};
   std::vector<uint8_t> gorient(S); std::vector<uint32_t> topo(S), tpos(S), sclean(ncomp ? ncomp : 1, 0);

@@ -30,7 +30,7 @@ def kernels(res, pattern):
 
 
 def test_component_kernels_have_no_scratch(res):
-    for name, r in kernels(res, r"k_components(_pool|_fast|_lds|_team)?11GtsCompView|k_components_fast2ILi10E|"
+    for name, r in kernels(res, r"k_components(_lds|_team)?11GtsCompView|k_components_(pool|fast)PK11GtsCompView|k_components_fast2ILi10E|"
                                 r"k_walk_tasks|k_select_walks").items():
         assert r["vspill"] == 0 and r["scratch"] == 0, (name, r)
 
@@ -38,11 +38,11 @@ def test_component_kernels_have_no_scratch(res):
 def test_dominant_kernel_register_budget(res):
     # one workgroup of 16 wavefronts per CU needs <= 128; the lean program is held to 96
     # (five wavefronts per SIMD) so that the geometry can change without a rewrite
-    for name, r in kernels(res, r"k_components_fast11GtsCompView").items():
+    for name, r in kernels(res, r"k_components_fastPK11GtsCompView").items():
         assert r["vgpr"] <= 96, (name, r)
     for name, r in kernels(res, r"k_components_fast2ILi10E").items():
         assert r["vgpr"] <= 96, (name, r)
-    for name, r in kernels(res, r"k_components_pool").items():
+    for name, r in kernels(res, r"k_components_poolPK11GtsCompView").items():
         assert r["vgpr"] <= 128, (name, r)
 
 
