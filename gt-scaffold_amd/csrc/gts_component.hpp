@@ -446,6 +446,9 @@ struct GtsComponent {
      (flush_local_marks) when the component is done or hands its walks to tasks:
      no chain of dependent global reads per marked edge in the middle of the program */
   bool local_marks, any_scaffold_marks;
+  bool run_clean, run_deferred;   /* run(): the component was clean after cycle removal / handed its walks to tasks */
+  bool lean_stats;      /* no clocks, no per-component statistics (k_components_pool outside the detailed
+                           profile: the kernel adds nfast / nslow / clean / deferred up itself) */
   GtsHelpJob *hub;      /* k_components_pool: the workgroup's job slot (or null) */
   uint32_t hub_me;      /* this wavefront's index in the workgroup (its result entry of the job) */
   /* k_components_team */
@@ -456,7 +459,10 @@ struct GtsComponent {
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), local_marks(false), any_scaffold_marks(false), hub(nullptr), hub_me(0), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), local_marks(false), any_scaffold_marks(false), run_clean(false), run_deferred(false), lean_stats(false), hub(nullptr), hub_me(0), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1) {}
+
+  /* a clock read costs a wait for every LDS operation in flight: only where somebody looks */
+  GTS_HD uint64_t tick() const { return lean_stats ? 0 : W::clock(); }
 
   /* bases into the global arrays */
   static GTS_HD GtsCompMem global_mem(const GtsCompView &C, uint32_t comp)
@@ -2896,17 +2902,17 @@ struct GtsComponent {
   {
     /* (the reference's test for a start without any edge, algorithms.c:655,
        cannot fire: a vertex is in a component because it has a live edge) */
-    const uint64_t t0 = W::clock();
+    const uint64_t t0 = tick();
     if (C.fast_walks && (clean ? create_walk_clean(start, cc_len, cc_n)
                                : create_walk_fast(start, cc_len, cc_n))) {
-      ++nfast; tfast += W::clock() - t0; return true;
+      ++nfast; tfast += tick() - t0; return true;
     }
-    const uint64_t t1 = W::clock();
+    const uint64_t t1 = tick();
     tfast += t1 - t0;
     if (no_reference) { needs_reference = true; return true; }
     ++nslow;
     const bool ok = create_walk_reference(start, cc_len, cc_n);
-    tslow += W::clock() - t1;
+    tslow += tick() - t1;
     return ok;
   }
 
@@ -2958,18 +2964,18 @@ struct GtsComponent {
           bool batched = false;
           if constexpr (LDS) {
             if (C.fast_walks && C.batch_walks && M.wslots >= 2 && (clean || C.batch_walks >= 2)) {
-              const uint64_t tw0 = W::clock();
+              const uint64_t tw0 = tick();
               batched = clean ? cc_walks_batched<GTS_WALK_LANES>(tb, te, cc_len, cc_n, &cc_start)
                               : cc_walks_batched_unclean(tb, te, cc_len, cc_n, &cc_start);
-              tfast += W::clock() - tw0;
+              tfast += tick() - tw0;
               if (!batched) { cc_len = 0; cc_n = 0; }
             }
           }
           if constexpr (W::TEAM) {
             if (clean && C.fast_walks && team) {
-              const uint64_t tw0 = W::clock();
+              const uint64_t tw0 = tick();
               batched = cc_walks_team(tb, te, cc_len, cc_n);
-              tfast += W::clock() - tw0;
+              tfast += tick() - tw0;
               if (!batched) { cc_len = 0; cc_n = 0; }
             }
           }
@@ -3442,11 +3448,11 @@ struct GtsComponent {
   GTS_HD void run(int mode)
   {
     const uint32_t lane = W::lane();
-    const uint64_t t0 = W::clock();
+    const uint64_t t0 = tick();
     if (local_marks) removecycles_t<true>(mode == GTS_MODE_MAKESCAFFOLD);
     else removecycles(mode == GTS_MODE_MAKESCAFFOLD);
     reuse_cc = clean;   /* the terminal search of the last pass is makescaffold's */
-    const uint64_t t1 = W::clock();
+    const uint64_t t1 = tick();
     if (C.small_stat && nv <= 64 && lane == 0) {
       W::add64((uint64_t *)C.small_stat + (was_all_live && clean ? 0 : 1), 1);
       W::add64((uint64_t *)C.small_stat + (was_all_live && clean ? 2 : 3), t1 - t0);
@@ -3457,7 +3463,7 @@ struct GtsComponent {
       makescaffold();
       deferred = deferred_late;
     }
-    const uint64_t t2 = W::clock();
+    const uint64_t t2 = tick();
     if (local_marks) flush_local_marks();
     /* (not unrolled: an eight-fold copy hipcc 7.2 made of this loop inside
        k_components_pool -- lane-dependent trip count, address registers spilled
@@ -3471,7 +3477,9 @@ struct GtsComponent {
          513-517, 550-553); makescaffold leaves VISITED or SCAFFOLD */
       C.G.vstate[C.slot_v[s0 + s]] = st;
     }
-    if (lane == 0) {
+    run_clean = was_clean; run_deferred = deferred;
+    if (lean_stats) { if (lane == 0 && err) C.cerr[c] = err; }
+    else if (lane == 0) {
       C.cerr[c] = err; C.stat_fast[c] = nfast; C.stat_slow[c] = nslow; C.stat_ncc[c] = ncc;
       C.stat_clean[c] = (was_clean ? 1u : 0u) | (deferred ? 2u : 0u) | (nodefer << 2) | (nterm << 8);
       C.tstat[5 * (uint64_t)c] = t1 - t0;
@@ -3479,7 +3487,7 @@ struct GtsComponent {
       C.tstat[5 * (uint64_t)c + 2] = tfast;
       C.tstat[5 * (uint64_t)c + 3] = tslow;
       C.tstat[5 * (uint64_t)c + 4] = npops;
-      if (C.tspan) { C.tspan[2 * (uint64_t)c] = t0; C.tspan[2 * (uint64_t)c + 1] = W::clock(); }
+      if (C.tspan) { C.tspan[2 * (uint64_t)c] = t0; C.tspan[2 * (uint64_t)c + 1] = tick(); }
     }
     W::fence();
   }

@@ -67,6 +67,7 @@ static const char *klass_event(int makescaffold, uint32_t bytes);
 #define GTS_S_TEAMSTAT 432 /* 8 x u64: statistics of k_components_team */
 #define GTS_S_SMALLSTAT 448 /* 4 x u64: small components by "all edges live" */
 #define GTS_S_COLD 464      /* 8 x u64: the cold list's words (GTS_COLD_*) */
+#define GTS_S_POOLTOT 512   /* 3 x u64: totals of the pool's programs that keep no per-component statistics */
 #define GTS_S_VIEW 2048     /* byte offset 8192: the GtsCompView of the pool kernels (d_scalars holds 16 KB) */
 #define GTS_S_FASTSTAT 480  /* 16 x u64: statistics of k_components_fast (as GTS_S_POOLSTAT, + [10..12]) */
 
@@ -1512,6 +1513,7 @@ struct GtsPoolArgs {
   uint32_t first, count;               /* the launch's slice of them */
   int mode;
   unsigned long long *cursor, *pstat;
+  unsigned long long *ptot;            /* 3 words: totals of the full program's lean statistics */
   uint32_t nbig, g0;
   int poison;
   uint64_t wait_limit;
@@ -1940,9 +1942,17 @@ __device__ __forceinline__ void pool_body(const GtsCompView *C0, const GtsPoolAr
       } else {
         prog.local_marks = C.local_marks != 0;
         if (C.help_walks) { prog.hub = &ctl->job; prog.hub_me = my_wave; }
+        prog.lean_stats = C.tspan == nullptr;   /* per-component tables for the detailed profile only */
         if (lane == 0) GtsWave64::hub_add(&ctl->job.n_running, 1u);
         prog.run(A.mode);
-        if (lane == 0) GtsWave64::hub_add(&ctl->job.n_running, 0xFFFFFFFFu);
+        if (lane == 0) {
+          GtsWave64::hub_add(&ctl->job.n_running, 0xFFFFFFFFu);
+          if (prog.lean_stats) {
+            atomicAdd(&ctl->n_done, prog.run_clean ? 0x100000001ull : 1ull);
+            atomicAdd(&ctl->n_walks, (unsigned long long)prog.nfast | (unsigned long long)prog.nslow << 32);
+            if (prog.run_deferred) atomicAdd(&ctl->n_cold, 1ull);
+          }
+        }
       }
       if (lane == 0) atomicAdd(&ctl->t_run, (unsigned long long)(GtsWave64::clock() - tr0));
     }
@@ -1971,7 +1981,12 @@ __device__ __forceinline__ void pool_body(const GtsCompView *C0, const GtsPoolAr
       volatile GtsPoolCtl *v = (volatile GtsPoolCtl *)ctl;
       atomicAdd(pstat + 0, v->t_run); atomicAdd(pstat + 1, v->t_wait); atomicAdd(pstat + 2, v->t_life);
       if constexpr (FAST) atomicAdd(pstat + 15, v->t_claim);
-      else if (v->n_helped) { atomicAdd(pstat + 10, v->n_helped); atomicAdd(pstat + 11, v->t_helping); }
+      else {
+        if (v->n_helped) { atomicAdd(pstat + 10, v->n_helped); atomicAdd(pstat + 11, v->t_helping); }
+        /* totals of the programs that kept no per-component statistics (lean_stats):
+           finished | clean << 32, linear walks | reference walks << 32, deferred */
+        if (v->n_done) { atomicAdd(A.ptot + 0, v->n_done); atomicAdd(A.ptot + 1, v->n_walks); atomicAdd(A.ptot + 2, v->n_cold); }
+      }
       if constexpr (FAST) {
         if (v->n_done) { atomicAdd(pstat + 10, v->n_done); atomicAdd(pstat + 11, v->n_walks); atomicAdd(pstat + 13, v->b_done_bytes); }
         if (v->n_cold) { atomicAdd(pstat + 12, v->n_cold); atomicAdd(pstat + 14, v->b_cold_bytes); }
@@ -3241,7 +3256,7 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemsetAsync(e->d_scalars + 12, 0, 16, e->st));
     LAUNCH("comp_max_size", k_max_u32_diff, nblk(ncomp), GTS_BLOCK, comp_off, ncomp,
            e->d_scalars + 14);
-    bool pool_ran = false, fast_ran = false;
+    bool pool_ran = false, fast_ran = false, lean_pool = false;
     /* an entry per component and one per ticket a cold wavefront can hold beyond them */
     const size_t cold_entries = (size_t)ncomp + 1 + 256u * GTS_POOL_WAVES;
     PALLOC(cold_list, unsigned long long, cold_entries);
@@ -3369,6 +3384,15 @@ static int run_components(GtsgEngine *e, int mode)
         GtsPoolArgs *PAdev = (GtsPoolArgs *)(e->d_scalars + GTS_S_VIEW + 256), *CAdev = PAdev + 1, *FAdev = PAdev + 2;
         GtsPoolArgs PA;
         PA.order = order; PA.order_key = order_key; PA.first = first; PA.count = pooled; PA.mode = mode;
+        PA.ptot = (unsigned long long *)(e->d_scalars + GTS_S_POOLTOT);
+        HIPCHK(hipMemsetAsync(PA.ptot, 0, 24, ss));
+        lean_pool = e->profile < 2;
+        if (lean_pool) {   /* (the programs leave these alone; the walk tasks add to them) */
+          HIPCHK(hipMemsetAsync(stat_fast, 0, (size_t)ncomp * 4, ss));
+          HIPCHK(hipMemsetAsync(stat_slow, 0, (size_t)ncomp * 4, ss));
+          HIPCHK(hipMemsetAsync(stat_clean, 0, (size_t)ncomp * 4, ss));
+          HIPCHK(hipMemsetAsync(stat_ncc, 0, (size_t)ncomp * 4, ss));
+        }
         PA.cursor = cursor; PA.pstat = pstat; PA.nbig = nbig; PA.g0 = g0; PA.poison = (int)e->lds_poison;
         PA.wait_limit = (uint64_t)e->pool_wait_limit_us * 100ull; PA.cold = nullptr; PA.cold_list = nullptr;
         /* the clean program on two workgroups per CU, the full program next to it on
@@ -3581,6 +3605,8 @@ static int run_components(GtsgEngine *e, int mode)
     HIPCHK(hipMemcpyAsync(why, e->d_scalars + 96, 96, hipMemcpyDeviceToHost, e->st));
     uint64_t pst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (pool_ran) HIPCHK(hipMemcpyAsync(pst, e->d_scalars + GTS_S_POOLSTAT, 96, hipMemcpyDeviceToHost, e->st));
+    uint64_t ptot[3] = {0, 0, 0};
+    if (pool_ran) HIPCHK(hipMemcpyAsync(ptot, e->d_scalars + GTS_S_POOLTOT, 24, hipMemcpyDeviceToHost, e->st));
     uint64_t fst[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (fast_ran) HIPCHK(hipMemcpyAsync(fst, e->d_scalars + GTS_S_FASTSTAT, 128, hipMemcpyDeviceToHost, e->st));
     uint64_t tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3768,6 +3794,9 @@ static int run_components(GtsgEngine *e, int mode)
     /* (the fast program counts in its own words unless the detailed profile made
        it write the per-component tables the sums above are taken from) */
     if (fast_ran && e->profile < 2) { wstat[0] += fst[11]; wstat[2] += fst[10] >> 32; }
+    if (pool_ran && lean_pool) {
+      wstat[0] += ptot[1] & 0xFFFFFFFFull; wstat[1] += ptot[1] >> 32; wstat[2] += ptot[0] >> 32; wstat[3] += ptot[2];
+    }
     e->stats["fast_walks"] = (int64_t)wstat[0];
     e->stats["slow_walks"] = (int64_t)wstat[1];
     e->stats["clean_components"] = (int64_t)wstat[2];
