@@ -188,6 +188,9 @@ struct GtsgEngine {
   int64_t team_components = 1, team_max_components = 512, team_pool_mb = 4096;
   char *team_pool = nullptr;
   char *text_buf = nullptr;   /* .dot text of a chunk of edges (gtsg_format_dot_edges) */
+  char *rec_buf = nullptr;    /* the scaffold records between gtsg_scaffold_records and ..._fetch */
+  size_t rec_counts[4] = {0, 0, 0, 0};
+  bool rec_ready = false;
   char *text_host = nullptr;  /* its page-locked host copy (gtsg_format_dot_edges_pinned) */
   size_t text_host_cap = 0;
   int profile = 0;        /* 1: hipEvents around kernels, 2: also per-component clocks */
@@ -2358,7 +2361,7 @@ void gtsg_destroy(GtsgEngine *e)
   collect_times(e);
   free_graph(e, true);
   void *ptrs[] = {e->seq_len, e->astat, e->copy_num, e->vstate, e->vtime, e->pool, e->d_scalars,
-                  e->gtask_pool, e->team_pool, e->text_buf};
+                  e->gtask_pool, e->team_pool, e->text_buf, e->rec_buf};
   for (void *p : ptrs) if (p) hipFree(p);
   if (e->text_host) hipHostFree(e->text_host);
   for (auto ev : e->free_events) hipEventDestroy(ev);
@@ -4141,6 +4144,337 @@ int gtsg_get_scaffold_edges(GtsgEngine *e, uint64_t *count, uint32_t *row, uint3
       return fail(e, GTSG_EHIP, "copying the scaffold edges");
     return rc;
   }
+  return sync_stream(e);
+}
+
+/* ---- the scaffold records on the device (ref algorithms.c:901-997) -----------
+   The reference visits the vertices in index order; an unvisited, unmarked vertex
+   with at most one SCAFFOLD edge opens a record, and the record follows the
+   SCAFFOLD edges -- marking the vertices it arrives at VISITED, stopping at one
+   that is already -- while exactly one of them, not the way back, leaves the
+   vertex in the direction the arriving edge asks for.
+
+   makescaffold marks the edges of a walk and their twins.  Nearly all of these
+   walks are simple paths: every edge u -> w has exactly one edge w -> u, w has at
+   most two SCAFFOLD edges and is not marked, and the other edge of w (if there is
+   one) points in the asked direction.  Call such an edge regular and a path of
+   regular edges between untainted vertices clean (a vertex is tainted by any
+   irregular edge at it, in or out).  Nothing leads into a clean path: an edge from
+   outside would find no edge back at the vertex it ends in and taint it.  The
+   record of a clean path therefore depends on nothing else: it starts at the end
+   of lower index (the first the loop meets; the other end is visited by then) and
+   runs to the other end, and no vertex is met twice -- list ranking.  For a
+   directed edge k = (u -> w), next[k] is the other edge of w; pointer jumping
+   gives last[k], the final edge of the chain from k, and hops[k], the edges after
+   k, and whether an irregular edge lies ahead.  With t = twin(k): the chain from t
+   ends at the path end the walk through k started from (start = end[last[t]]),
+   and k is edge number hops[t] of that walk.  Clean cycles have no end and no
+   record, as in the reference (none of their vertices has fewer than two edges).
+
+   A walk of the reference's search that passes a contig twice (a contig pushed
+   again with a shorter distance, create_walk :700-730) leaves a vertex with three
+   or four SCAFFOLD edges: about one contig in a thousand on the synthetic
+   graphs.  The paths such vertices lie on, their edges and the vertices that
+   could open a record there are handed to the caller as the "open" part -- a
+   compact list in adjacency order -- to be walked in the reference's order of
+   visits; being closed under SCAFFOLD edges as well, the two parts do not see
+   each other, and the records of both merge by root index. */
+#define GTS_REC_NONE 0xFFFFFFFFu
+#define GTS_REC_OPEN 0x80000000u
+__global__ void k_scaf_fill_start(const uint8_t *flag, const uint32_t *ipos, const uint32_t *estart,
+                                  uint32_t *o_start, uint32_t m)
+{
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < m && flag[p]) o_start[ipos[p]] = estart[p];
+}
+__device__ __forceinline__ bool rec_marked(uint8_t s)
+{
+  return s == GIS_POLYMORPHIC || s == GIS_REPEAT || s == GIS_CYCLIC;
+}
+/* per directed SCAFFOLD edge: its twin and the edge the walk takes after it, or what is
+   irregular about it (gtsg_get_stat "records_irregular": 1 self loop, 2 more than two
+   SCAFFOLD edges at the end vertex, 4 a marked vertex, 8 two edges back, 16 none, 32 the
+   edge on points the other way) */
+__global__ void k_rec_links(const uint32_t *srow, const uint32_t *su, const uint32_t *en, const uint8_t *fl,
+                            const uint8_t *vstate, uint32_t *tw, uint32_t *other_of, uint8_t *taint,
+                            uint32_t cnt, uint32_t *why)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const uint32_t u = su[k], w = en[k];
+  const uint32_t b = srow[w], ns = srow[w + 1] - b;
+  const bool sense = fl[k] & 1, same = fl[k] & 2, dir = same ? sense : !sense;
+  uint32_t back = GTS_REC_NONE, other = GTS_REC_NONE;
+  uint32_t bad = (u == w ? 1u : 0u) | (ns > 2 ? 2u : 0u) | (rec_marked(vstate[w]) || rec_marked(vstate[u]) ? 4u : 0u);
+  if (!bad)
+    for (uint32_t j = b; j < b + ns; ++j) {
+      if (en[j] == u) { if (back != GTS_REC_NONE) bad |= 8u; back = j; }
+      else other = j;
+    }
+  if (!bad && back == GTS_REC_NONE) bad |= 16u;
+  if (!bad && other != GTS_REC_NONE && ((fl[other] & 1) != 0) != dir) bad |= 32u;
+  if (bad) {
+    atomicOr(why, bad);
+    taint[u] = 1; taint[w] = 1;
+    tw[k] = GTS_REC_NONE; other_of[k] = GTS_REC_NONE;
+    return;
+  }
+  tw[k] = back; other_of[k] = other;
+}
+/* (pointer, hops) to start the jumping from; an edge at a tainted vertex ends its chain */
+__global__ void k_rec_start(const uint32_t *su, const uint32_t *en, const uint32_t *tw, const uint32_t *other_of,
+                            const uint8_t *taint, uint2 *link, uint32_t cnt)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const uint32_t o = other_of[k];
+  if (tw[k] == GTS_REC_NONE || taint[su[k]] || taint[en[k]]) link[k] = make_uint2((uint32_t)k, GTS_REC_OPEN);
+  else link[k] = o == GTS_REC_NONE ? make_uint2((uint32_t)k, 0u) : make_uint2(o, 1u);
+}
+/* one round of pointer jumping: (pointer, hops) -> (pointer of pointer, hops + its hops) */
+__global__ void k_rec_jump(const uint2 *in, uint2 *out, uint32_t cnt, uint32_t *changed)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const uint2 a = in[k];
+  const uint2 b = in[a.x];
+  out[k] = make_uint2(b.x, (((a.y & ~GTS_REC_OPEN) + (b.y & ~GTS_REC_OPEN)) & ~GTS_REC_OPEN) | ((a.y | b.y) & GTS_REC_OPEN));
+  if (b.x != a.x) *changed = 1;
+}
+/* per vertex: does it open a record of a clean path (and with how many edges), or could it
+   open one in the open part */
+__global__ void k_rec_roots(const uint32_t *srow, const uint32_t *en, const uint2 *link, const uint8_t *vstate,
+                            const uint8_t *taint, uint8_t *isroot, uint32_t *nedge, uint8_t *isopen, uint32_t n)
+{
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const uint32_t b = srow[v], ns = srow[v + 1] - b;
+  uint8_t r = 0, o = 0;
+  uint32_t c = 0;
+  if (!rec_marked(vstate[v])) {
+    if (ns == 0) { if (taint[v]) o = 1; else r = 1; }
+    else if (ns == 1) {
+      const uint2 l = link[b];
+      if ((l.y & GTS_REC_OPEN) || taint[v]) o = 1;
+      else if ((uint32_t)v < en[l.x]) { r = 1; c = l.y + 1; }
+    }
+  }
+  isroot[v] = r; nedge[v] = c; isopen[v] = o;
+}
+/* per directed SCAFFOLD edge: is it part of the open part (something irregular ahead of it
+   or behind it on its path) */
+__global__ void k_rec_open_edges(const uint32_t *tw, const uint2 *link, uint8_t *eopen, uint32_t cnt)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const uint32_t t = tw[k];
+  const uint2 a = link[k];
+  uint8_t o = 0;
+  if (t == GTS_REC_NONE || (a.y & GTS_REC_OPEN)) o = 1;
+  else if (link[t].y & GTS_REC_OPEN) o = 1;
+  /* (the chains of a clean cycle never end: neither open nor anybody's) */
+  eopen[k] = o;
+}
+__global__ void k_rec_heads(const uint8_t *isroot, const uint32_t *ridx, const uint32_t *eoff,
+                            const uint8_t *isopen, const uint32_t *oidx, const int64_t *seq_len,
+                            uint32_t *root, uint32_t *off, unsigned long long *seqlen, uint32_t *open_root,
+                            uint32_t n)
+{
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  if (isroot[v]) {
+    const uint32_t r = ridx[v];
+    root[r] = (uint32_t)v; off[r] = eoff[v]; seqlen[r] = (unsigned long long)seq_len[v];
+  }
+  if (isopen[v]) open_root[oidx[v]] = (uint32_t)v;
+}
+/* per directed SCAFFOLD edge: the record it belongs to (if it points away from the root of
+   its clean path) and its place in it; or its place in the list of the open part */
+__global__ void k_rec_place(const uint32_t *tw, const uint2 *link, const uint32_t *su, const uint32_t *en,
+                            const uint8_t *isroot, const uint32_t *ridx, const uint32_t *eoff,
+                            const uint8_t *eopen, const uint32_t *eoidx, const int64_t *seq_len,
+                            const uint32_t *i_eid, const int64_t *i_dist, const float *i_sd, const uint8_t *i_fl,
+                            uint32_t *o_eid, uint32_t *o_end, int64_t *o_dist, float *o_sd, uint8_t *o_fl,
+                            unsigned long long *seqlen,
+                            uint32_t *p_start, uint32_t *p_eid, uint32_t *p_end, int64_t *p_dist, float *p_sd,
+                            uint8_t *p_fl, uint32_t cnt)
+{
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cnt) return;
+  const uint32_t w = en[k];
+  const int64_t d = i_dist[k];
+  if (eopen[k]) {
+    const uint32_t pos = eoidx[k];
+    p_start[pos] = su[k]; p_eid[pos] = i_eid[k]; p_end[pos] = w; p_dist[pos] = d; p_sd[pos] = i_sd[k];
+    p_fl[pos] = i_fl[k];
+    return;
+  }
+  const uint2 l = link[tw[k]];
+  if (l.y & GTS_REC_OPEN) return;
+  const uint32_t s = en[l.x];
+  if (!isroot[s]) return;
+  const uint32_t pos = eoff[s] + l.y;
+  o_eid[pos] = i_eid[k]; o_end[pos] = w; o_dist[pos] = d; o_sd[pos] = i_sd[k]; o_fl[pos] = i_fl[k];
+  atomicAdd(seqlen + ridx[s], (unsigned long long)seq_len[w] + (unsigned long long)d);
+}
+
+struct RecLayout {
+  size_t nr, ne, pr, pe;
+  char *seqlen, *dist, *p_dist, *root, *off, *eid, *end, *sd, *p_root, *p_start, *p_eid, *p_end, *p_sd, *fl, *p_fl;
+  size_t bytes;
+};
+static RecLayout rec_layout(char *base, size_t nr, size_t ne, size_t pr, size_t pe)
+{
+  RecLayout L;
+  char *kp = base;
+  auto carve = [&](size_t bytes) { char *r = kp; kp += (bytes + 15) & ~(size_t)15; return r; };
+  L.nr = nr; L.ne = ne; L.pr = pr; L.pe = pe;
+  L.seqlen = carve(nr * 8); L.dist = carve(ne * 8); L.p_dist = carve(pe * 8);
+  L.root = carve(nr * 4); L.off = carve(nr * 4); L.eid = carve(ne * 4); L.end = carve(ne * 4); L.sd = carve(ne * 4);
+  L.p_root = carve(pr * 4); L.p_start = carve(pe * 4); L.p_eid = carve(pe * 4); L.p_end = carve(pe * 4);
+  L.p_sd = carve(pe * 4);
+  L.fl = carve(ne); L.p_fl = carve(pe);
+  L.bytes = (size_t)(kp - base) + 64;
+  return L;
+}
+
+int gtsg_scaffold_records(GtsgEngine *e, GtsgRecordCounts *counts)
+{
+  if (!e || !counts) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->built) return fail(e, GTSG_EINVAL, "graph not built");
+  if (e->filter_open) return fail(e, GTSG_EINVAL, "gtsg_filter_begin without gtsg_filter_end");
+  const uint32_t n = e->n, m = e->m;
+  int rc;
+  memset(counts, 0, sizeof *counts);
+  e->rec_counts[0] = e->rec_counts[1] = e->rec_counts[2] = e->rec_counts[3] = 0;
+  e->rec_ready = false;
+  e->stats["records_irregular"] = 0;
+  uint32_t cnt = 0;
+  {
+    const size_t need = (size_t)m * 5 + (size_t)n * 4 + gts_scan_tmp_elems((uint64_t)m + 16) * 4 + (1u << 20);
+    if ((rc = pool_reserve(e, need))) return rc;
+  }
+  uint8_t *flag = nullptr;
+  uint32_t *ipos = nullptr;
+  if (m) {
+    flag = pool_alloc<uint8_t>(e, (size_t)m + 1); ipos = pool_alloc<uint32_t>(e, (size_t)m + 2);
+    uint32_t *sctmp = pool_alloc<uint32_t>(e, gts_scan_tmp_elems((uint64_t)m + 16));
+    if (!flag || !ipos || !sctmp) return GTSG_ENOMEM;
+    LAUNCH("scaf_flags", k_scaf_flags, nblk(m), GTS_BLOCK, e->state, flag, m);
+    gts_exscan<uint8_t, uint32_t>(flag, ipos, m, sctmp, ipos + m, e->st);
+    if ((rc = read_u32(e, ipos + m, &cnt))) return rc;
+  }
+  /* the compact CSR and everything the ranking needs, in an allocation of its own
+     (the pool holds flag / ipos until the fill is done) */
+  const size_t c1 = (size_t)cnt + 16, n1 = (size_t)n + 16;
+  const size_t scan_elems = gts_scan_tmp_elems((uint64_t)(cnt > n ? cnt : n) + 16);
+  const size_t work = c1 * (8 + 8 + 8 + 4 * 7 + 2) + n1 * (4 * 5 + 3) + scan_elems * 4 + 64 * 32;
+  char *wbuf = nullptr;
+  if (hipMalloc((void **)&wbuf, work) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(e, GTSG_ENOMEM, "scaffold record workspace of %zu bytes", work);
+  }
+  char *wp = wbuf;
+  auto carve = [&](size_t bytes) { char *r = wp; wp += (bytes + 15) & ~(size_t)15; return r; };
+  int64_t *c_dist = (int64_t *)carve(c1 * 8);
+  uint2 *linkA = (uint2 *)carve(c1 * 8), *linkB = (uint2 *)carve(c1 * 8);
+  uint32_t *su = (uint32_t *)carve(c1 * 4), *en = (uint32_t *)carve(c1 * 4);
+  float *c_sd = (float *)carve(c1 * 4);
+  uint32_t *c_eid = (uint32_t *)carve(c1 * 4), *tw = (uint32_t *)carve(c1 * 4), *other_of = (uint32_t *)carve(c1 * 4);
+  uint32_t *eoidx = (uint32_t *)carve(c1 * 4);
+  uint32_t *srow = (uint32_t *)carve(n1 * 4), *nedge = (uint32_t *)carve(n1 * 4), *ridx = (uint32_t *)carve(n1 * 4);
+  uint32_t *eoff = (uint32_t *)carve(n1 * 4), *oidx = (uint32_t *)carve(n1 * 4);
+  uint32_t *sctmp2 = (uint32_t *)carve(scan_elems * 4);
+  uint8_t *c_fl = (uint8_t *)carve(c1), *eopen = (uint8_t *)carve(c1);
+  uint8_t *isroot = (uint8_t *)carve(n1), *isopen = (uint8_t *)carve(n1), *taint = (uint8_t *)carve(n1);
+  if ((size_t)(wp - wbuf) > work) { hipFree(wbuf); return fail(e, GTSG_EINTERNAL, "scaffold record workspace layout"); }
+  /* [0] why irregular, [1] changed, [2] records, [3] their edges, [4] open roots, [5] open edges */
+  uint32_t *d_flag = (uint32_t *)(e->d_scalars + 8);
+  auto bail = [&](int r) { hipStreamSynchronize(e->st); hipFree(wbuf); return r; };
+#define RECCHK(x) do { if ((x) != hipSuccess) return bail(fail(e, GTSG_EHIP, "scaffold records: %s", #x)); } while (0)
+  RECCHK(hipMemsetAsync(d_flag, 0, 32, e->st));
+  RECCHK(hipMemsetAsync(taint, 0, n1, e->st));
+  if (m) LAUNCH("scaf_rows", k_scaf_rows, nblk((uint64_t)n + 1), GTS_BLOCK, e->row, ipos, srow, n);
+  else RECCHK(hipMemsetAsync(srow, 0, n1 * 4, e->st));
+  uint2 *link = linkA;
+  if (cnt) {
+    LAUNCH("scaf_fill", k_scaf_fill, nblk(m), GTS_BLOCK, flag, ipos, e->eid, e->eend, e->dist, e->sd,
+           e->flags, c_eid, en, c_dist, c_sd, c_fl, m);
+    LAUNCH("scaf_fill", k_scaf_fill_start, nblk(m), GTS_BLOCK, flag, ipos, e->estart, su, m);
+    LAUNCH("rec_links", k_rec_links, nblk(cnt), GTS_BLOCK, srow, su, en, c_fl, e->vstate, tw, other_of, taint, cnt,
+           d_flag);
+    LAUNCH("rec_links", k_rec_start, nblk(cnt), GTS_BLOCK, su, en, tw, other_of, taint, linkA, cnt);
+    uint32_t h[2] = {0, 0};
+    /* a path of L edges is ranked after ceil(log2 L) rounds; the chains of a cycle
+       never settle and are nobody's: 32 rounds at most */
+    for (int round = 0; round < 32; ++round) {
+      RECCHK(hipMemsetAsync(d_flag + 1, 0, 4, e->st));
+      uint2 *out = link == linkA ? linkB : linkA;
+      LAUNCH("rec_jump", k_rec_jump, nblk(cnt), GTS_BLOCK, link, out, cnt, d_flag + 1);
+      link = out;
+      RECCHK(hipMemcpyAsync(h, d_flag, 8, hipMemcpyDeviceToHost, e->st));
+      if ((rc = sync_stream(e))) return bail(rc);
+      e->stats["records_jump_rounds"] = round + 1;
+      if (!h[1]) break;
+    }
+    e->stats["records_irregular"] = h[0];
+    LAUNCH("rec_open", k_rec_open_edges, nblk(cnt), GTS_BLOCK, tw, link, eopen, cnt);
+    gts_exscan<uint8_t, uint32_t>(eopen, eoidx, cnt, sctmp2, d_flag + 5, e->st);
+  }
+  if (n) {
+    LAUNCH("rec_roots", k_rec_roots, nblk(n), GTS_BLOCK, srow, en, link, e->vstate, taint, isroot, nedge, isopen, n);
+    gts_exscan<uint8_t, uint32_t>(isroot, ridx, n, sctmp2, d_flag + 2, e->st);
+    gts_exscan<uint32_t, uint32_t>(nedge, eoff, n, sctmp2, d_flag + 3, e->st);
+    gts_exscan<uint8_t, uint32_t>(isopen, oidx, n, sctmp2, d_flag + 4, e->st);
+  }
+  uint32_t tot[4] = {0, 0, 0, 0};
+  RECCHK(hipMemcpyAsync(tot, d_flag + 2, 16, hipMemcpyDeviceToHost, e->st));
+  if ((rc = sync_stream(e))) return bail(rc);
+  const size_t nr = tot[0], ne = tot[1], pr = tot[2], pe = tot[3];
+  {
+    RecLayout L0 = rec_layout(nullptr, nr, ne, pr, pe);
+    if ((rc = dev_alloc(e, &e->rec_buf, L0.bytes))) return bail(rc);
+  }
+  const RecLayout L = rec_layout(e->rec_buf, nr, ne, pr, pe);
+  if (n) LAUNCH("rec_heads", k_rec_heads, nblk(n), GTS_BLOCK, isroot, ridx, eoff, isopen, oidx, e->seq_len,
+                (uint32_t *)L.root, (uint32_t *)L.off, (unsigned long long *)L.seqlen, (uint32_t *)L.p_root, n);
+  if (cnt) LAUNCH("rec_place", k_rec_place, nblk(cnt), GTS_BLOCK, tw, link, su, en, isroot, ridx, eoff, eopen, eoidx,
+                  e->seq_len, c_eid, c_dist, c_sd, c_fl, (uint32_t *)L.eid, (uint32_t *)L.end, (int64_t *)L.dist,
+                  (float *)L.sd, (uint8_t *)L.fl, (unsigned long long *)L.seqlen, (uint32_t *)L.p_start,
+                  (uint32_t *)L.p_eid, (uint32_t *)L.p_end, (int64_t *)L.p_dist, (float *)L.p_sd, (uint8_t *)L.p_fl,
+                  cnt);
+  if ((rc = sync_stream(e))) return bail(rc);
+#undef RECCHK
+  hipFree(wbuf);
+  e->rec_counts[0] = nr; e->rec_counts[1] = ne; e->rec_counts[2] = pr; e->rec_counts[3] = pe;
+  e->rec_ready = true;
+  counts->n_records = nr; counts->n_edges = ne; counts->n_open_roots = pr; counts->n_open_edges = pe;
+  e->stats["records_ranked"] = (int64_t)nr;
+  e->stats["records_open_roots"] = (int64_t)pr;
+  e->stats["records_open_edges"] = (int64_t)pe;
+  return 0;
+}
+
+int gtsg_scaffold_records_fetch(GtsgEngine *e, const GtsgRecordArrays *a)
+{
+  if (!e || !a) return GTSG_EINVAL;
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->rec_ready || !e->rec_buf) return fail(e, GTSG_EINVAL, "gtsg_scaffold_records first");
+  const size_t nr = e->rec_counts[0], ne = e->rec_counts[1], pr = e->rec_counts[2], pe = e->rec_counts[3];
+  if ((nr && (!a->root || !a->off || !a->seqlen)) ||
+      (ne && (!a->eid || !a->end || !a->dist || !a->std_dev || !a->flags)) || (pr && !a->open_root) ||
+      (pe && (!a->open_start || !a->open_eid || !a->open_end || !a->open_dist || !a->open_std_dev || !a->open_flags)))
+    return GTSG_EINVAL;
+  const RecLayout L = rec_layout(e->rec_buf, nr, ne, pr, pe);
+#define RECGET(dst, src, bytes) do { if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->st)); } while (0)
+  RECGET(a->seqlen, L.seqlen, nr * 8); RECGET(a->root, L.root, nr * 4); RECGET(a->off, L.off, nr * 4);
+  RECGET(a->dist, L.dist, ne * 8); RECGET(a->eid, L.eid, ne * 4); RECGET(a->end, L.end, ne * 4);
+  RECGET(a->std_dev, L.sd, ne * 4); RECGET(a->flags, L.fl, ne);
+  RECGET(a->open_root, L.p_root, pr * 4);
+  RECGET(a->open_dist, L.p_dist, pe * 8); RECGET(a->open_start, L.p_start, pe * 4); RECGET(a->open_eid, L.p_eid, pe * 4);
+  RECGET(a->open_end, L.p_end, pe * 4); RECGET(a->open_std_dev, L.p_sd, pe * 4); RECGET(a->open_flags, L.p_fl, pe);
+#undef RECGET
   return sync_stream(e);
 }
 

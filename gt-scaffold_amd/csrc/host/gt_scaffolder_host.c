@@ -759,6 +759,13 @@ void gt_scaffolder_set_distance_parser(int mode) { g_host_parser = mode; }
    for a graph that lives there, 1 the host (the reference's loop by hand) */
 static int g_host_dot;
 void gt_scaffolder_set_dot_writer(int mode) { g_host_dot = mode; }
+/* who walks the scaffold records of a graph on the GPU: 0 (default) the GPU ranks
+   the clean SCAFFOLD paths (gtsg_scaffold_records) and the host walks the open
+   part; 1 the host walks everything (the checker).  gt_scaffolder_last_record_walk:
+   which of the two the last call was. */
+static int g_host_records, g_last_record_walk;
+void gt_scaffolder_set_record_walk(int mode) { g_host_records = mode; }
+int gt_scaffolder_last_record_walk(void) { return g_last_record_walk; }
 
 /* The GPU parser of the graph with the sorted headers as its name table.
    *have = 0: there is none (host-only mode, no GPU, too many names). */
@@ -1401,6 +1408,145 @@ static int scaf_csr(GtScaffolderGraph *g, ScafCsr *c)
   return 0;
 }
 
+/* The records of a graph on the GPU (gtsg_scaffold_records): those of the clean
+   SCAFFOLD paths come ranked -- roots in index order, the edges of each in walk
+   order, the lengths summed.  The open part (paths through a contig a walk of
+   makescaffold passed twice: a few per cent of the edges at most) is walked here
+   in the reference's order of visits, ref algorithms.c:925-995, on its own short
+   edge list; the two parts share no vertex and merge by root index. */
+typedef struct {
+  uint32_t *root, *off, *eid, *end, *p_root, *p_start, *p_eid, *p_end;
+  uint64_t *seqlen;
+  int64_t *dist, *p_dist;
+  float *sd, *p_sd;
+  uint8_t *fl, *p_fl;
+} RecDl;
+
+static void recdl_free(RecDl *d)
+{
+  free(d->root); free(d->off); free(d->eid); free(d->end); free(d->p_root); free(d->p_start); free(d->p_eid);
+  free(d->p_end); free(d->seqlen); free(d->dist); free(d->p_dist); free(d->sd); free(d->p_sd); free(d->fl);
+  free(d->p_fl);
+}
+
+/* first position of the open edge list whose start vertex is >= v */
+static uint64_t open_lower(const uint32_t *start, uint64_t n, uint32_t v)
+{
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint64_t mid = lo + (hi - lo) / 2;
+    if (start[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+static GtScaffolderGraphRecords *records_from_device(GtScaffolderGraph *g, uint64_t **seqlen_out, double *t0)
+{
+  GtsgRecordCounts c;
+  GtsgRecordArrays a;
+  RecDl d;
+  GtScaffolderGraphRecords *r;
+  uint64_t nr, ne, pr, pe, i, j, nb = 0, nbe = 0, *seqlen, *b_len = NULL, *b_off = NULL;
+  uint32_t *b_root = NULL, *took = NULL;
+  uint64_t capt = 0;
+  int rc = gtsg_scaffold_records(g->eng, &c);
+  if (rc) { engine_err(g, rc, NULL, 0); return NULL; }
+  lap("records: ranked on the device", t0);
+  nr = c.n_records; ne = c.n_edges; pr = c.n_open_roots; pe = c.n_open_edges;
+  memset(&d, 0, sizeof d);
+  d.root = xcalloc(nr + 1, 4); d.off = xcalloc(nr + 1, 4); d.seqlen = xcalloc(nr + 1, 8);
+  d.eid = xcalloc(ne + 1, 4); d.end = xcalloc(ne + 1, 4); d.dist = xcalloc(ne + 1, 8); d.sd = xcalloc(ne + 1, 4);
+  d.fl = xcalloc(ne + 1, 1);
+  d.p_root = xcalloc(pr + 1, 4); d.p_start = xcalloc(pe + 1, 4); d.p_eid = xcalloc(pe + 1, 4);
+  d.p_end = xcalloc(pe + 1, 4); d.p_dist = xcalloc(pe + 1, 8); d.p_sd = xcalloc(pe + 1, 4); d.p_fl = xcalloc(pe + 1, 1);
+  a.root = d.root; a.off = d.off; a.seqlen = d.seqlen; a.eid = d.eid; a.end = d.end; a.dist = d.dist;
+  a.std_dev = d.sd; a.flags = d.fl; a.open_root = d.p_root; a.open_start = d.p_start; a.open_eid = d.p_eid;
+  a.open_end = d.p_end; a.open_dist = d.p_dist; a.open_std_dev = d.p_sd; a.open_flags = d.p_fl;
+  rc = gtsg_scaffold_records_fetch(g->eng, &a);
+  if (rc) { recdl_free(&d); engine_err(g, rc, NULL, 0); return NULL; }
+  d.off[nr] = (uint32_t)ne;
+  lap("records: download", t0);
+  if (pr) {
+    /* the open part in the reference's order of visits */
+    uint8_t *visited = xcalloc(g->nof_vertices / 8 + 1, 1);
+    b_root = xcalloc(pr, 4); b_len = xcalloc(pr, 8); b_off = xcalloc(pr + 1, 8);
+    capt = pe + 16;
+    took = xrealloc(NULL, capt * sizeof *took);
+    for (i = 0; i < pr; i++) {
+      const uint32_t v = d.p_root[i];
+      uint64_t lo = open_lower(d.p_start, pe, v), hi = lo, len;
+      if (visited[v >> 3] >> (v & 7) & 1) continue;
+      while (hi < pe && d.p_start[hi] == v) hi++;
+      if (hi - lo > 1) continue;
+      b_root[nb] = v; b_off[nb] = nbe;
+      len = g->ctg[v].seq_len;
+      visited[v >> 3] |= (uint8_t)(1u << (v & 7));
+      if (hi - lo == 1) {
+        uint32_t from = v;
+        uint64_t k = lo;
+        for (;;) {
+          const uint32_t w = d.p_end[k];
+          const uint8_t fl = d.p_fl[k];
+          const bool sense = fl & 1, same = fl & 2, dir = same ? sense : !sense;
+          uint64_t cnt = 0, nk = 0, q;
+          if (nbe == capt) { capt *= 2; took = xrealloc(took, capt * sizeof *took); }
+          took[nbe++] = (uint32_t)k;
+          len += g->ctg[w].seq_len + (uint64_t)d.p_dist[k];
+          if (visited[w >> 3] >> (w & 7) & 1) break;
+          visited[w >> 3] |= (uint8_t)(1u << (w & 7));
+          for (q = open_lower(d.p_start, pe, w); q < pe && d.p_start[q] == w; q++)
+            /* (not the edge back to where the walk came from: the twin) */
+            if (((d.p_fl[q] & 1) != 0) == dir && d.p_end[q] != from) { cnt++; nk = q; }
+          if (cnt != 1) break;
+          from = w;
+          k = nk;
+        }
+      }
+      b_len[nb] = len;
+      nb++;
+    }
+    b_off[nb] = nbe;
+    free(visited);
+    lap("records: open part walked", t0);
+  }
+  r = xcalloc(1, sizeof *r);
+  r->g = g;
+  r->n = r->cap = nr + nb;
+  r->nedge = r->capedge = ne + nbe;
+  r->root = xrealloc(NULL, (r->n + 1) * sizeof *r->root);
+  r->off = xrealloc(NULL, (r->n + 1) * sizeof *r->off);
+  r->edge = xrealloc(NULL, (r->nedge + 1) * sizeof *r->edge);
+  seqlen = xrealloc(NULL, (r->n + 1) * sizeof *seqlen);
+  {
+    uint64_t ia = 0, ib = 0, o = 0, pos = 0;
+    while (ia < nr || ib < nb) {
+      if (ib == nb || (ia < nr && d.root[ia] < b_root[ib])) {
+        r->root[o] = d.root[ia]; r->off[o] = pos; seqlen[o] = d.seqlen[ia];
+        for (j = d.off[ia]; j < d.off[ia + 1]; j++) {
+          REdge *x = r->edge + pos++;
+          x->eid = d.eid[j]; x->end = d.end[j]; x->dist = d.dist[j]; x->std_dev = d.sd[j]; x->flags = d.fl[j];
+        }
+        ia++;
+      } else {
+        r->root[o] = b_root[ib]; r->off[o] = pos; seqlen[o] = b_len[ib];
+        for (j = b_off[ib]; j < b_off[ib + 1]; j++) {
+          const uint32_t k = took[j];
+          REdge *x = r->edge + pos++;
+          x->eid = d.p_eid[k]; x->end = d.p_end[k]; x->dist = d.p_dist[k]; x->std_dev = d.p_sd[k]; x->flags = d.p_fl[k];
+        }
+        ib++;
+      }
+      o++;
+    }
+    r->off[o] = pos;
+  }
+  free(b_root); free(b_len); free(b_off); free(took);
+  recdl_free(&d);
+  lap("records: edges", t0);
+  *seqlen_out = seqlen;
+  return r;
+}
+
 /* ref gt_scaffolder_algorithms.c:901-997.  Vertices in index order; a record
    starts at an unvisited vertex with at most one SCAFFOLD edge and follows the
    SCAFFOLD edges while the way on is unique.  Every test of the reference's
@@ -1415,6 +1561,14 @@ gt_scaffolder_graph_iterate_scaffolds(GtScaffolderGraph *g, uint64_t **scaf_seql
   ScafCsr c;
   double t0 = now_s();
   if (!g) return NULL;
+  g_last_record_walk = 1;
+  if (g->eng && g_host_records != 1) {
+    r = records_from_device(g, &seqlen, &t0);
+    if (!r) return NULL;
+    g_last_record_walk = 0;
+    if (scaf_seqlen) *scaf_seqlen = seqlen; else free(seqlen);
+    return r;
+  }
   if (g->eng) {
     int rc = gtsg_get_vertex_states(g->eng, g->vstate);
     if (rc) { engine_err(g, rc, NULL, 0); return NULL; }

@@ -27,6 +27,7 @@ SYMBOLS = [
     "gtsg_deparser_trim", "gtsg_sort_names", "gtsg_fasta_records", "gtsg_deparser_accumulate",
     "gtsg_find_edge", "gtsg_alter_edge", "gtsg_plan_weights", "gtsg_plan_deal", "gtsg_route_unpack_ex",
     "gtsg_get_scaffold_edges", "gtsg_format_dot_edges", "gtsg_format_dot_edges_pinned",
+    "gtsg_scaffold_records", "gtsg_scaffold_records_fetch",
 ]
 
 
@@ -45,12 +46,26 @@ HOST_SYMBOLS = [
     "gt_scaffolder_set_distance_parser", "gt_scaffolder_graph_get_edges",
     "gt_scaffolder_graph_find_edge", "gt_scaffolder_graph_get_vertex_id",
     "gt_scaffolder_graph_get_vertex", "gt_scaffolder_graph_alter_edge", "gt_scaffolder_set_dot_writer",
+    "gt_scaffolder_set_record_walk", "gt_scaffolder_last_record_walk",
 ]
 
 
 class DeParseResult(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("n_candidates", C.c_uint64), ("error_pos", C.c_uint64),
                 ("error", C.c_int), ("irregular", C.c_int)]
+
+
+class RecordCounts(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_edges", C.c_uint64), ("n_open_roots", C.c_uint64),
+                ("n_open_edges", C.c_uint64)]
+
+
+_REC_FIELDS = ("root", "off", "seqlen", "eid", "end", "dist", "std_dev", "flags", "open_root", "open_start",
+               "open_eid", "open_end", "open_dist", "open_std_dev", "open_flags")
+
+
+class RecordArrays(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in _REC_FIELDS]
 
 
 class KernelTime(C.Structure):
@@ -102,6 +117,8 @@ def lib():
         L.gtsg_get_csr.argtypes = [vp, vp, vp]
         L.gtsg_find_edge.argtypes = [vp, u64, u64, C.POINTER(u64)]
         L.gtsg_alter_edge.argtypes = [vp, u64, i64, f32, u64, ci, ci]
+        L.gtsg_scaffold_records.argtypes = [vp, C.POINTER(RecordCounts)]
+        L.gtsg_scaffold_records_fetch.argtypes = [vp, C.POINTER(RecordArrays)]
         L.gtsg_state_digest.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.gtsg_selftest_ambiguous.argtypes = [vp, u64, vp, vp, vp, vp, f32, vp]
         L.gtsg_set_option.argtypes = [vp, C.c_char_p, i64]
@@ -142,6 +159,9 @@ def lib():
         L.gt_scaffolder_parser_read_distances.argtypes = [cp, vp, b, cp, sz]
         L.gt_scaffolder_set_distance_parser.argtypes = [ci]
         L.gt_scaffolder_set_dot_writer.argtypes = [ci]
+        L.gt_scaffolder_set_record_walk.argtypes = [ci]
+        L.gt_scaffolder_last_record_walk.argtypes = []
+        L.gt_scaffolder_last_record_walk.restype = ci
         L.gt_scaffolder_graph_get_edges.argtypes = [vp] * 7
         L.gt_scaffolder_graph_find_edge.argtypes = [vp, u64, u64]
         L.gt_scaffolder_graph_find_edge.restype = u64
@@ -514,6 +534,27 @@ class Engine:
         """ref gt_scaffolder_graph.c:219-235"""
         self._chk(self._L.gtsg_alter_edge(self._h, int(eid), int(dist), float(std_dev), int(num_pairs),
                                           int(bool(sense)), int(bool(same))))
+
+    def scaffold_records(self):
+        """gtsg_scaffold_records (ref gt_scaffolder_algorithms.c:901-997): the records of the clean
+        SCAFFOLD paths ranked on the device -- root, off [n+1], seqlen per record; eid, end, dist,
+        std_dev, flags per edge -- and the open part left to the caller: open_root, and per open
+        edge open_start / _eid / _end / _dist / _std_dev / _flags."""
+        c = RecordCounts()
+        self._chk(self._L.gtsg_scaffold_records(self._h, C.byref(c)))
+        nr, ne, pr, pe = c.n_records, c.n_edges, c.n_open_roots, c.n_open_edges
+        size = dict(root=nr, off=nr, seqlen=nr, open_root=pr)
+        dt = dict(seqlen=np.uint64, dist=np.int64, open_dist=np.int64, std_dev=np.float32,
+                  open_std_dev=np.float32, flags=np.uint8, open_flags=np.uint8)
+        o = {}
+        for k in _REC_FIELDS:
+            o[k] = np.zeros(size.get(k, pe if k.startswith("open_") else ne) + 1, dt.get(k, np.uint32))
+        a = RecordArrays(**{k: o[k].ctypes.data for k in _REC_FIELDS})
+        self._chk(self._L.gtsg_scaffold_records_fetch(self._h, C.byref(a)))
+        o["off"][nr] = ne
+        out = {k: v[:-1] for k, v in o.items() if k != "off"}
+        out["off"] = o["off"]
+        return out
 
     def digest(self):
         a, b = C.c_uint64(), C.c_uint64()

@@ -198,6 +198,39 @@ int gtsg_format_dot_edges_pinned(GtsgEngine *e, uint64_t first, uint64_t count,
    distance, deviation and flags (bit 0 sense, bit 1 same).  Host pointers. */
 int gtsg_get_scaffold_edges(GtsgEngine *e, uint64_t *count, uint32_t *row, uint32_t *eid,
                             uint32_t *end, int64_t *dist, float *std_dev, uint8_t *flags);
+/* ref gt_scaffolder_algorithms.c:901-997 gt_scaffolder_graph_iterate_scaffolds
+   on the device.  The SCAFFOLD edges are nearly all vertex-disjoint simple
+   paths with a twin per edge; the records of those ("clean" paths, and of the
+   unmarked contigs without SCAFFOLD edges) are a list ranking: root vertices in
+   index order, the edges of each in walk order, the sequence length of each =
+   lengths of its contigs plus the distances between them.  What is not such a
+   path -- a walk of makescaffold that passed a contig twice, a hand-built or
+   altered graph -- comes back as the "open" part: the vertices that could open
+   a record there (index order) and the SCAFFOLD edges of those paths (adjacency
+   order, start vertex per edge), closed under SCAFFOLD edges, for the caller to
+   walk in the reference's order of visits; the records of both parts merge by
+   root index.  gtsg_scaffold_records computes and returns the counts; the
+   arrays wait on the device for gtsg_scaffold_records_fetch (host pointers):
+   root / off (first edge of a record) / seqlen per record; id, end vertex,
+   distance, deviation and flags (bit 0 sense, bit 1 same) per edge. */
+typedef struct {
+  uint64_t n_records, n_edges;          /* ranked on the device */
+  uint64_t n_open_roots, n_open_edges;  /* left to the caller */
+} GtsgRecordCounts;
+typedef struct {
+  uint32_t *root, *off;
+  uint64_t *seqlen;
+  uint32_t *eid, *end;
+  int64_t *dist;
+  float *std_dev;
+  uint8_t *flags;
+  uint32_t *open_root, *open_start, *open_eid, *open_end;
+  int64_t *open_dist;
+  float *open_std_dev;
+  uint8_t *open_flags;
+} GtsgRecordArrays;
+int gtsg_scaffold_records(GtsgEngine *e, GtsgRecordCounts *counts);
+int gtsg_scaffold_records_fetch(GtsgEngine *e, const GtsgRecordArrays *arrays);
 /* ref gt_scaffolder_graph.c:174-193 gt_scaffolder_graph_find_edge: the id of
    the first edge in vertex_1's list (creation order) that ends in vertex_2,
    GTSG_NO_EDGE if there is none */

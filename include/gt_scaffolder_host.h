@@ -155,6 +155,13 @@ void gt_scaffolder_set_distance_parser(int mode);
 /* who formats the edge lines of gt_scaffolder_graph_print for a graph on the
    GPU: 0 (default) the GPU (gtsg_format_dot_edges), 1 the host */
 void gt_scaffolder_set_dot_writer(int mode);
+/* who walks the scaffold records (gt_scaffolder_graph_iterate_scaffolds) of a
+   graph on the GPU: 0 (default) the GPU ranks the records of the SCAFFOLD edges
+   that form vertex-disjoint simple paths (gtsg_scaffold_records) and the host
+   walks the few paths that do not, in the reference's order of visits; 1 the
+   host walks everything.  _last_record_walk: which of the two the last call was */
+void gt_scaffolder_set_record_walk(int mode);
+int gt_scaffolder_last_record_walk(void);
 
 #ifdef __cplusplus
 }

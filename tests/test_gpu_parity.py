@@ -360,6 +360,16 @@ def test_file_api_on_synthetic_files(tmp_path):
     lens = G.write_scaffold(str(tmp_path / "e.scaf"))
     assert filecmp.cmp(tmp_path / "o.scaf", tmp_path / "e.scaf", shallow=False)
     assert np.array_equal(lens, og.scaffolds()[3])
+    # the records were ranked on the GPU (gtsg_scaffold_records); the host walk gives the same file
+    assert pkg.engine.lib().gt_scaffolder_last_record_walk() == 0
+    pkg.engine.lib().gt_scaffolder_set_record_walk(1)
+    try:
+        lens = G.write_scaffold(str(tmp_path / "h.scaf"))
+    finally:
+        pkg.engine.lib().gt_scaffolder_set_record_walk(0)
+    assert pkg.engine.lib().gt_scaffolder_last_record_walk() == 1
+    assert filecmp.cmp(tmp_path / "o.scaf", tmp_path / "h.scaf", shallow=False)
+    assert np.array_equal(lens, og.scaffolds()[3])
 
 
 def test_file_api_at_100k_contigs(tmp_path):
@@ -384,6 +394,7 @@ def test_file_api_at_100k_contigs(tmp_path):
         assert filecmp.cmp(tmp_path / "o.dot", tmp_path / "e.dot", shallow=False), name
     og.write_scaffold(str(tmp_path / "o.scaf"))
     G.write_scaffold(str(tmp_path / "e.scaf"))
+    assert pkg.engine.lib().gt_scaffolder_last_record_walk() == 0    # ranked on the GPU
     assert filecmp.cmp(tmp_path / "o.scaf", tmp_path / "e.scaf", shallow=False)
 
 
@@ -1027,3 +1038,120 @@ def test_lean_program_with_cold_list(split):
     g = make_inputs(6000, 33, p_chimeric=0.1, p_bubble=0.05, p_relist_flip=0.1)
     eng, _ = run_pipeline(g, fast_components=1, fast_split=split, cold_cus=4)
     assert eng.stat("fast_kernel") == 1 and eng.stat("fast_components_done") > 0
+
+
+def walk_open_part(rec, seq_len):
+    """The open part of gtsg_scaffold_records walked in the reference's order of visits
+    (ref gt_scaffolder_algorithms.c:925-995), as the host layer does it."""
+    start, end, fl = rec["open_start"], rec["open_end"], rec["open_flags"]
+    lo_of = lambda v: int(np.searchsorted(start, v, "left"))
+    hi_of = lambda v: int(np.searchsorted(start, v, "right"))
+    visited, out = set(), []
+    for v in rec["open_root"].tolist():
+        lo, hi = lo_of(v), hi_of(v)
+        if v in visited or hi - lo > 1:
+            continue
+        visited.add(v)
+        took, length = [], int(seq_len[v])
+        if hi - lo == 1:
+            frm, k = v, lo
+            while True:
+                w = int(end[k]); took.append(k)
+                length += int(seq_len[w]) + int(rec["open_dist"][k])
+                if w in visited:
+                    break
+                visited.add(w)
+                sense, same = bool(fl[k] & 1), bool(fl[k] & 2)
+                d = sense if same else not sense
+                nxt = [q for q in range(lo_of(w), hi_of(w)) if bool(fl[q] & 1) == d and int(end[q]) != frm]
+                if len(nxt) != 1:
+                    break
+                frm, k = w, nxt[0]
+        out.append((v, took, length & (2 ** 64 - 1)))
+    return out
+
+
+def assert_same_records(rec, og, seq_len, max_open=None):
+    roots, off, edges, seqlen = og.scaffolds()
+    e = og.edges()
+    want = {int(r): (edges[int(off[i]):int(off[i + 1])], int(seqlen[i])) for i, r in enumerate(roots)}
+    got = {}
+    for i, r in enumerate(rec["root"].tolist()):
+        sl = slice(int(rec["off"][i]), int(rec["off"][i + 1]))
+        got[r] = (rec["eid"][sl].astype(np.uint64), int(rec["seqlen"][i]))
+        for k in ("end", "dist", "std_dev", "flags"):
+            assert np.array_equal(rec[k][sl], e[k][rec["eid"][sl].astype(np.int64)]), k
+    assert np.all(np.diff(rec["root"].astype(np.int64)) > 0) and np.all(np.diff(rec["open_root"].astype(np.int64)) > 0)
+    for v, took, length in walk_open_part(rec, seq_len):
+        assert v not in got
+        got[v] = (rec["open_eid"][took].astype(np.uint64), length)
+    assert sorted(got) == sorted(want)
+    for r in want:
+        assert np.array_equal(got[r][0], want[r][0]) and got[r][1] == want[r][1], r
+    if max_open is not None:
+        assert len(rec["open_eid"]) <= max_open * max(1, len(rec["eid"])), (len(rec["open_eid"]), len(rec["eid"]))
+
+
+@pytest.mark.parametrize("case", ["small", "noisy", "inversions", "relisted", "100k", "empty"])
+def test_scaffold_records_ranked_on_the_device(case):
+    """ref gt_scaffolder_algorithms.c:901-997 as a list ranking of the clean SCAFFOLD paths
+    (gtsg_scaffold_records) plus the open part walked in the reference's order: every record of
+    the oracle's walk, root by root -- edges in walk order, summed length"""
+    g = {"small": lambda: make_inputs(3000, 17, repeat_degree=12),
+         "noisy": lambda: make_inputs(20000, 5, p_chimeric=0.3, p_bubble=0.1, p_repeat=0.05, links_per_side=3),
+         "inversions": lambda: make_inputs(30000, 9, p_inversion=0.3),
+         "relisted": lambda: make_inputs(20000, 11, p_relist=0.1, p_relist_flip=0.5),
+         "100k": lambda: make_inputs(100000, 5, contig_median=320, links_per_side=5, p_repeat=0.03,
+                                     repeat_degree=43, p_inversion=0.0, unique_pairs=True),
+         "empty": lambda: make_inputs(500, 3)}[case]()
+    if case == "empty":
+        for k in ("root", "ctg", "dist", "std_dev", "num_pairs", "flags"):
+            g[k] = g[k][:0]
+    eng, og = run_pipeline(g)
+    rec = eng.scaffold_records()
+    assert_same_records(rec, og, g["seq_len"], max_open=None if case in ("relisted", "noisy") else 0.2)
+    if case != "empty":
+        assert len(rec["eid"]) > 0 and int(np.diff(rec["off"].astype(np.int64)).max()) > 2
+    # and before any stage ran: no SCAFFOLD edges, every unmarked contig is a record
+    eng2 = engine_from_inputs(g)
+    og2 = oracle_from_inputs(g)
+    rec2 = eng2.scaffold_records()
+    assert len(rec2["eid"]) == 0 and len(rec2["open_root"]) == 0
+    assert_same_records(rec2, og2, g["seq_len"])
+
+
+def test_records_of_scaffold_paths_with_two_orientations(tmp_path):
+    """A pair listed twice with another orientation (parser.c:357-366 alters one direction
+    only) leaves SCAFFOLD paths whose two directions disagree: they go to the open part, the
+    host walks them in the reference's order of visits; same .scaf as the oracle, and as the
+    host walk of everything"""
+    import filecmp
+    g = make_inputs(3000, 77, p_chimeric=0.05, unique_pairs=True)
+    rng = np.random.default_rng(5)
+    picks = rng.choice(len(g["root"]), 400, replace=False)
+    g2 = dict(g)
+    extra = dict(root=g["root"][picks], ctg=g["ctg"][picks], dist=g["dist"][picks] + 37,
+                 std_dev=(g["std_dev"].max() + 100.0 + picks % 7).astype(np.float32),
+                 num_pairs=(3 + picks % 5).astype(g["num_pairs"].dtype),
+                 flags=rng.integers(0, 4, len(picks)).astype(np.uint8))
+    for k in extra:
+        g2[k] = np.concatenate([g[k], extra[k].astype(g[k].dtype)])
+    pkg.synth.write_files(g2, str(tmp_path / "syn"))
+    fa, de, astat = [str(tmp_path / ("syn" + x)) for x in (".fa", ".de", ".astat")]
+    og = OracleGraph.from_files(fa, de)
+    G = pkg.engine.ScaffolderGraph.from_files(fa, de)
+    og.mark_repeats_file(astat); G.mark_repeats(astat)
+    og.filter(); G.filter(); og.makescaffold(True); G.makescaffold()
+    og.write_scaffold(str(tmp_path / "o.scaf"))
+    L = pkg.engine.lib()
+    lens = G.write_scaffold(str(tmp_path / "e.scaf"))
+    assert L.gt_scaffolder_last_record_walk() == 0
+    assert filecmp.cmp(tmp_path / "o.scaf", tmp_path / "e.scaf", shallow=False)
+    assert np.array_equal(lens, og.scaffolds()[3])
+    L.gt_scaffolder_set_record_walk(1)
+    try:
+        G.write_scaffold(str(tmp_path / "h.scaf"))
+    finally:
+        L.gt_scaffolder_set_record_walk(0)
+    assert L.gt_scaffolder_last_record_walk() == 1
+    assert filecmp.cmp(tmp_path / "o.scaf", tmp_path / "h.scaf", shallow=False)
