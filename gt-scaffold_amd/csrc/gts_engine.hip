@@ -163,6 +163,9 @@ struct GtsgEngine {
   int64_t help_walks = 1;    /* k_components_pool: walks of a cc that have to be made one by one go over the workgroup's wavefronts (GtsHelpJob) */
   int64_t local_marks = 1;   /* LDS programs keep their CYCLIC / SCAFFOLD marks in the working copy until they are done */
   int64_t timing_skip_writeback = 0;   /* timing aid (results are wrong): what the scattered write-back of the fast program costs */   /* two workgroups with half a pool each per CU; 0: one with the whole pool */
+  bool pair_sort_full = false;         /* build: sort the records on (larger, smaller) contig, not by the larger one only */
+  int64_t pair_bucket_limit = 2048;    /* build: records a thread of k_pair_segments_bucket looks at one way before the full sort is asked for */
+  bool gather_nt = true;               /* build: nontemporal stores for the coalesced outputs of the gather kernels */
   int64_t gather_unroll = 4;           /* edges a thread of the gather-shaped build kernels (1: A/B measurements) */
   int64_t lds_poison = -1;             /* test aid: fill a component's pages with this byte before staging */
   int64_t pool_wait_limit_us = 10000000; /* bound of every wait inside that launch (0: test aid, a wait gives up at once) */
@@ -373,23 +376,6 @@ __global__ void k_iota(uint32_t *p, uint64_t n)
 }
 
 /* ---- build ---- */
-__global__ void k_pair_keys(const uint32_t *root, const uint32_t *ctg,
-                            uint64_t *keys, uint32_t *vals, uint64_t nrec,
-                            uint32_t n, uint32_t *bad)
-{
-  uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nrec) return;
-  uint32_t a = root[k], b = ctg[k];
-  /* ids come straight from the caller: nothing may be indexed with them before
-     the host has seen this flag */
-  if (a >= n || b >= n) *bad = 1;
-  uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-  /* bit 63 (contig ids stay below 2^31, no sorting pass looks at it): the
-     record is listed from the smaller contig */
-  keys[k] = ((uint64_t)hi << 32) | lo | (a <= b ? 1ull << 63 : 0ull);
-  vals[k] = (uint32_t)k;
-}
-
 /* One thread per sorted position.  Records of one contig pair are adjacent,
    in file order: the first creates both edges, a later record listed from the
    same root replaces the estimate of "its" direction when its std_dev is
@@ -431,6 +417,116 @@ __global__ void k_pair_segments(const uint64_t *keys, const uint32_t *recs,
   if (fw != k0 || bw != k0) { fwd_win[k0] = fw; bwd_win[k0] = bw; replaced[k0] = 1; }
 }
 
+/* The same fold on records that are only BUCKETED: sorted on a few digits of
+   the pair key (bmask: the key bits the sorting passes looked at, about log2 of
+   the number of records of them, so a bucket holds a handful of records of a
+   few pairs).  All records of a pair share a bucket and keep their file order
+   there, which is all the fold needs: a record is the creator iff no earlier
+   record of its bucket has the same pair; a creator folds the later ones of
+   its pair as above.  Half the sorting passes of the full order (three instead
+   of six for 100 M records of 10 M contigs) -- and the digits are taken from
+   the low bits of BOTH contigs, so a contig with thousands of links does not
+   make a long bucket.  The workgroup's 256 keys and 32 either side are staged
+   in LDS and looked at eight at a time (independent reads: a loop that ends on
+   the key it has just read costs a latency per record); records and
+   deviations are fetched by all lanes at once after the search.  A thread
+   whose bucket reaches beyond the staged keys goes on in global memory, and
+   one that would have to look at more than `limit` records one way raises
+   *over: the host then sorts on the full key (ids that agree in their low
+   bits, e.g. all multiples of 256; quadratic work here). */
+#define GTS_SEG_HALO 32
+__global__ void __launch_bounds__(GTS_BLOCK)
+k_pair_segments_bucket(const uint64_t *keys, const uint32_t *recs,
+                       const float *sd, uint8_t *is_creator, uint8_t *replaced,
+                       uint32_t *fwd_win, uint32_t *bwd_win, uint64_t nrec,
+                       int never_replace, uint64_t bmask, uint32_t limit, uint32_t *over)
+{
+  __shared__ uint64_t s_key[GTS_BLOCK + 2 * GTS_SEG_HALO];
+  const uint64_t PAIR = ~(1ull << 63);
+  const uint64_t base = (uint64_t)blockIdx.x * GTS_BLOCK;
+  for (uint32_t t = threadIdx.x; t < GTS_BLOCK + 2 * GTS_SEG_HALO; t += GTS_BLOCK) {
+    const uint64_t g = base + t;   /* index + halo */
+    s_key[t] = (g >= GTS_SEG_HALO && g - GTS_SEG_HALO < nrec) ? keys[g - GTS_SEG_HALO] : 0ull;
+  }
+  __syncthreads();
+  const uint64_t i = base + threadIdx.x;
+  if (i >= nrec) return;
+  const uint32_t at = threadIdx.x + GTS_SEG_HALO;
+  const uint64_t key = s_key[at];
+  {
+    const uint32_t avail = i < GTS_SEG_HALO ? (uint32_t)i : GTS_SEG_HALO;   /* staged records before this one */
+    bool edge = false, found = false;
+    for (uint32_t c = 0; c < GTS_SEG_HALO && !edge && !found; c += 8) {
+      uint64_t kj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) kj[u] = s_key[at - c - 1 - u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint64_t x = kj[u] ^ key;
+        if (edge || found) continue;
+        if (c + 1 + u > avail || (x & bmask) != 0) edge = true;
+        else if ((x & PAIR) == 0) found = true;
+      }
+    }
+    if (!edge && !found) {   /* the bucket starts before the staged keys (i >= GTS_SEG_HALO here) */
+      const uint64_t jmin = i > limit ? i - limit : 0;
+      uint64_t j = i - GTS_SEG_HALO;
+      while (j-- > jmin) {
+        const uint64_t x = keys[j] ^ key;
+        if ((x & bmask) != 0) { edge = true; break; }
+        if ((x & PAIR) == 0) { found = true; break; }
+      }
+      if (!edge && !found && jmin > 0) { *over = 1; return; }
+    }
+    if (found) { is_creator[recs[i]] = 0; return; }
+  }
+  if (never_replace) return;   /* ismatepair: an existing edge is never altered (parser.c:362) */
+  /* where the pair's next record is, from the staged keys */
+  const bool selfloop = ((uint32_t)(key >> 32) & 0x7FFFFFFFu) == (uint32_t)key;
+  const uint32_t avail = nrec - 1 - i < GTS_SEG_HALO ? (uint32_t)(nrec - 1 - i) : GTS_SEG_HALO;
+  uint32_t first = 0, nmatch = 0;
+  bool edge = false;
+  for (uint32_t c = 0; c < GTS_SEG_HALO && !edge; c += 8) {
+    uint64_t kj[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) kj[u] = s_key[at + c + 1 + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint64_t x = kj[u] ^ key;
+      if (edge) continue;
+      if (c + 1 + u > avail || (x & bmask) != 0) { edge = true; continue; }
+      if ((x & PAIR) == 0 && nmatch++ == 0) first = c + 1 + u;
+    }
+  }
+  if (nmatch == 0 && edge) return;   /* the pair's only record */
+  uint32_t k0 = recs[i], fw = k0, bw = k0;
+  float fsd = 0.f, bsd = 0.f;
+  if (nmatch) {
+    const uint64_t kj = s_key[at + first];
+    const uint32_t k = recs[i + first];
+    const float s0 = sd[k0], s = sd[k];
+    fsd = bsd = s0;
+    if (selfloop || ((kj ^ key) >> 63) == 0) { if (fsd < s) { fsd = s; fw = k; } }   /* same root */
+    else { if (bsd < s) { bsd = s; bw = k; } }
+  }
+  if (nmatch > 1 || !edge) {   /* a pair listed three times or more, or a bucket that goes on: one by one */
+    if (!nmatch) fsd = bsd = sd[k0];
+    const uint64_t jmax = nrec - i - 1 > limit ? i + 1 + limit : nrec;
+    uint64_t j = i + (nmatch ? first : GTS_SEG_HALO) + 1;
+    for (; j < jmax; ++j) {
+      const uint64_t kj = keys[j];
+      if (((kj ^ key) & bmask) != 0) break;
+      if (((kj ^ key) & PAIR) != 0) continue;
+      const uint32_t k = recs[j];
+      const float s = sd[k];
+      if (selfloop || ((kj ^ key) >> 63) == 0) { if (fsd < s) { fsd = s; fw = k; } }
+      else { if (bsd < s) { bsd = s; bw = k; } }
+    }
+    if (j >= jmax && jmax < nrec) { *over = 1; return; }
+  }
+  if (fw != k0 || bw != k0) { fwd_win[k0] = fw; bwd_win[k0] = bw; replaced[k0] = 1; }
+}
+
 struct __attribute__((aligned(32))) GtsEdgeRec {
   int64_t dist;
   int64_t npairs;
@@ -445,7 +541,7 @@ __global__ void k_emit_edges(const uint8_t *is_creator, const uint8_t *replaced,
                              const uint32_t *root, const uint32_t *ctg,
                              const int64_t *dist, const float *sd,
                              const int64_t *npairs, const uint8_t *flags,
-                             uint32_t *estart, uint32_t *ids, GtsEdgeRec *rec, uint64_t nrec)
+                             uint32_t *estart, GtsEdgeRec *rec, uint64_t nrec)
 {
   uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nrec) return;
@@ -472,8 +568,7 @@ __global__ void k_emit_edges(const uint8_t *is_creator, const uint8_t *replaced,
      compaction does not have to fetch the twin's flags per edge */
   if (((b.flags & GTS_F_SENSE) != 0) == gts_next_dir((uint8_t)a.flags)) a.flags |= GTS_F_UTURN;
   if (((a.flags & GTS_F_SENSE) != 0) == gts_next_dir((uint8_t)b.flags)) b.flags |= GTS_F_UTURN;
-  estart[e0] = r; estart[e0 + 1] = c;
-  ids[e0] = (uint32_t)e0; ids[e0 + 1] = (uint32_t)e0 + 1u;   /* values of the CSR sort */
+  estart[e0] = r; estart[e0 + 1] = c;   /* (the values of the CSR sort, the edge ids, are made by its first pass) */
   rec[e0] = a; rec[e0 + 1] = b;
 }
 
@@ -487,14 +582,19 @@ __global__ void k_row_offsets(const uint32_t *sorted_start, uint32_t *row,
   for (uint32_t v = lo; v <= hi; ++v) row[v] = (uint32_t)i;
 }
 
-#define GTS_GATHER_UNROLL 4
-template <int GTS_U, bool INV = true>
+/* coalesced outputs that are not read again soon go past the caches */
+template <bool NT, typename T>
+__device__ __forceinline__ void gts_store(T *p, T v)
+{
+  if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <int GTS_U, bool NT>
 __global__ void k_gather_csr(const uint32_t *perm, const GtsEdgeRec *rec,
                              uint32_t *eend, int64_t *dist, int64_t *npairs,
                              float *sd, uint8_t *flags, uint8_t *state,
                              uint32_t *pos_of_eid, uint32_t m)
 {
-  /* four edges a thread, the four random 32-byte records in flight together:
+  /* several edges a thread, their random 32-byte records in flight together:
      one dependent gather per thread leaves the memory system idle (1.4 TB/s) */
   const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x) * GTS_U + threadIdx.x;
   uint32_t id[GTS_U];
@@ -510,16 +610,17 @@ __global__ void k_gather_csr(const uint32_t *perm, const GtsEdgeRec *rec,
   for (int k = 0; k < GTS_U; ++k) {
     const uint64_t p = base + (uint64_t)k * blockDim.x;
     if (p >= m) continue;
-    eend[p] = r[k].end; dist[p] = r[k].dist; npairs[p] = r[k].npairs; sd[p] = r[k].sd;
-    flags[p] = (uint8_t)r[k].flags; state[p] = GIS_UNVISITED;
-    if (INV) pos_of_eid[id[k]] = (uint32_t)p;   /* (INV = false: timing aid, gather_unroll = 101) */
+    gts_store<NT>(eend + p, r[k].end); gts_store<NT>(dist + p, r[k].dist);
+    gts_store<NT>(npairs + p, r[k].npairs); gts_store<NT>(sd + p, r[k].sd);
+    gts_store<NT>(flags + p, (uint8_t)r[k].flags); gts_store<NT>(state + p, (uint8_t)GIS_UNVISITED);
+    pos_of_eid[id[k]] = (uint32_t)p;
   }
 }
-template <int GTS_U>
+template <int GTS_U, bool NT>
 __global__ void k_twins(const uint32_t *eid, const uint32_t *pos_of_eid,
                         uint32_t *twin, uint32_t m)
 {
-  /* four gathers a thread in flight (see k_gather_csr) */
+  /* several gathers a thread in flight (see k_gather_csr) */
   const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x) * GTS_U + threadIdx.x;
   uint32_t id[GTS_U], t[GTS_U];
 #pragma unroll
@@ -532,7 +633,7 @@ __global__ void k_twins(const uint32_t *eid, const uint32_t *pos_of_eid,
 #pragma unroll
   for (int k = 0; k < GTS_U; ++k) {
     const uint64_t p = base + (uint64_t)k * blockDim.x;
-    if (p < m) twin[p] = t[k];
+    if (p < m) gts_store<NT>(twin + p, t[k]);
   }
 }
 __global__ void k_hub_flags(const uint32_t *row, uint32_t *flag, uint32_t n,
@@ -2399,6 +2500,9 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "pool_waves") && value >= 1 && value <= GTS_POOL_WAVES) e->pool_waves = value;
   else if (!strcmp(name, "lds_poison") && value >= -1 && value <= 256) e->lds_poison = value;   /* 256: also clobbers the canaries */
   else if (!strcmp(name, "gather_unroll") && value >= 1) e->gather_unroll = value;
+  else if (!strcmp(name, "gather_nt")) e->gather_nt = value != 0;
+  else if (!strcmp(name, "pair_sort_full")) e->pair_sort_full = value != 0;
+  else if (!strcmp(name, "pair_bucket_limit") && value >= 1 && value <= (1 << 20)) e->pair_bucket_limit = value;
   else if (!strcmp(name, "pool_fill_kb") && value >= 0) e->pool_fill_kb = value;
   else if (!strcmp(name, "fast_components")) e->fast_components = value != 0;
   else if (!strcmp(name, "fast_split")) e->fast_split = value != 0;
@@ -2521,30 +2625,62 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
     PALLOC(k0, uint64_t, nrec); PALLOC(k1, uint64_t, nrec);
     PALLOC(v0, uint32_t, nrec); PALLOC(v1, uint32_t, nrec);
     PALLOC(stmp, uint32_t, gts_sort_tmp_elems(nrec));
-    HIPCHK(hipMemsetAsync(e->d_scalars + 6, 0, 4, e->st));
-    LAUNCH("build_pair_keys", k_pair_keys, nblk(nrec), GTS_BLOCK, d_root, d_ctg, k0, v0, nrec, n,
-           e->d_scalars + 6);
-    const int vb = bits_for(n);
-    int shifts[8], np = 0;
-    for (int s = 0; s < vb; s += 8) shifts[np++] = s;
-    for (int s = 0; s < vb; s += 8) shifts[np++] = 32 + s;
-    int where;
-    { ProfScope ps(e, "build_sort_pairs");
-      where = gts_radix_sort<uint64_t>(k0, v0, k1, v1, nrec, shifts, np, stmp, e->st); }
-    if (where < 0) return fail(e, GTSG_ELIMIT, "too many records for the pair sort");
-    uint64_t *ks = where ? k1 : k0;
-    uint32_t *vs = where ? v1 : v0;
-    /* reuse the other value buffer and fresh arrays for the segment fold */
     PALLOC(t_isc, uint8_t, nrec); PALLOC(t_rep, uint8_t, nrec);
     is_creator = t_isc; replaced = t_rep;
-    HIPCHK(hipMemsetAsync(replaced, 0, nrec, e->st));
     PALLOC(t_fwd, uint32_t, nrec); PALLOC(t_bwd, uint32_t, nrec);
     PALLOC(t_jidx, uint32_t, nrec);
     PALLOC(sctmp, uint32_t, gts_scan_tmp_elems(nrec));
     fwd = t_fwd; bwd = t_bwd; jidx = t_jidx;
-    HIPCHK(hipMemsetAsync(is_creator, 1, nrec, e->st));
-    LAUNCH("build_pair_segments", k_pair_segments, nblk(nrec), GTS_BLOCK, ks, vs, d_sd,
-           is_creator, replaced, fwd, bwd, nrec, ismatepair ? 1 : 0);
+    HIPCHK(hipMemsetAsync(e->d_scalars + 6, 0, 8, e->st));
+    e->stats["pair_sort_fallback"] = 0;
+    const int vb = bits_for(n);
+    /* the pair keys are made inside the sort's first pass (and its histogram
+       pass) from the records themselves: no key / value arrays are written first */
+    const GtsSortSrc src = {GTS_SRC_RECORDS, d_root, d_ctg, n, e->d_scalars + 6};
+    /* first the short way: the records bucketed on about log2(nrec) bits taken from
+       the low end of both contig ids (k_pair_segments_bucket); the full order on
+       (larger, smaller) when a bucket is too long for that, or when asked for
+       (pair_sort_full) */
+    for (int full = e->pair_sort_full ? 1 : 0; full < 2; ++full) {
+      int shifts[8], np = 0;
+      uint64_t bmask = 0;
+      if (full) {
+        for (int s = 0; s < vb; s += 8) shifts[np++] = s;
+        for (int s = 0; s < vb; s += 8) shifts[np++] = 32 + s;
+      } else {
+        /* digits alternately from the smaller and the larger contig, lowest first,
+           until the buckets hold ~8 records on average or the ids are used up */
+        const int want = bits_for(nrec) > 4 ? bits_for(nrec) - 3 : 1;
+        for (int s = 0; s < vb && 8 * np < want; s += 8) {
+          shifts[np++] = s;
+          if (8 * np < want) shifts[np++] = 32 + s;
+        }
+        for (int q = 0; q < np; ++q) {
+          const int width = vb - (shifts[q] & 31) < 8 ? vb - (shifts[q] & 31) : 8;
+          bmask |= ((1ull << width) - 1) << shifts[q];
+        }
+      }
+      int where;
+      { ProfScope ps(e, "build_sort_pairs");
+        where = gts_radix_sort<uint64_t>(k0, v0, k1, v1, nrec, shifts, np, stmp, e->st, &src); }
+      if (where < 0) return fail(e, GTSG_ELIMIT, "too many records for the pair sort");
+      uint64_t *ks = where ? k1 : k0;
+      uint32_t *vs = where ? v1 : v0;
+      HIPCHK(hipMemsetAsync(replaced, 0, nrec, e->st));
+      HIPCHK(hipMemsetAsync(is_creator, 1, nrec, e->st));
+      if (full) {
+        LAUNCH("build_pair_segments", k_pair_segments, nblk(nrec), GTS_BLOCK, ks, vs, d_sd,
+               is_creator, replaced, fwd, bwd, nrec, ismatepair ? 1 : 0);
+        break;
+      }
+      LAUNCH("build_pair_segments", k_pair_segments_bucket, nblk(nrec), GTS_BLOCK, ks, vs, d_sd,
+             is_creator, replaced, fwd, bwd, nrec, ismatepair ? 1 : 0, bmask, (uint32_t)e->pair_bucket_limit,
+             e->d_scalars + 7);
+      uint32_t over = 0;
+      if ((rc = read_u32(e, e->d_scalars + 7, &over))) return rc;
+      if (!over) break;
+      e->stats["pair_sort_fallback"] += 1;
+    }
     { ProfScope ps(e, "build_scan_creators");
       gts_exscan<uint8_t, uint32_t>(is_creator, jidx, nrec, sctmp, e->d_scalars, e->st); }
     uint32_t bad = 0;
@@ -2580,28 +2716,29 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
     PALLOC(rec, GtsEdgeRec, m);
     PALLOC(stmp2, uint32_t, gts_sort_tmp_elems(m));
     LAUNCH("build_emit_edges", k_emit_edges, nblk(nrec), GTS_BLOCK, is_creator, replaced, jidx, fwd,
-           bwd, d_root, d_ctg, d_dist, d_sd, d_np, d_flags, es0, id0, rec, nrec);
+           bwd, d_root, d_ctg, d_dist, d_sd, d_np, d_flags, es0, rec, nrec);
     int where;
+    const GtsSortSrc iota = {GTS_SRC_IOTA, nullptr, nullptr, 0, nullptr};
     { ProfScope ps(e, "build_sort_csr");
-      where = gts_radix_sort<uint32_t>(es0, id0, es1, id1, m, shifts, np, stmp2, e->st); }
+      where = gts_radix_sort<uint32_t>(es0, id0, es1, id1, m, shifts, np, stmp2, e->st, &iota); }
     if (where < 0 || (where ? es1 : es0) != e->estart)
       return fail(e, GTSG_EHIP, "CSR sort ended in the wrong buffer");
     LAUNCH("build_row_offsets", k_row_offsets, nblk((uint64_t)m + 1), GTS_BLOCK, e->estart,
            e->row, n, m);
-    if (e->gather_unroll == 101) {   /* timing aid: the gather without the inverse permutation (results are wrong) */
-      LAUNCH("build_gather_csr", (k_gather_csr<GTS_GATHER_UNROLL, false>), nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK,
-             e->eid, rec, e->eend, e->dist, e->npairs, e->sd, e->flags, e->state, e->pos_of_eid, m);
-      LAUNCH("build_twins", k_twins<GTS_GATHER_UNROLL>, nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK, e->eid,
-             e->pos_of_eid, e->twin, m);
-    } else if (e->gather_unroll > 1) {
-      LAUNCH("build_gather_csr", k_gather_csr<GTS_GATHER_UNROLL>, nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK,
-             e->eid, rec, e->eend, e->dist, e->npairs, e->sd, e->flags, e->state, e->pos_of_eid, m);
-      LAUNCH("build_twins", k_twins<GTS_GATHER_UNROLL>, nblk(m, GTS_BLOCK * GTS_GATHER_UNROLL), GTS_BLOCK, e->eid,
-             e->pos_of_eid, e->twin, m);
+#define GTS_GATHER_LAUNCH(U, NT)                                                                          \
+  do {                                                                                                   \
+    LAUNCH("build_gather_csr", (k_gather_csr<U, NT>), nblk(m, GTS_BLOCK * U), GTS_BLOCK, e->eid, rec,    \
+           e->eend, e->dist, e->npairs, e->sd, e->flags, e->state, e->pos_of_eid, m);                    \
+    LAUNCH("build_twins", (k_twins<U, NT>), nblk(m, GTS_BLOCK * U), GTS_BLOCK, e->eid, e->pos_of_eid,    \
+           e->twin, m);                                                                                  \
+  } while (0)
+    const int gu = (int)e->gather_unroll;
+    if (e->gather_nt) {
+      if (gu >= 8) GTS_GATHER_LAUNCH(8, true); else if (gu >= 4) GTS_GATHER_LAUNCH(4, true);
+      else if (gu >= 2) GTS_GATHER_LAUNCH(2, true); else GTS_GATHER_LAUNCH(1, true);
     } else {
-      LAUNCH("build_gather_csr", k_gather_csr<1>, nblk(m), GTS_BLOCK, e->eid, rec, e->eend, e->dist, e->npairs,
-             e->sd, e->flags, e->state, e->pos_of_eid, m);
-      LAUNCH("build_twins", k_twins<1>, nblk(m), GTS_BLOCK, e->eid, e->pos_of_eid, e->twin, m);
+      if (gu >= 8) GTS_GATHER_LAUNCH(8, false); else if (gu >= 4) GTS_GATHER_LAUNCH(4, false);
+      else if (gu >= 2) GTS_GATHER_LAUNCH(2, false); else GTS_GATHER_LAUNCH(1, false);
     }
   } else
     HIPCHK(hipMemsetAsync(e->row, 0, ((size_t)n + 1) * 4, e->st));

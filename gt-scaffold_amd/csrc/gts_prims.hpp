@@ -189,10 +189,40 @@ __device__ __forceinline__ uint32_t gts_lookback(uint32_t *status, uint32_t tile
   return gbase + excl;
 }
 
+/* Where the first pass (and the histogram pass) takes its pairs from.
+   GTS_SRC_PLAIN: (keys, vals) arrays.  GTS_SRC_IOTA: keys array, value = index
+   (no value array is read).  GTS_SRC_RECORDS (64-bit keys only): the key is made
+   from the record's two contig ids a[i], b[i] -- (max << 32) | min, bit 63 = "listed
+   from the smaller contig" -- and the value is the record number; ids of nvert
+   or more raise *bad (the caller looks at it before anything is indexed with
+   them). */
+enum { GTS_SRC_PLAIN = 0, GTS_SRC_IOTA = 1, GTS_SRC_RECORDS = 2 };
+struct GtsSortSrc {
+  int kind;
+  const uint32_t *a, *b;
+  uint32_t nvert;
+  uint32_t *bad;
+};
+__device__ __forceinline__ uint64_t gts_pair_key(uint32_t a, uint32_t b)
+{
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  return ((uint64_t)hi << 32) | lo | (a <= b ? 1ull << 63 : 0ull);
+}
+template <typename K, int SRC>
+__device__ __forceinline__ K gts_sort_key(const K *keys, const GtsSortSrc &src, uint64_t idx)
+{
+  if constexpr (SRC == GTS_SRC_RECORDS && sizeof(K) == 8) {
+    const uint32_t a = src.a[idx], b = src.b[idx];
+    if (a >= src.nvert || b >= src.nvert) *src.bad = 1;
+    return (K)gts_pair_key(a, b);
+  } else
+    return keys[idx];
+}
+
 /* digit histograms of every pass in one read of the keys: ghist[pass][256] */
-template <typename K>
+template <typename K, int SRC>
 __global__ void __launch_bounds__(GTS_BLOCK)
-k_onesweep_hist(const K *keys, uint64_t n, uint32_t *ghist, int npasses, int s0, int s1, int s2,
+k_onesweep_hist(const K *keys, GtsSortSrc src, uint64_t n, uint32_t *ghist, int npasses, int s0, int s1, int s2,
                 int s3, int s4, int s5, int s6, int s7)
 {
   __shared__ uint32_t h[8][256];
@@ -201,7 +231,7 @@ k_onesweep_hist(const K *keys, uint64_t n, uint32_t *ghist, int npasses, int s0,
   __syncthreads();
   for (uint64_t idx = (uint64_t)blockIdx.x * GTS_BLOCK + threadIdx.x; idx < n;
        idx += (uint64_t)gridDim.x * GTS_BLOCK) {
-    const K k = keys[idx];
+    const K k = gts_sort_key<K, SRC>(keys, src, idx);
 #pragma unroll
     for (int p = 0; p < 8; ++p)
       if (p < npasses) atomicAdd(&h[p][gts_digit(k, sh[p])], 1u);
@@ -238,9 +268,9 @@ k_onesweep_bases(uint32_t *ghist)
    with 12, 5.7 with 16; 32-bit 1.96 ms for three passes with 16, 2.2 with 12) */
 template <typename K> struct GtsSortItems { static const int value = sizeof(K) > 4 ? 12 : 16; };
 
-template <typename K, int ITEMS>
+template <typename K, int ITEMS, int SRC>
 __global__ void __launch_bounds__(GTS_SB)
-k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
+k_radix_scatter(const K *keys, const uint32_t *vals, GtsSortSrc src, K *okeys, uint32_t *ovals,
                 uint64_t n, int shift, const uint32_t *gbase, uint32_t *status,
                 uint32_t *ticket)
 {
@@ -263,8 +293,9 @@ k_radix_scatter(const K *keys, const uint32_t *vals, K *okeys, uint32_t *ovals,
   for (int i = 0; i < ITEMS; ++i) {
     const uint64_t idx = wbase + (uint64_t)i * GTS_WAVE + lane;
     const bool valid = idx < n;
-    key[i] = valid ? keys[idx] : (K)0;
-    val[i] = valid ? vals[idx] : 0u;
+    key[i] = valid ? gts_sort_key<K, SRC>(keys, src, idx) : (K)0;
+    if constexpr (SRC == GTS_SRC_PLAIN) val[i] = valid ? vals[idx] : 0u;
+    else val[i] = (uint32_t)idx;
   }
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
@@ -370,10 +401,25 @@ static inline uint64_t gts_sort_tmp_elems(uint64_t n)
    digit shifts (at most GTS_SORT_MAX_PASSES).  Ping-pongs between (k0, v0) and
    (k1, v1); returns 0 if the result is in (k0, v0), 1 if in (k1, v1), -1 if n
    is too large. */
+template <typename K, int SRC>
+static void gts_sort_first(const K *ki, const uint32_t *vi, const GtsSortSrc &src, K *ko, uint32_t *vo,
+                           uint64_t n, const int *sh, int npasses, uint32_t ntiles, uint32_t hgrid,
+                           uint32_t *ghist, uint32_t *status, uint32_t *ticket, hipStream_t st)
+{
+  k_onesweep_hist<K, SRC><<<hgrid, GTS_BLOCK, 0, st>>>(ki, src, n, ghist, npasses, sh[0], sh[1], sh[2],
+                                                       sh[3], sh[4], sh[5], sh[6], sh[7]);
+  k_onesweep_bases<<<npasses, GTS_BLOCK, 0, st>>>(ghist);
+  k_radix_scatter<K, GtsSortItems<K>::value, SRC><<<ntiles, GTS_SB, 0, st>>>(ki, vi, src, ko, vo, n, sh[0],
+                                                                            ghist, status, ticket);
+}
+
+/* src (optional) describes where the first pass reads from: with
+   GTS_SRC_IOTA v0 is never read, with GTS_SRC_RECORDS neither k0 nor v0 is;
+   the result still ends in (k0, v0) or (k1, v1) as the return value says. */
 template <typename K>
 static int gts_radix_sort(K *k0, uint32_t *v0, K *k1, uint32_t *v1, uint64_t n,
                           const int *shifts, int npasses, uint32_t *tmp,
-                          hipStream_t st)
+                          hipStream_t st, const GtsSortSrc *srcp = nullptr)
 {
   if (n == 0) return 0;
   if (n >= GTS_ONESWEEP_MAX_N || npasses > GTS_SORT_MAX_PASSES) return -1;
@@ -385,15 +431,22 @@ static int gts_radix_sort(K *k0, uint32_t *v0, K *k1, uint32_t *v1, uint64_t n,
   int sh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int p = 0; p < npasses; ++p) sh[p] = shifts[p];
   const uint32_t hgrid = ntiles < 4096 ? ntiles : 4096;
-  k_onesweep_hist<K><<<hgrid, GTS_BLOCK, 0, st>>>(k0, n, ghist, npasses, sh[0], sh[1], sh[2], sh[3],
-                                                  sh[4], sh[5], sh[6], sh[7]);
-  k_onesweep_bases<<<npasses, GTS_BLOCK, 0, st>>>(ghist);
-  int cur = 0;
-  for (int p = 0; p < npasses; ++p) {
+  GtsSortSrc src = {GTS_SRC_PLAIN, nullptr, nullptr, 0, nullptr};
+  if (srcp) src = *srcp;
+  if (npasses == 0) return src.kind == GTS_SRC_PLAIN ? 0 : -1;
+  if (src.kind == GTS_SRC_RECORDS && sizeof(K) != 8) return -1;
+  if (src.kind == GTS_SRC_RECORDS)
+    gts_sort_first<K, GTS_SRC_RECORDS>(k0, v0, src, k1, v1, n, sh, npasses, ntiles, hgrid, ghist, status, ticket, st);
+  else if (src.kind == GTS_SRC_IOTA)
+    gts_sort_first<K, GTS_SRC_IOTA>(k0, v0, src, k1, v1, n, sh, npasses, ntiles, hgrid, ghist, status, ticket, st);
+  else
+    gts_sort_first<K, GTS_SRC_PLAIN>(k0, v0, src, k1, v1, n, sh, npasses, ntiles, hgrid, ghist, status, ticket, st);
+  int cur = 1;
+  for (int p = 1; p < npasses; ++p) {
     K *ki = cur ? k1 : k0, *ko = cur ? k0 : k1;
     uint32_t *vi = cur ? v1 : v0, *vo = cur ? v0 : v1;
-    k_radix_scatter<K, GtsSortItems<K>::value><<<ntiles, GTS_SB, 0, st>>>(ki, vi, ko, vo, n, shifts[p], ghist + 256 * p,
-                                                     status + 256ull * ntiles * p, ticket + p);
+    k_radix_scatter<K, GtsSortItems<K>::value, GTS_SRC_PLAIN><<<ntiles, GTS_SB, 0, st>>>(
+        ki, vi, src, ko, vo, n, shifts[p], ghist + 256 * p, status + 256ull * ntiles * p, ticket + p);
     cur ^= 1;
   }
   return cur;

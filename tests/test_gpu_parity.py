@@ -813,6 +813,14 @@ def test_pair_sort_is_stable():
     og = oracle_from_inputs(g)
     eng = engine_from_inputs(g)
     assert_same_graph(eng, og)
+    # the three ways the records of a pair are brought together: sorted by the larger
+    # contig only and folded per bucket whatever its length, the same with the full
+    # sort taken as soon as a thread has looked at 16 records, the full sort from the start
+    for opts, fell_back in ((dict(pair_bucket_limit=1 << 20), 0), (dict(pair_bucket_limit=16), 1),
+                            (dict(pair_sort_full=1), 0)):
+        e2 = engine_from_inputs(g, **opts)
+        assert_same_graph(e2, og)
+        assert e2.stat("pair_sort_fallback") == fell_back, opts
     # and with the never-replace rule of a mate-pair library (parser.c:297, :362)
     og2 = OracleGraph.from_records(g["seq_len"], g["astat"], g["copy_num"], g["root"], g["ctg"], g["dist"],
                                    g["std_dev"], g["num_pairs"], g["flags"], ismatepair=True)
