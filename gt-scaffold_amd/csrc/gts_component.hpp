@@ -158,8 +158,9 @@ struct GtsCompView {
    its terminals (walks_clean_batch_global) and leaves the best walk it has seen. */
 #define GTS_TEAM_WAVES_MAX 16
 struct GtsTeamCtl {
-  uint32_t kind;             /* 1: walks of the cc [tb, te); 0: done, the helpers leave */
+  uint32_t kind;             /* 1: walks of the cc [tb, te); 2: the topological order (peel_team); 0: done, the helpers leave */
   uint32_t tb, te;
+  uint32_t pq_lvl[3];        /* peel_team: contigs appended in level l, at [l % 3] */
   uint32_t slab_ok;
   unsigned long long slab;   /* byte offset of the workgroup's slab */
   unsigned long long len[GTS_TEAM_WAVES_MAX];   /* per wavefront: its longest walk, */
@@ -455,11 +456,18 @@ struct GtsComponent {
   GtsTeamCtl *team;     /* null: no team */
   char *team_base;      /* this workgroup's slab */
   uint32_t team_wave, team_waves;
+  /* LDS addresses of the team's vertex states, BFS queue and edge scratch (GTS_NONE:
+     not in LDS): calc_cc_team reaches them with ds_* instructions */
+  uint32_t tl_vst, tl_queue, tl_scratch;
+  /* LDS the team has no other use for while it makes the walks of a cc (the
+     search's scratch, its queue, the degrees of peel): the position bitmaps of
+     the walks in flight (walks_clean_batch_global) */
+  uint32_t tl_pbits, tl_pbits_bytes;
 
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), local_marks(false), any_scaffold_marks(false), run_clean(false), run_deferred(false), lean_stats(false), hub(nullptr), hub_me(0), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), local_marks(false), any_scaffold_marks(false), run_clean(false), run_deferred(false), lean_stats(false), hub(nullptr), hub_me(0), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1), tl_vst(GTS_NONE), tl_queue(GTS_NONE), tl_scratch(GTS_NONE), tl_pbits(GTS_NONE), tl_pbits_bytes(0) {}
 
   /* a clock read costs a wait for every LDS operation in flight: only where somebody looks */
   GTS_HD uint64_t tick() const { return lean_stats ? 0 : W::clock(); }
@@ -531,7 +539,126 @@ struct GtsComponent {
   }
 
   /* ---- ref algorithms.c:379-436 (with isterminal, :346-373, fused) ---- */
-  GTS_HD void calc_cc() { bool unused; calc_cc_t<false>(unused); }
+  GTS_HD void calc_cc()
+  {
+#if defined(__HIPCC__)
+    if constexpr (W::TEAM && !LDS) {
+      if (tl_vst != GTS_NONE && tl_queue != GTS_NONE && tl_scratch != GTS_NONE) { calc_cc_team(); return; }
+    }
+#endif
+    bool unused;
+    calc_cc_t<false>(unused);
+  }
+
+#if defined(__HIPCC__)
+  /* calc_cc_t<false> for a component in global memory whose vertex states and
+     queue the team keeps in LDS (k_components_team).  The search visits one
+     vertex at a time in queue order (ref algorithms.c:398-430: that order is the
+     order of the terminals, which decides between walks of equal length), and
+     through generic pointers a vertex cost a round trip to L2 for its edges
+     plus the wait for the global stores in flight that a flat_load implies:
+     ~1.1 us a vertex, ten passes over the 8247 contigs of the 50 M workload's
+     largest component = 90 ms.  Here the states and the queue are reached with
+     ds_read / ds_write, and the list bounds and the first GTS_TCC_K edges of the 64
+     queue vertices a chunk holds are fetched by all lanes at once into an LDS
+     scratch: a vertex then costs a few LDS round trips (longer lists read the
+     rest from L2 as before). */
+#define GTS_TCC_K 8u
+  GTS_HD void calc_cc_team()
+  {
+    typedef uint8_t __attribute__((address_space(3))) *l8p;
+    typedef uint32_t __attribute__((address_space(3))) *l32p;
+    typedef uint64_t __attribute__((address_space(3))) *l64p;
+    const l8p vst = (l8p)(uintptr_t)tl_vst;
+    const l32p queue = (l32p)(uintptr_t)tl_queue;
+    const l64p scratch = (l64p)(uintptr_t)tl_scratch;   /* [64][GTS_TCC_K]: end vertex | edge bits << 32 */
+    const uint32_t lane = W::lane();
+    /* the other functions reach the same bytes with flat_* instructions, which
+       are not ordered with ds_* ones: everything in flight lands first (and
+       the ds_writes below before this returns) */
+    __builtin_amdgcn_s_waitcnt(0);
+    for (uint32_t s = lane; s < nv; s += W::WIDTH)
+      if (!gts_vertex_is_marked(vst[s])) vst[s] = GIS_UNVISITED;
+    W::fence();
+    auto ccoff = M.ccoff;
+    nterm = 0; ncc = 0;
+    for (uint32_t base0 = 0; base0 < nv; base0 += W::WIDTH) {
+      uint32_t next_lane = 0;
+      for (;;) {
+        bool cand = false;
+        if (base0 + lane < nv && lane >= next_lane) {
+          const uint8_t st = vst[base0 + lane];
+          cand = !gts_vertex_is_marked(st) && st != GIS_VISITED;
+        }
+        const uint64_t cm = W::ballot(cand);
+        if (!cm) break;
+        const uint32_t l0 = W::ctz(cm);
+        next_lane = l0 + 1;
+        const uint32_t s = base0 + l0;
+        if (lane == 0) { vst[s] = GIS_PROCESSED; queue[0] = s; }
+        ccoff[ncc++] = nterm;
+        W::fence();
+        uint32_t bh = 0, bn = 1;
+        while (bh < bn) {
+          const uint32_t cnt = bn - bh < W::WIDTH ? bn - bh : W::WIDTH;
+          uint32_t my_v = 0, my_eb = 0, my_ee = 0;
+          if (lane < cnt) {
+            my_v = queue[bh + lane];
+            my_eb = M.coff[my_v] - M.e0; my_ee = M.coff[my_v + 1] - M.e0;
+          }
+          {
+            uint32_t nb[GTS_TCC_K], fl[GTS_TCC_K];
+#pragma unroll
+            for (uint32_t k = 0; k < GTS_TCC_K; ++k) {
+              const uint32_t ce = my_eb + k < my_ee ? my_eb + k : my_eb;
+              const bool in = lane < cnt && my_eb + k < my_ee;
+              nb[k] = in ? (uint32_t)M.cend[ce] : 0u;
+              fl[k] = in ? edge_bits(ce) : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < GTS_TCC_K; ++k)
+              scratch[lane * GTS_TCC_K + k] = (uint64_t)nb[k] | (uint64_t)fl[k] << 32;
+          }
+          W::fence();
+          for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t cur = W::bcast(my_v, i), eb = W::bcast(my_eb, i), ee = W::bcast(my_ee, i);
+            bool has_s = false, has_a = false;
+            for (uint32_t base = eb; base < ee; base += W::WIDTH) {
+              const uint32_t ce = base + lane;
+              const bool in = ce < ee;
+              uint32_t fl = 0, nb = 0;
+              if (base == eb && lane < GTS_TCC_K) {
+                const uint64_t x = scratch[i * GTS_TCC_K + lane];
+                nb = (uint32_t)x; fl = (uint32_t)(x >> 32);
+              } else if (in) {   /* (a list of more than GTS_TCC_K entries) */
+                fl = edge_bits(ce); nb = M.cend[ce];
+              }
+              const bool live = in && !bits_marked(fl);
+              const bool sense = (fl & GTS_F_SENSE) != 0;
+              const bool unv = live && vst[nb] == GIS_UNVISITED;
+              has_s |= W::ballot(live && sense) != 0;
+              has_a |= W::ballot(live && !sense) != 0;
+              const uint64_t mask = W::ballot(unv);
+              if (unv) {
+                queue[bn + W::popc_below(mask, lane)] = nb;
+                vst[nb] = GIS_PROCESSED;
+              }
+              bn += W::popc(mask);
+              W::fence();
+            }
+            if (!(has_s && has_a)) M.term[nterm++] = cur;
+            if (lane == 0) vst[cur] = GIS_VISITED;
+            W::fence();
+          }
+          bh += cnt;
+        }
+      }
+    }
+    ccoff[ncc] = nterm;
+    W::fence();
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+#endif
 
   /* ORIENT: also assigns the strands as orient() does.  Only for a component
      whose compact edges are all live: then the terminal search and orient()
@@ -1723,12 +1850,93 @@ struct GtsComponent {
     return true;
   }
 
+  /* peel() of a component in global memory over the team's wavefronts, by levels:
+     the contigs whose in-arcs are all used up take the next positions together,
+     a lane each, and use up their out-arcs with atomic decrements; whoever takes
+     a contig's last in-arc appends it.  Any topological order serves the sweeps
+     (see peel_small), so the order inside a level is left to the atomics.  On one
+     wavefront a pass over the 8247 contigs of the 50 M workload's largest
+     component took 7 ms, and the cycle removal makes one after every cycle it
+     marks: 79 of its 103 ms.  Every wavefront of the team calls this; all return
+     the same.  One barrier a level (the order of that component is ~1000 levels
+     deep, so the barriers are what a pass costs): the number of contigs a level
+     appends is counted in one of three words taken in turn -- level l adds to
+     [l % 3], reads it after the barrier and zeroes [(l + 1) % 3], which the slowest
+     lane stopped reading a barrier ago. */
+  GTS_HD bool peel_team_run()
+  {
+#if defined(__HIPCC__)
+    if constexpr (W::TEAM && !LDS) {
+      const uint32_t lane = W::lane();
+      const uint32_t T = team_waves * W::WIDTH, t = team_wave * W::WIDTH + lane;
+      auto deg = M.st_v;
+      for (int pass = 0; pass < 2; ++pass) {
+        const bool fwd = pass == 0;     /* pass 0 peels sources, pass 1 sinks */
+        const uint32_t bit = fwd ? 4u : 8u;
+        auto Qp = M.topo;
+        if (!fwd) Qp = M.visited;
+        for (uint32_t s = t; s < nv; s += T) {
+          const uint32_t g = M.gorient[s];
+          const bool os = (g & 3u) == 2;
+          uint32_t d = 0;
+          const uint32_t le = M.coff[s + 1] - M.e0;
+          for (uint32_t ce = M.coff[s] - M.e0; ce < le; ++ce)
+            d += d_arc(ce, os, !fwd) ? 1u : 0u;   /* in-arcs when peeling sources */
+          deg[s] = d;
+          M.gorient[s] = (uint8_t)((g & (fwd ? 3u : 7u)) | bit);
+        }
+        if (t == 0) { team->pq_lvl[0] = 0; team->pq_lvl[1] = 0; }
+        W::team_barrier();
+        /* level 0: the sources */
+        for (uint32_t s = t; s < nv; s += T)
+          if (deg[s] == 0) Qp[W::team_add(&team->pq_lvl[0], 1u)] = s;
+        uint32_t th = 0, tn = 0, l = 0;
+        for (;;) {
+          W::team_barrier();
+          const uint32_t added = *(volatile uint32_t *)&team->pq_lvl[l % 3u];
+          th = tn; tn += added; ++l;
+          if (added == 0) break;
+          if (t == 0) team->pq_lvl[(l + 1u) % 3u] = 0;
+          uint32_t *cnt = &team->pq_lvl[l % 3u];
+          for (uint32_t idx = th + t; idx < tn; idx += T) {
+            const uint32_t u = Qp[idx];
+            const uint32_t g = M.gorient[u];
+            if (fwd) M.tpos[u] = idx;
+            M.gorient[u] = (uint8_t)(g & ~bit);
+            const bool ou = (g & 3u) == 2;
+            const uint32_t le = M.coff[u + 1] - M.e0;
+            for (uint32_t ce = M.coff[u] - M.e0; ce < le; ++ce) {
+              if (!d_arc(ce, ou, fwd)) continue;   /* out-arcs when peeling sources */
+              const uint32_t v = M.cend[ce];
+              if (W::team_add(&deg[v], 0xFFFFFFFFu) == 1u) Qp[tn + W::team_add(cnt, 1u)] = v;
+            }
+          }
+        }
+        W::team_barrier();   /* (the words are set again by the next pass) */
+        if (fwd && tn == nv) return true;   /* acyclic: flags all cleared */
+      }
+    }
+#endif
+    return false;
+  }
+
   GTS_HD bool peel()
   {
     const uint32_t lane = W::lane();
     if constexpr (LDS) {
       if (C.small_masks && nv <= W::WIDTH && peel_small()) return true;
     }
+#if defined(__HIPCC__)
+    if constexpr (W::TEAM && !LDS) {
+      if (team && team_waves > 1) {
+        if (lane == 0) team->kind = 2;
+        W::team_barrier();
+        const bool r = peel_team_run();
+        W::team_barrier();
+        return r;
+      }
+    }
+#endif
     auto deg = M.st_v;
     for (int pass = 0; pass < 2; ++pass) {
       const bool fwd = pass == 0;     /* pass 0 peels sources, pass 1 sinks */
@@ -2580,9 +2788,15 @@ struct GtsComponent {
      vertex of a sweep comes from the slot's bitmap over the positions (a walk
      costs its reachable set, not the component: create_walk_clean), eight words
      a step */
+  /* pb_lds: LDS address of the batch's position bitmaps (pb_stride bytes a walk)
+     or GTS_NONE: the bitmaps of the slots in global memory.  A sweep step is a
+     chain of dependent accesses -- the bitmap word, the contig's label and list
+     bounds, its arcs, the labels at their ends, the bit of a new label (an atomic
+     the next step's read waits for): with the bitmap in LDS two of its five round
+     trips to L2 are gone. */
   template <uint32_t L>
-  GTS_HD void walks_clean_batch_global(uint32_t j0, uint32_t nb, char *slots, uint64_t &r_len,
-                                       uint32_t &r_t, bool &r_bad)
+  GTS_HD void walks_clean_batch_global(uint32_t j0, uint32_t nb, char *slots, uint32_t pb_lds, uint32_t pb_stride,
+                                       uint64_t &r_len, uint32_t &r_t, bool &r_bad)
   {
     const uint32_t lane = W::lane(), g = lane / L, a = lane % L;
     const uint32_t gsh = g * L;
@@ -2596,6 +2810,11 @@ struct GtsComponent {
     uint32_t *emap = (uint32_t *)(sbase + p4 + p8);
     uint32_t *par = (uint32_t *)(sbase + 2 * p4 + p8);
     uint32_t *pbits = (uint32_t *)(sbase + 3 * p4 + p8);
+#if defined(__HIPCC__)
+    typedef uint32_t __attribute__((address_space(3))) *l32p;
+    const bool pl = pb_lds != GTS_NONE;
+    const l32p lbits = (l32p)(uintptr_t)(pl ? pb_lds + (active ? g : 0u) * pb_stride : 0u);
+#endif
     const uint32_t start = active ? (uint32_t)M.term[j0 + g] : 0u;
     const uint32_t sb0 = M.coff[start] - M.e0, se0 = M.coff[start + 1] - M.e0;
     bool hs = false, ha = false;
@@ -2626,7 +2845,11 @@ struct GtsComponent {
       const bool scan = active && !have_u;
       const int32_t wi = wcur + (int32_t)a * step;
       const bool inr = scan && wi >= 0 && wi < (int32_t)nw;
-      const uint32_t word = inr ? pbits[wi] : 0u;
+      uint32_t word = 0;
+#if defined(__HIPCC__)
+      if (pl) { if (inr) word = lbits[wi]; } else
+#endif
+      if (inr) word = pbits[wi];
       const uint64_t rb = (W::ballot(word != 0) >> gsh) & gm;
       const uint32_t k = rb ? W::ctz(rb) : 0u;
       const uint32_t wk = W::shfl(word, gsh + k);          /* the word of the group's lane k */
@@ -2634,6 +2857,9 @@ struct GtsComponent {
         if (rb) {
           const uint32_t bit = forward ? W::ctz((uint64_t)wk) : 31u - W::clz32(wk);
           wcur += (int32_t)k * step;
+#if defined(__HIPCC__)
+          if (pl) { if (a == 0) __hip_atomic_fetch_and(lbits + wcur, ~(1u << bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); } else
+#endif
           if (a == 0) W::and_bits(pbits + wcur, ~(1u << bit));
           u = M.topo[(uint32_t)wcur * 32u + bit];
           have_u = true; is_start = false; us = ua = false;
@@ -2672,7 +2898,13 @@ struct GtsComponent {
         par[v] = u;
         plen[v] = plu + (uint64_t)M.cseq[v];
       }
-      if (fresh) { const uint32_t tp = M.tpos[v]; W::or_bits(pbits + (tp >> 5), 1u << (tp & 31)); }
+      if (fresh) {
+        const uint32_t tp = M.tpos[v];
+#if defined(__HIPCC__)
+        if (pl) __hip_atomic_fetch_or(lbits + (tp >> 5), 1u << (tp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); else
+#endif
+        W::or_bits(pbits + (tp >> 5), 1u << (tp & 31));
+      }
       const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
       const uint64_t fm = W::ballot(fresh), tm = W::ballot(tie || wide);
       us |= ((bs >> gsh) & gm) != 0;
@@ -2717,6 +2949,10 @@ struct GtsComponent {
     uint32_t *path = (uint32_t *)(wbase + GTS_WALK_SLOTS_MAX * sbytes);
     const uint64_t a16 = 16, p4 = (((uint64_t)nv * 4 + a16 - 1) / a16) * a16, p8 = (((uint64_t)nv * 8 + a16 - 1) / a16) * a16;
     const uint32_t nw = (nv + 31) / 32;
+    /* this wavefront's G bitmaps in the team's spare LDS, if all of them fit */
+    const uint32_t pb_stride = ((nw * 4u + 15u) / 16u) * 16u;
+    const uint32_t pb_lds = tl_pbits != GTS_NONE && (uint64_t)team_waves * G * pb_stride <= tl_pbits_bytes
+                                ? tl_pbits + team_wave * G * pb_stride : GTS_NONE;
     uint64_t best_len = 0;
     uint32_t best_j = GTS_NONE, best_n = 0;
     bool bad = false;
@@ -2727,6 +2963,13 @@ struct GtsComponent {
         float *dist = (float *)(wbase + k * sbytes);
         uint32_t *pb = (uint32_t *)(wbase + k * sbytes + 3 * p4 + p8);
         for (uint32_t s = lane; s < nv; s += W::WIDTH) dist[s] = GTS_DIST_UNSET;
+#if defined(__HIPCC__)
+        if (pb_lds != GTS_NONE) {
+          uint32_t __attribute__((address_space(3))) *lb =
+              (uint32_t __attribute__((address_space(3))) *)(uintptr_t)(pb_lds + k * pb_stride);
+          for (uint32_t s = lane; s < nw; s += W::WIDTH) lb[s] = 0;
+        } else
+#endif
         for (uint32_t s = lane; s < nw; s += W::WIDTH) pb[s] = 0;
       }
       W::fence();
@@ -2734,7 +2977,7 @@ struct GtsComponent {
       uint64_t r_len;
       uint32_t r_t;
       bool r_bad;
-      walks_clean_batch_global<L>(j0, nb, wbase, r_len, r_t, r_bad);
+      walks_clean_batch_global<L>(j0, nb, wbase, pb_lds, pb_stride, r_len, r_t, r_bad);
       const uint64_t tc2 = W::clock();
       if (lane == 0) {
         W::add64((uint64_t *)C.team_stat + 1, 1); W::add64((uint64_t *)C.team_stat + 4, tc1 - tc0);

@@ -1307,9 +1307,17 @@ k_components(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t coun
    the ccs it posts (GtsTeamCtl) and sweep their share of the cc's walks.  Every
    wavefront meets every barrier: two per posted cc, one for the end. */
 #define GTS_TEAM_WAVES 8u
+/* LDS address (byte offset) of a generic pointer into the workgroup's LDS */
+static __device__ __forceinline__ uint32_t lds_offset(const void *p)
+{
+  return (uint32_t)(uintptr_t)(const char __attribute__((address_space(3))) *)p;
+}
 struct GtsWave64Team : GtsWave64 {
   static const bool TEAM = true;
   static __device__ __forceinline__ void team_barrier() { __syncthreads(); }
+  /* returning add on a word of the workgroup (LDS or global memory) */
+  static __device__ __forceinline__ uint32_t team_add(uint32_t *p, uint32_t v)
+  { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 };
 __global__ void __launch_bounds__(GTS_TEAM_WAVES * GTS_WAVE)
 k_components_team(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t count, int mode,
@@ -1322,6 +1330,7 @@ k_components_team(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
   const uint32_t wv = threadIdx.x / GTS_WAVE;
   C.defer_min_nv = 0; C.defer_ref_min_nv = 0;
   GtsCompMem M = GtsComponent<GtsWave64Team>::global_mem(C, c);
+  uint32_t tl_vst = GTS_NONE, tl_queue = GTS_NONE, tl_scratch = GTS_NONE, tl_pbits = GTS_NONE, tl_pbits_bytes = 0;
   {
     /* the vertex-indexed arrays the traversals chase -- states, strands, the
        queue, degrees, the sweep order -- move to the workgroup's LDS as far as
@@ -1332,11 +1341,17 @@ k_components_team(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
     if (off + nv1 <= lds_bytes) {
       uint8_t *p = (uint8_t *)(smem + off); off += nv1;
       for (uint32_t s = threadIdx.x; s < nv; s += blockDim.x) p[s] = M.vst[s];
-      M.vst = p;
+      M.vst = p; tl_vst = lds_offset(p);
     }
     if (off + nv1 <= lds_bytes) { M.gorient = (uint8_t *)(smem + off); off += nv1; }
-    if (off + nv4 <= lds_bytes) { M.queue = (uint32_t *)(smem + off); off += nv4; }
+    /* the edge scratch of the terminal search (calc_cc_team), its queue and the
+       degrees of peel in one piece: free while the walks of a cc are made, when it
+       holds the walks' position bitmaps */
+    const uint32_t spare0 = off;
+    if (off + 64u * GTS_TCC_K * 8u <= lds_bytes) { tl_scratch = lds_offset(smem + off); off += 64u * GTS_TCC_K * 8u; }
+    if (off + nv4 <= lds_bytes) { M.queue = (uint32_t *)(smem + off); tl_queue = lds_offset(M.queue); off += nv4; }
     if (off + nv4 <= lds_bytes) { M.st_v = (uint32_t *)(smem + off); off += nv4; }
+    tl_pbits = lds_offset(smem + spare0); tl_pbits_bytes = off - spare0;
     if (off + nv4 <= lds_bytes) { M.topo = (uint32_t *)(smem + off); off += nv4; }
     if (off + nv4 <= lds_bytes) { M.tpos = (uint32_t *)(smem + off); off += nv4; }
   }
@@ -1353,6 +1368,8 @@ k_components_team(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
     prog.team = &ctl; prog.team_base = C.team_slab + ctl.slab;
     prog.team_wave = wv; prog.team_waves = GTS_TEAM_WAVES;
   }
+  prog.tl_vst = tl_vst; prog.tl_queue = tl_queue; prog.tl_scratch = tl_scratch;
+  prog.tl_pbits = tl_pbits; prog.tl_pbits_bytes = tl_pbits_bytes;
   if (wv == 0) {
     prog.run(mode);
     if (ok) {
@@ -1364,7 +1381,8 @@ k_components_team(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
     for (;;) {
       __syncthreads();
       if (ctl.kind == 0) break;
-      prog.team_share(ctl.tb, ctl.te);
+      if (ctl.kind == 2) (void)prog.peel_team_run();
+      else prog.team_share(ctl.tb, ctl.te);
       __syncthreads();
     }
   }
@@ -3477,7 +3495,7 @@ static int run_components(GtsgEngine *e, int mode)
           C.team_stat = (unsigned long long *)(e->d_scalars + GTS_S_TEAMSTAT);
           HIPCHK(hipMemsetAsync(C.team_stat, 0, 64, e->st));
           team_ran = true;
-          uint64_t lds = 18ull * maxcomp + 128;
+          uint64_t lds = 18ull * maxcomp + 128 + 64ull * GTS_TCC_K * 8ull;
           if (lds > 159744u - 1024u) lds = 159744u - 1024u;
           { ProfScope ps(e, kname);
             k_components_team<<<kcount[nk], GTS_TEAM_WAVES * GTS_WAVE, (size_t)lds, e->st>>>(
