@@ -70,13 +70,17 @@ def algorithmic_bytes(name, n, m, nrec, eng):
     vb = max(1, (int(n - 1).bit_length() + 7) // 8)         # 8-bit digits per vertex id
     nce = max(eng.stat("compact_edges"), 0)
     ns = max(eng.stat("slots"), 0)
+    pp = max(eng.stat("pair_sort_passes"), 1)
     table = {
-        # 64-bit pair keys + record ids: per digit pass read twice, written once
-        "build_sort_pairs": 2 * vb * nrec * (8 + (8 + 4) + (8 + 4)),
-        "build_sort_csr": vb * m * (4 + (4 + 4) + (4 + 4)),
-        "build_pair_keys": nrec * (8 + 12),
+        # records bucketed on pp digits of the pair key (engine statistic; 3 for 100 M
+        # records): the two contig ids read for the histograms and again by the first
+        # pass (which makes the 64-bit key and the record number), then 12 B per pair
+        # written / read per pass
+        "build_sort_pairs": nrec * (8 + 8 + 12 + (pp - 1) * 24),
+        # start vertex keys; the edge ids are made by the first pass
+        "build_sort_csr": m * (4 + 4 + 8 + (vb - 1) * 16),
         "build_pair_segments": nrec * (12 + 4 + 2),
-        "build_emit_edges": nrec * 8 + m * (29 + 36),
+        "build_emit_edges": nrec * 8 + m * (29 + 32),
         "build_gather_csr": m * (4 + 32 + 30),
         "build_twins": m * 12,
         "build_row_offsets": m * 4 + n * 4,
@@ -133,10 +137,10 @@ def kernel_groups(kt):
 
 # bench-event name -> kernel names in the rocprofv3 --pmc passes
 PMC_NAMES = {
-    "build_sort_pairs": ["k_onesweep_hist<unsigned long>", "k_radix_scatter<unsigned long, 12>"],
-    "build_pair_keys": ["k_pair_keys"], "build_pair_segments": ["k_pair_segments"],
-    "build_emit_edges": ["k_emit_edges"], "build_gather_csr": ["k_gather_csr<4>", "k_gather_csr<1>", "k_gather_csr"],
-    "build_twins": ["k_twins<4>", "k_twins<1>", "k_twins"], "repeat_edges": ["k_repeat_edges"],
+    "build_sort_pairs": ["k_onesweep_hist<unsigned long", "k_radix_scatter<unsigned long"],
+    "build_pair_segments": ["k_pair_segments"],
+    "build_emit_edges": ["k_emit_edges"], "build_gather_csr": ["k_gather_csr"],
+    "build_twins": ["k_twins"], "repeat_edges": ["k_repeat_edges"],
     "filter_pairs": ["k_filter_pairs"], "filter_ovf_init": ["k_filter_ovf_init"],
     "filter_final": ["k_filter_final"], "filter_tpoly": ["k_filter_tpoly"],
     "filter_lasthit": ["k_filter_lasthit"], "comp_live_union": ["k_live_union"],
@@ -162,7 +166,7 @@ def recorded_traffic(name):
         tot2 = sum((d[k]["fetch_bytes_per_launch_x2"] + d[k]["write_bytes_per_launch"]) * d[k]["launches"] for k in ks)
         n = sum(d[k]["launches"] for k in ks)
         return (tot / n, tot2 / n) if n else None      # average over the launches of the recorded step
-    ks = [k for k in PMC_NAMES.get(name, []) if k in d]
+    ks = [k for k in d if any(k.startswith(pre) for pre in PMC_NAMES.get(name, []))]   # (template arguments vary)
     if not ks:
         return None
     per_step = sum((d[k]["fetch_bytes_per_launch_raw"] + d[k]["write_bytes_per_launch"]) * d[k]["launches"] for k in ks)

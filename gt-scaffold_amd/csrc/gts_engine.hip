@@ -2679,6 +2679,7 @@ int gtsg_build_from_records_ex(GtsgEngine *e, uint64_t nrec, const uint32_t *roo
         }
       }
       int where;
+      e->stats["pair_sort_passes"] = np;
       { ProfScope ps(e, "build_sort_pairs");
         where = gts_radix_sort<uint64_t>(k0, v0, k1, v1, nrec, shifts, np, stmp, e->st, &src); }
       if (where < 0) return fail(e, GTSG_ELIMIT, "too many records for the pair sort");
