@@ -94,6 +94,8 @@ struct GtsgEngine {
   bool own_stream = false;
   hipStream_t side[GTS_NSTREAMS] = {};  /* class launches */
   hipEvent_t ev_fork = nullptr, ev_join[GTS_NKLASS] = {};
+  hipStream_t team_st = nullptr;        /* k_components_team: next to the class launches AND the rounds of walk tasks */
+  hipEvent_t ev_team = nullptr;
   std::string err;
   /* vertices */
   uint32_t n = 0;
@@ -2440,6 +2442,16 @@ int gtsg_create(GtsgEngine **out, int device, void *stream)
   for (int k = 0; k < GTS_NKLASS && !rc; ++k)
     if (hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
   if (!rc && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
+  if (!rc) {
+    /* at the lowest priority: the runtime keeps a pool of hardware queues per
+       priority, so this stream does not share a queue with the streams of the
+       rounds (measured with a default-priority stream: the rounds of walk tasks
+       queued up behind the team kernel, 18 -> 200 ms) */
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&e->team_st, hipStreamNonBlocking, least) != hipSuccess) rc = GTSG_EHIP;
+  }
+  if (!rc && hipEventCreateWithFlags(&e->ev_team, hipEventDisableTiming) != hipSuccess) rc = GTSG_EHIP;
   const void *big_lds[] = {(const void *)k_walk_tasks_mixed, (const void *)k_walk_tasks,
                            (const void *)k_components_lds,
                            (const void *)k_components_pool, (const void *)k_components_fast2<GTS_FAST_WAVES>,
@@ -2487,6 +2499,8 @@ void gtsg_destroy(GtsgEngine *e)
   for (int k = 0; k < GTS_NSTREAMS; ++k) if (e->side[k]) hipStreamDestroy(e->side[k]);
   for (int k = 0; k < GTS_NKLASS; ++k) if (e->ev_join[k]) hipEventDestroy(e->ev_join[k]);
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
+  if (e->ev_team) hipEventDestroy(e->ev_team);
+  if (e->team_st) hipStreamDestroy(e->team_st);
   if (e->own_stream) hipStreamDestroy(e->st);
   delete e;
 }
@@ -3443,6 +3457,12 @@ static int run_components(GtsgEngine *e, int mode)
       HIPCHK(hipMemsetAsync(C.small_stat, 0, 32, e->st));
     }
     bool team_ran = false; C.plen = s_plen; C.tight = s_tight;
+    /* (a return before the join below must not leave the team kernel running on
+       the workspace) */
+    struct TeamJoin {
+      GtsgEngine *e; bool armed;
+      ~TeamJoin() { if (armed) hipStreamSynchronize(e->team_st); }
+    } team_join = {e, false};
     C.stat_fast = stat_fast; C.stat_slow = stat_slow; C.tstat = tstat; C.stat_clean = stat_clean;
     C.stat_ncc = stat_ncc;
     C.gorient = s_gorient; C.topo = s_topo; C.tpos = s_tpos;
@@ -3492,15 +3512,25 @@ static int run_components(GtsgEngine *e, int mode)
           if ((rc = dev_alloc(e, &e->team_pool, (size_t)team_bytes))) return rc;
           C.team_slab = e->team_pool; C.team_cap = team_bytes;
           C.team_used = (unsigned long long *)(e->d_scalars + GTS_S_TEAMUSED);
-          HIPCHK(hipMemsetAsync(C.team_used, 0, 8, e->st));
           C.team_stat = (unsigned long long *)(e->d_scalars + GTS_S_TEAMSTAT);
-          HIPCHK(hipMemsetAsync(C.team_stat, 0, 64, e->st));
+          /* on a stream of its own, joined only after the rounds of walk tasks: the
+             launch is as long as its largest component's program (223 ms on the 50 M
+             workload) and occupies a handful of CUs; team components do not defer
+             walks, so the rounds (18 ms there) have nothing to wait for in it */
+          hipStream_t ts = e->team_st;
+          HIPCHK(hipStreamWaitEvent(ts, e->ev_fork, 0));
+          HIPCHK(hipMemsetAsync(C.team_used, 0, 8, ts));
+          HIPCHK(hipMemsetAsync(C.team_stat, 0, 64, ts));
           team_ran = true;
+          team_join.armed = true;
           uint64_t lds = 18ull * maxcomp + 128 + 64ull * GTS_TCC_K * 8ull;
           if (lds > 159744u - 1024u) lds = 159744u - 1024u;
-          { ProfScope ps(e, kname);
-            k_components_team<<<kcount[nk], GTS_TEAM_WAVES * GTS_WAVE, (size_t)lds, e->st>>>(
-                C, order, first, kcount[nk], mode, (uint32_t)lds); }
+          hipEvent_t _a = nullptr, _b = nullptr;
+          if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ts); }
+          k_components_team<<<kcount[nk], GTS_TEAM_WAVES * GTS_WAVE, (size_t)lds, ts>>>(
+              C, order, first, kcount[nk], mode, (uint32_t)lds);
+          if (e->profile) { hipEventRecord(_b, ts); e->pending.push_back({kname, _a, _b}); }
+          HIPCHK(hipEventRecord(e->ev_team, ts));
         } else
           LAUNCH(kname, k_components, kcount[nk], GTS_WAVE, C, order, first, kcount[nk], mode,
                  (int)e->defer_global_components);
@@ -3742,6 +3772,7 @@ static int run_components(GtsgEngine *e, int mode)
       for (uint32_t k = 0; k < nk; ++k)
         e->stats["bytes_components_lds_class" + std::to_string(k)] = (int64_t)kbytes[k];
     }
+    if (team_ran) HIPCHK(hipStreamWaitEvent(e->st, e->ev_team, 0));
     LAUNCH("comp_count_errors", k_count_errors, nblk(ncomp), GTS_BLOCK, cerr, ncomp,
            e->d_scalars + 12);
     HIPCHK(hipMemsetAsync(e->d_scalars + 16, 0, 16, e->st));

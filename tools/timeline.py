@@ -3,8 +3,8 @@ order with start offset, duration and the idle gap before each."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last step = after the last k_radix_hist burst? take the tail starting at the last 'k_pair_keys'
-starts = [i for i, r in enumerate(rows) if "k_pair_keys" in r["Kernel_Name"]]
+# last step = the tail starting at the last histogram pass of the pair sort (the build's first kernel)
+starts = [i for i, r in enumerate(rows) if "k_onesweep_hist<unsigned long" in r["Kernel_Name"] or "k_pair_keys" in r["Kernel_Name"]]
 rows = rows[starts[-1]:] if starts else rows
 t0 = int(rows[0]["Start_Timestamp"]); end = t0
 for r in rows:
