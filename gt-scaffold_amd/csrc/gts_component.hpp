@@ -81,6 +81,7 @@ struct GtsCompView {
   int fast_walks;            /* 0: always run the reference's search */
   int batch_walks;           /* LDS-resident clean components: the walks of a cc side by side */
   int small_masks;           /* LDS-resident components of at most 64 contigs: peel_small() */
+  int team_coff;             /* k_components_team: the list offsets in LDS during the walks of a cc */
   int timing_skip_writeback; /* timing aid: run_fast() does not write its results to the global graph */
   int local_marks;           /* the LDS programs keep their marks in the working copy (GtsComponent::local_marks) */
   int help_walks;            /* k_components_pool: jobs for the walks that are made one by one (GtsHelpJob) */
@@ -458,7 +459,7 @@ struct GtsComponent {
   uint32_t team_wave, team_waves;
   /* LDS addresses of the team's vertex states, BFS queue and edge scratch (GTS_NONE:
      not in LDS): calc_cc_team reaches them with ds_* instructions */
-  uint32_t tl_vst, tl_queue, tl_scratch;
+  uint32_t tl_vst, tl_queue, tl_scratch, tl_stv;
   /* LDS the team has no other use for while it makes the walks of a cc (the
      search's scratch, its queue, the degrees of peel): the position bitmaps of
      the walks in flight (walks_clean_batch_global) */
@@ -467,7 +468,7 @@ struct GtsComponent {
   GTS_HD GtsComponent(const GtsCompView &cv, const GtsCompMemT<LDS> &mem, uint32_t comp)
       : C(cv), M(mem), c(comp), s0(cv.comp_off[comp]), e0g(cv.coff[cv.comp_off[comp]]),
         nv(mem.nv), nterm(0), ncc(0), err(0), qbase(0), qcap(0), qh(0), qn(0),
-        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), local_marks(false), any_scaffold_marks(false), run_clean(false), run_deferred(false), lean_stats(false), hub(nullptr), hub_me(0), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1), tl_vst(GTS_NONE), tl_queue(GTS_NONE), tl_scratch(GTS_NONE), tl_pbits(GTS_NONE), tl_pbits_bytes(0) {}
+        ntouch(0), nfast(0), nslow(0), tfast(0), tslow(0), npops(0), clean(false), reuse_cc(false), nodefer(0), reach_bits(nullptr), ubases(~0ull), walk_from(0), no_reference(false), needs_reference(false), deferred_late(false), was_all_live(false), local_marks(false), any_scaffold_marks(false), run_clean(false), run_deferred(false), lean_stats(false), hub(nullptr), hub_me(0), team(nullptr), team_base(nullptr), team_wave(0), team_waves(1), tl_vst(GTS_NONE), tl_queue(GTS_NONE), tl_scratch(GTS_NONE), tl_stv(GTS_NONE), tl_pbits(GTS_NONE), tl_pbits_bytes(0) {}
 
   /* a clock read costs a wait for every LDS operation in flight: only where somebody looks */
   GTS_HD uint64_t tick() const { return lean_stats ? 0 : W::clock(); }
@@ -543,7 +544,7 @@ struct GtsComponent {
   {
 #if defined(__HIPCC__)
     if constexpr (W::TEAM && !LDS) {
-      if (tl_vst != GTS_NONE && tl_queue != GTS_NONE && tl_scratch != GTS_NONE) { calc_cc_team(); return; }
+      if (tl_vst != GTS_NONE && tl_queue != GTS_NONE && tl_scratch != GTS_NONE && tl_stv != GTS_NONE) { calc_cc_team(); return; }
     }
 #endif
     bool unused;
@@ -572,13 +573,16 @@ struct GtsComponent {
     const l8p vst = (l8p)(uintptr_t)tl_vst;
     const l32p queue = (l32p)(uintptr_t)tl_queue;
     const l64p scratch = (l64p)(uintptr_t)tl_scratch;   /* [64][GTS_TCC_K]: end vertex | edge bits << 32 */
+    const l32p claim = (l32p)(uintptr_t)tl_stv;         /* a word per vertex: the lowest lane that wants to append it */
     const uint32_t lane = W::lane();
     /* the other functions reach the same bytes with flat_* instructions, which
        are not ordered with ds_* ones: everything in flight lands first (and
        the ds_writes below before this returns) */
     __builtin_amdgcn_s_waitcnt(0);
-    for (uint32_t s = lane; s < nv; s += W::WIDTH)
+    for (uint32_t s = lane; s < nv; s += W::WIDTH) {
       if (!gts_vertex_is_marked(vst[s])) vst[s] = GIS_UNVISITED;
+      claim[s] = 0xFFFFFFFFu;   /* (a vertex is appended once, so its word is used once) */
+    }
     W::fence();
     auto ccoff = M.ccoff;
     nterm = 0; ncc = 0;
@@ -620,7 +624,50 @@ struct GtsComponent {
               scratch[lane * GTS_TCC_K + k] = (uint64_t)nb[k] | (uint64_t)fl[k] << 32;
           }
           W::fence();
-          for (uint32_t i = 0; i < cnt; ++i) {
+          /* which of the chunk's vertices have at most GTS_TCC_K entries: up to eight
+             of those in a row are visited in ONE step, eight lanes each.  The queue
+             order stays the reference's: the lanes are in (queue position, list
+             position) order, a neighbour two of them see unvisited goes to the
+             lowest lane (an LDS minimum on a word per vertex), and the winners are
+             appended in lane order. */
+          const uint64_t shortm = W::ballot(lane < cnt && my_ee - my_eb <= GTS_TCC_K);
+          for (uint32_t i = 0; i < cnt;) {
+            const uint64_t longs = ~shortm >> i;
+            uint32_t nbat = longs ? W::ctz(longs) : W::WIDTH;
+            if (nbat > cnt - i) nbat = cnt - i;
+            if (nbat > W::WIDTH / GTS_TCC_K) nbat = W::WIDTH / GTS_TCC_K;
+            if (nbat >= 2) {
+              const uint32_t g = lane / GTS_TCC_K, a = lane % GTS_TCC_K;
+              const uint32_t vi = i + (g < nbat ? g : 0u);
+              const uint32_t cur = W::shfl(my_v, vi), eb = W::shfl(my_eb, vi), ee = W::shfl(my_ee, vi);
+              const bool in = g < nbat && eb + a < ee;
+              uint32_t fl = 0, nb = 0;
+              if (in) {
+                const uint64_t x = scratch[vi * GTS_TCC_K + a];
+                nb = (uint32_t)x; fl = (uint32_t)(x >> 32);
+              }
+              const bool live = in && !bits_marked(fl);
+              const bool sense = (fl & GTS_F_SENSE) != 0;
+              const bool unv = live && vst[nb] == GIS_UNVISITED;
+              if (unv) __hip_atomic_fetch_min(claim + nb, lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              const bool win = unv && claim[nb] == lane;
+              const uint64_t mask = W::ballot(win);
+              if (win) {
+                queue[bn + W::popc_below(mask, lane)] = nb;
+                vst[nb] = GIS_PROCESSED;
+              }
+              bn += W::popc(mask);
+              const uint64_t bs = W::ballot(live && sense), ba = W::ballot(live && !sense);
+              const uint64_t gmask = ((1ull << GTS_TCC_K) - 1ull) << (g * GTS_TCC_K);
+              const bool is_term = a == 0 && g < nbat && !((bs & gmask) && (ba & gmask));
+              const uint64_t tm = W::ballot(is_term);
+              if (is_term) M.term[nterm + W::popc_below(tm, lane)] = cur;
+              nterm += W::popc(tm);
+              if (a == 0 && g < nbat) vst[cur] = GIS_VISITED;
+              W::fence();
+              i += nbat;
+              continue;
+            }
             const uint32_t cur = W::bcast(my_v, i), eb = W::bcast(my_eb, i), ee = W::bcast(my_ee, i);
             bool has_s = false, has_a = false;
             for (uint32_t base = eb; base < ee; base += W::WIDTH) {
@@ -649,6 +696,7 @@ struct GtsComponent {
             if (!(has_s && has_a)) M.term[nterm++] = cur;
             if (lane == 0) vst[cur] = GIS_VISITED;
             W::fence();
+            ++i;
           }
           bh += cnt;
         }
@@ -2796,7 +2844,7 @@ struct GtsComponent {
      trips to L2 are gone. */
   template <uint32_t L>
   GTS_HD void walks_clean_batch_global(uint32_t j0, uint32_t nb, char *slots, uint32_t pb_lds, uint32_t pb_stride,
-                                       uint64_t &r_len, uint32_t &r_t, bool &r_bad)
+                                       uint32_t coff_lds, uint64_t &r_len, uint32_t &r_t, bool &r_bad)
   {
     const uint32_t lane = W::lane(), g = lane / L, a = lane % L;
     const uint32_t gsh = g * L;
@@ -2814,9 +2862,15 @@ struct GtsComponent {
     typedef uint32_t __attribute__((address_space(3))) *l32p;
     const bool pl = pb_lds != GTS_NONE;
     const l32p lbits = (l32p)(uintptr_t)(pl ? pb_lds + (active ? g : 0u) * pb_stride : 0u);
+    /* the list bounds from the team's copy in LDS (coff_lds; team_share_t) */
+    const bool cl = coff_lds != GTS_NONE;
+    const l32p lcoff = (l32p)(uintptr_t)(cl ? coff_lds : 0u);
+#define GTS_TCOFF(i) (cl ? (uint32_t)lcoff[i] : (uint32_t)M.coff[i])
+#else
+#define GTS_TCOFF(i) ((uint32_t)M.coff[i])
 #endif
     const uint32_t start = active ? (uint32_t)M.term[j0 + g] : 0u;
-    const uint32_t sb0 = M.coff[start] - M.e0, se0 = M.coff[start + 1] - M.e0;
+    const uint32_t sb0 = GTS_TCOFF(start) - M.e0, se0 = GTS_TCOFF(start + 1) - M.e0;
     bool hs = false, ha = false;
     for (uint32_t cur0 = sb0; W::ballot(active && cur0 < se0); cur0 += L) {
       const uint32_t ce = cur0 + a;
@@ -2864,7 +2918,7 @@ struct GtsComponent {
           u = M.topo[(uint32_t)wcur * 32u + bit];
           have_u = true; is_start = false; us = ua = false;
           --pending;
-          ub = cur = M.coff[u] - M.e0; ue = M.coff[u + 1] - M.e0;
+          ub = cur = GTS_TCOFF(u) - M.e0; ue = GTS_TCOFF(u + 1) - M.e0;
           du = ((M.gorient[u] & 3u) == 2) == forward;
           ndu = (int64_t)dist[u];
           plu = plen[u];
@@ -2927,6 +2981,7 @@ struct GtsComponent {
     }
     if (lane == 0) W::add64((uint64_t *)C.team_stat + 2, steps);
     r_len = best_len; r_t = best_t; r_bad = bad;
+#undef GTS_TCOFF
   }
 
   /* this wavefront's share of the walks of the cc [tb, te): batches
@@ -2953,6 +3008,20 @@ struct GtsComponent {
     const uint32_t pb_stride = ((nw * 4u + 15u) / 16u) * 16u;
     const uint32_t pb_lds = tl_pbits != GTS_NONE && (uint64_t)team_waves * G * pb_stride <= tl_pbits_bytes
                                 ? tl_pbits + team_wave * G * pb_stride : GTS_NONE;
+    /* behind the bitmaps the component's list offsets, if they fit as well: copied
+       by all wavefronts for every cc (33 KB, ~2 us: what else uses this LDS between
+       two ccs is not tracked); one more barrier */
+    uint32_t coff_lds = GTS_NONE;
+#if defined(__HIPCC__)
+    if (C.team_coff && pb_lds != GTS_NONE &&
+        (uint64_t)team_waves * G * pb_stride + ((uint64_t)nv + 1) * 4 <= tl_pbits_bytes) {
+      coff_lds = tl_pbits + team_waves * G * pb_stride;
+      uint32_t __attribute__((address_space(3))) *lc =
+          (uint32_t __attribute__((address_space(3))) *)(uintptr_t)coff_lds;
+      for (uint32_t i = team_wave * W::WIDTH + lane; i <= nv; i += team_waves * W::WIDTH) lc[i] = M.coff[i];
+      W::team_barrier();
+    }
+#endif
     uint64_t best_len = 0;
     uint32_t best_j = GTS_NONE, best_n = 0;
     bool bad = false;
@@ -2977,7 +3046,7 @@ struct GtsComponent {
       uint64_t r_len;
       uint32_t r_t;
       bool r_bad;
-      walks_clean_batch_global<L>(j0, nb, wbase, pb_lds, pb_stride, r_len, r_t, r_bad);
+      walks_clean_batch_global<L>(j0, nb, wbase, pb_lds, pb_stride, coff_lds, r_len, r_t, r_bad);
       const uint64_t tc2 = W::clock();
       if (lane == 0) {
         W::add64((uint64_t *)C.team_stat + 1, 1); W::add64((uint64_t *)C.team_stat + 4, tc1 - tc0);

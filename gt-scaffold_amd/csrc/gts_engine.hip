@@ -179,6 +179,8 @@ struct GtsgEngine {
   int64_t batch_walks = 2, batch_big_contigs = 64, batch_big_slots = 3;
   int64_t batch_huge_contigs = 256, batch_huge_slots = 5;   /* second tier: the launch's longest programs */
   int64_t lds_int16_distances = 1;   /* packed layout: int16 distances for components whose distances all fit */
+  int64_t team_coff = 0;     /* k_components_team: list offsets in LDS while the walks of a cc are made (measured: walks
+                                185 -> 180 ms, cycle removal 51 -> 58 ms on the 50 M workload's largest component: off) */
   int64_t small_masks = 1;   /* topological order of components of at most 64 contigs on bit masks (peel_small) */
   /* walks of global-memory components fan out only on request: the components
      that end up there on the 50 M workload are scaffolds tied together by an
@@ -1332,7 +1334,7 @@ k_components_team(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
   const uint32_t wv = threadIdx.x / GTS_WAVE;
   C.defer_min_nv = 0; C.defer_ref_min_nv = 0;
   GtsCompMem M = GtsComponent<GtsWave64Team>::global_mem(C, c);
-  uint32_t tl_vst = GTS_NONE, tl_queue = GTS_NONE, tl_scratch = GTS_NONE, tl_pbits = GTS_NONE, tl_pbits_bytes = 0;
+  uint32_t tl_vst = GTS_NONE, tl_queue = GTS_NONE, tl_scratch = GTS_NONE, tl_stv = GTS_NONE, tl_pbits = GTS_NONE, tl_pbits_bytes = 0;
   {
     /* the vertex-indexed arrays the traversals chase -- states, strands, the
        queue, degrees, the sweep order -- move to the workgroup's LDS as far as
@@ -1352,7 +1354,7 @@ k_components_team(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
     const uint32_t spare0 = off;
     if (off + 64u * GTS_TCC_K * 8u <= lds_bytes) { tl_scratch = lds_offset(smem + off); off += 64u * GTS_TCC_K * 8u; }
     if (off + nv4 <= lds_bytes) { M.queue = (uint32_t *)(smem + off); tl_queue = lds_offset(M.queue); off += nv4; }
-    if (off + nv4 <= lds_bytes) { M.st_v = (uint32_t *)(smem + off); off += nv4; }
+    if (off + nv4 <= lds_bytes) { M.st_v = (uint32_t *)(smem + off); tl_stv = lds_offset(M.st_v); off += nv4; }
     tl_pbits = lds_offset(smem + spare0); tl_pbits_bytes = off - spare0;
     if (off + nv4 <= lds_bytes) { M.topo = (uint32_t *)(smem + off); off += nv4; }
     if (off + nv4 <= lds_bytes) { M.tpos = (uint32_t *)(smem + off); off += nv4; }
@@ -1370,7 +1372,7 @@ k_components_team(GtsCompView C, const uint32_t *order, uint32_t first, uint32_t
     prog.team = &ctl; prog.team_base = C.team_slab + ctl.slab;
     prog.team_wave = wv; prog.team_waves = GTS_TEAM_WAVES;
   }
-  prog.tl_vst = tl_vst; prog.tl_queue = tl_queue; prog.tl_scratch = tl_scratch;
+  prog.tl_vst = tl_vst; prog.tl_queue = tl_queue; prog.tl_scratch = tl_scratch; prog.tl_stv = tl_stv;
   prog.tl_pbits = tl_pbits; prog.tl_pbits_bytes = tl_pbits_bytes;
   if (wv == 0) {
     prog.run(mode);
@@ -2518,6 +2520,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "lds_components")) e->lds_components = value != 0;
   else if (!strcmp(name, "batch_walks") && value >= 0 && value <= 2) e->batch_walks = value;   /* 2: components that are not clean too */
   else if (!strcmp(name, "small_masks")) e->small_masks = value != 0;
+  else if (!strcmp(name, "team_coff")) e->team_coff = value != 0;
   else if (!strcmp(name, "lds_int16_distances")) e->lds_int16_distances = value != 0;
   else if (!strcmp(name, "batch_big_contigs") && value >= 0) e->batch_big_contigs = value;
   else if (!strcmp(name, "batch_big_slots") && value >= 2 && value <= GTS_WALK_SLOTS_MAX) e->batch_big_slots = value;
@@ -3443,7 +3446,7 @@ static int run_components(GtsgEngine *e, int mode)
     C.distmap = s_distmap; C.ccoff = s_ccoff; C.wq_edge = wq_edge; C.wq_used = wq_used;
     C.wq_pool = wq_pool; C.wq_factor = (uint64_t)factor;
     C.wq_dist = wq_dist; C.cerr = cerr; C.max_pops = (uint64_t)e->max_walk_pops;
-    C.fast_walks = (int)e->fast_walks; C.batch_walks = (int)e->batch_walks; C.small_masks = (int)e->small_masks;
+    C.fast_walks = (int)e->fast_walks; C.batch_walks = (int)e->batch_walks; C.small_masks = (int)e->small_masks; C.team_coff = (int)e->team_coff;
     C.timing_skip_writeback = (int)e->timing_skip_writeback; C.local_marks = (int)e->local_marks;
     C.help_walks = (int)e->help_walks;
     C.nd = s_nd;
