@@ -302,9 +302,17 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
          itself like the walk queues), "defer_global_components" (0; 1: the
          components in global memory hand their walks out, too, with
          "global_task_pool_mb" (2048) of scratch slabs)
+     the build:
+       "pair_sort_full" (0: the records are bucketed on ~log2(records) bits of
+         their contig pair, three radix passes for 10^8 records; 1: sorted on the
+         whole pair, the fallback taken by itself when a thread of the fold
+         would look at more than "pair_bucket_limit" (2048) records of a bucket;
+         statistic "pair_sort_fallback" counts those),
+       "gather_unroll" (4: edges a thread of the gather-shaped build kernels),
+       "gather_nt" (1: nontemporal stores for their coalesced outputs)
      other:
-       "hub_degree" (32), "gather_unroll" (4: edges a thread of the gather-shaped
-       build kernels), "lds_poison" (-1; test aid: a byte to fill a component's
+       "hub_degree" (32), "team_coff" (0: 1 keeps the list offsets of a team's
+       component in LDS while the walks of a cc are made), "lds_poison" (-1; test aid: a byte to fill a component's
        LDS pages with before staging), "profile" (0, 1 = hipEvents around every
        kernel, 2 = also the per-component clocks: "us_sum_*" / "us_max_*", the
        slowest components as "top<r>_*", the size bands as "size_band<b>_*" and
