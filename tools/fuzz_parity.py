@@ -52,6 +52,12 @@ def params(seed):
         opts["batch_walks"] = 0
     if rng.random() < 0.1:
         opts["lds_components"] = 0
+    # round 4 (drawn last: the earlier draws of a seed stay what they were): the ways the
+    # records of a contig pair are brought together in the build
+    if rng.random() < 0.2:
+        opts["pair_bucket_limit"] = int(rng.choice([1, 4, 64]))
+    if rng.random() < 0.1:
+        opts["pair_sort_full"] = 1
     return n, kw, opts
 
 
