@@ -684,9 +684,14 @@ __global__ void k_repeat_edges(const uint32_t *estart, const uint32_t *twin,
    gather per edge for the end vertex' copy number and length) and then paired
    from LDS.  Without staging every pair re-gathers from HBM: 58 GB fetched for
    1.9 GB of edges (profiles/r01b_pmc_traffic.json). */
-/* staged as 32-bit values (17 B per edge, 3584 edges = 60 KB of LDS); a block
-   holding a distance or length outside int32 pairs from global memory */
-#define GTS_FP_CAP 3584
+/* staged as 32-bit values (17 B per edge, 3072 edges = 51 KB of LDS: three
+   workgroups a CU; with 3584 edges -- two workgroups, eight wavefronts a CU --
+   k_filter_pairs took 3.24 instead of 2.44 ms, with 2432 the edges that do not
+   fit and are paired from global memory make it 5.8 ms: same-call A/B, round 4);
+   a block holding a distance or length outside int32 pairs from global memory */
+#ifndef GTS_FP_CAP
+#define GTS_FP_CAP 3072
+#endif
 struct GtsEdgeAccLds {
   const int32_t *d, *l;
   const float *s, *c;
