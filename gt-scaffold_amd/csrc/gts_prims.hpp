@@ -266,7 +266,13 @@ k_onesweep_bases(uint32_t *ghist)
 /* pairs per thread: 12 with 64-bit keys, 16 with 32-bit keys (measured on
    100 M pairs, tools/microbench/sort_bench.hip: 64-bit 4.9 ms for six passes
    with 12, 5.7 with 16; 32-bit 1.96 ms for three passes with 16, 2.2 with 12) */
-template <typename K> struct GtsSortItems { static const int value = sizeof(K) > 4 ? 12 : 16; };
+#ifndef GTS_SORT_ITEMS64
+#define GTS_SORT_ITEMS64 12
+#endif
+#ifndef GTS_SORT_ITEMS32
+#define GTS_SORT_ITEMS32 16
+#endif
+template <typename K> struct GtsSortItems { static const int value = sizeof(K) > 4 ? GTS_SORT_ITEMS64 : GTS_SORT_ITEMS32; };
 
 template <typename K, int ITEMS, int SRC>
 __global__ void __launch_bounds__(GTS_SB)
@@ -394,7 +400,9 @@ static inline uint64_t gts_sort_tiles(uint64_t n, int items = 12)
    entries of every tile, the digit histograms of all passes, a ticket per pass */
 static inline uint64_t gts_sort_tmp_elems(uint64_t n)
 {
-  return (256 * gts_sort_tiles(n) + 256 + 1) * GTS_SORT_MAX_PASSES + 64;
+  /* (tiles of the smaller of the two tile sizes: enough for either key width) */
+  const int items = GTS_SORT_ITEMS64 < GTS_SORT_ITEMS32 ? GTS_SORT_ITEMS64 : GTS_SORT_ITEMS32;
+  return (256 * gts_sort_tiles(n, items) + 256 + 1) * GTS_SORT_MAX_PASSES + 64;
 }
 
 /* Stable sort of n (< 2^30) pairs on key bits [shift0 + 8*i) for the given
