@@ -3159,7 +3159,12 @@ struct GtsComponent {
         s = W::hub_load(&J->seq);
         if (!(s & 1u) && W::hub_cas(&J->seq, s, s + 1u) == s) {
           J->comp = c; J->tb = tb; J->te = te; J->clean = clean ? 1u : 0u; J->nv = nv;
-          J->next = tb; J->active = 0; J->need_ref = 0;
+          /* (J->active is NOT set here: it counts helpers between their increment and
+             their decrement, and one of them may still be on its way out of the last job --
+             a store of 0 under its feet left the count at -1 after its decrement, and
+             the owner of this job then waited for 0 for ever: one makescaffold call in
+             ~70 on the inversions workload never returned) */
+          J->next = tb; J->need_ref = 0;
           for (uint32_t w = 0; w < GTS_HUB_WAVES; ++w) { J->best_j[w] = GTS_NONE; J->best_len[w] = 0; J->best_n[w] = 0; }
           J->M = M;
           W::hub_release();
@@ -3183,7 +3188,11 @@ struct GtsComponent {
       typedef typename GtsCompMemT<LDS>::idx_t idx_t;
       GtsHelpJob *J = hub;
       const uint32_t lane = W::lane();
-      if (lane == 0) while (W::hub_load(&J->active) != 0) W::nap();
+      /* the gate first, then the wait: a helper counts itself in and THEN looks at
+         `ready` again (try_help), this side closes `ready` and THEN reads the count --
+         one of the two sees the other, so nobody joins a job whose results are being
+         read (it would walk on a graph that is being marked, or on the next job's) */
+      if (lane == 0) { W::hub_store(&J->ready, 0u); W::hub_fence(); while (W::hub_load(&J->active) != 0) W::nap(); }
       W::hub_acquire();
       W::fence();
       uint64_t best = cc_len;

@@ -1281,6 +1281,8 @@ struct GtsWave64 {
   { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   static __device__ __forceinline__ void hub_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
   static __device__ __forceinline__ void hub_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+  /* between a store and a load that must not change places (the gate / count handshake of a job) */
+  static __device__ __forceinline__ void hub_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
   static __device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(8); }
   template <class T> static __device__ __forceinline__ uint32_t lds_addr(T __attribute__((address_space(3))) *p)
   { return (uint32_t)(uintptr_t)p; }
@@ -1820,8 +1822,11 @@ __device__ __forceinline__ void pool_body(const GtsCompView *C0, const GtsPoolAr
         pool_unlock(ctl);
         if (hpos != GTS_NONE) {
           __hip_atomic_fetch_add(&J3->active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          /* (closed, or closed and opened again, meanwhile: not this one) */
-          if (__hip_atomic_load(&J3->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != s) {
+          GtsWave64::hub_fence();
+          /* (closing -- the owner has shut `ready` and is waiting for the count --, closed,
+             or closed and opened again meanwhile: not this one) */
+          if (__hip_atomic_load(&J3->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != s ||
+              __hip_atomic_load(&J3->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != s) {
             __hip_atomic_fetch_add(&J3->active, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             pool_bits_clear(ctl->used, pool_run_mask(hpos, hp));
             hpos = GTS_NONE;
