@@ -558,10 +558,11 @@ def main():
         # (or one workgroup), so no number of GPUs takes the component launch below this
         top = [sum(max(eng.stat("top%d_%s" % (r, k)), 0) for k in ("removecycles_us", "other_us", "walks_us", "ref_us"))
                for r in range(12)]
-        out["critical_path_ms"] = dict(longest_component_program=round(max(top) / 1e3, 3),
-                                       what="removecycles + makescaffold of the slowest component on its one "
-                                            "wavefront / workgroup: the floor of the component launch whatever "
-                                            "the number of GPUs (the stages before it divide by the rank count)")
+        if max(top) > 0:   # (the per-component clocks are copied back in "shards" mode only)
+          out["critical_path_ms"] = dict(longest_component_program=round(max(top) / 1e3, 3),
+                                         what="removecycles + makescaffold of the slowest component on its one "
+                                              "wavefront / workgroup: the floor of the component launch whatever "
+                                              "the number of GPUs (the stages before it divide by the rank count)")
         if mode == "partition" and stage_s:
             out["partition_stages_ms_per_step_rank0"] = {k: round(v / args.steps * 1e3, 3)
                                                          for k, v in stage_s.items()}
