@@ -179,6 +179,7 @@ struct GtsgEngine {
   int64_t batch_walks = 2, batch_big_contigs = 64, batch_big_slots = 3;
   int64_t batch_huge_contigs = 256, batch_huge_slots = 5;   /* second tier: the launch's longest programs */
   int64_t lds_int16_distances = 1;   /* packed layout: int16 distances for components whose distances all fit */
+  int64_t team_lds_bytes = 0;          /* test aid: cap of the team kernel's dynamic LDS (0: what the largest component asks for) */
   int64_t team_coff = 0;     /* k_components_team: list offsets in LDS while the walks of a cc are made (measured: walks
                                 185 -> 180 ms, cycle removal 51 -> 58 ms on the 50 M workload's largest component: off) */
   int64_t small_masks = 1;   /* topological order of components of at most 64 contigs on bit masks (peel_small) */
@@ -2531,6 +2532,7 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value)
   else if (!strcmp(name, "batch_walks") && value >= 0 && value <= 2) e->batch_walks = value;   /* 2: components that are not clean too */
   else if (!strcmp(name, "small_masks")) e->small_masks = value != 0;
   else if (!strcmp(name, "team_coff")) e->team_coff = value != 0;
+  else if (!strcmp(name, "team_lds_bytes") && value >= 0) e->team_lds_bytes = value;
   else if (!strcmp(name, "lds_int16_distances")) e->lds_int16_distances = value != 0;
   else if (!strcmp(name, "batch_big_contigs") && value >= 0) e->batch_big_contigs = value;
   else if (!strcmp(name, "batch_big_slots") && value >= 2 && value <= GTS_WALK_SLOTS_MAX) e->batch_big_slots = value;
@@ -3538,6 +3540,7 @@ static int run_components(GtsgEngine *e, int mode)
           team_join.armed = true;
           uint64_t lds = 18ull * maxcomp + 128 + 64ull * GTS_TCC_K * 8ull;
           if (lds > 159744u - 1024u) lds = 159744u - 1024u;
+          if (e->team_lds_bytes > 0 && (uint64_t)e->team_lds_bytes < lds) lds = (uint64_t)e->team_lds_bytes;   /* test aid */
           hipEvent_t _a = nullptr, _b = nullptr;
           if (e->profile) { _a = get_event(e); _b = get_event(e); hipEventRecord(_a, ts); }
           k_components_team<<<kcount[nk], GTS_TEAM_WAVES * GTS_WAVE, (size_t)lds, ts>>>(

@@ -312,7 +312,8 @@ int gtsg_set_option(GtsgEngine *e, const char *name, int64_t value);
        "gather_nt" (1: nontemporal stores for their coalesced outputs)
      other:
        "hub_degree" (32), "team_coff" (0: 1 keeps the list offsets of a team's
-       component in LDS while the walks of a cc are made), "lds_poison" (-1; test aid: a byte to fill a component's
+       component in LDS while the walks of a cc are made), "team_lds_bytes" (0;
+       test aid: a cap on the team kernel's LDS), "lds_poison" (-1; test aid: a byte to fill a component's
        LDS pages with before staging), "profile" (0, 1 = hipEvents around every
        kernel, 2 = also the per-component clocks: "us_sum_*" / "us_max_*", the
        slowest components as "top<r>_*", the size bands as "size_band<b>_*" and

@@ -1011,6 +1011,21 @@ def test_team_kernel_for_global_memory_components(case):
     assert eng.digest() == eng0.digest()
 
 
+@pytest.mark.parametrize("lds_bytes", [3000, 12000, 40000])
+def test_team_components_that_do_not_fit_the_workgroup_lds(lds_bytes):
+    """a component whose vertex arrays do not all fit the team's LDS (18 B a contig
+    against 158 KB: more than ~9000 contigs) keeps what does not fit behind generic
+    pointers: the terminal search on one wavefront, the level-by-level order on global
+    memory, the walks' bitmaps in the slab -- the other half of every `tl_* != GTS_NONE`
+    test of k_components_team.  Forced with a cap on the kernel's LDS (team_lds_bytes):
+    with 3000 bytes nothing but the small components' states fits, with 12000 the queue
+    of components of up to a few hundred contigs, with 40000 most of them whole."""
+    g = make_inputs(12000, 1201, p_chimeric=0.08, p_inversion=0.0, p_bubble=0.05, links_per_side=4,
+                    unique_pairs=True)
+    eng, _ = run_pipeline(g, lds_components=0, team_max_components=1 << 30, team_lds_bytes=lds_bytes)
+    assert eng.stat("team_components") == eng.stat("components") > 0
+
+
 def test_bench_verify_small():
     """bench.py --verify at a small size: the headline line with the secondary workload
     behind it, the digest compared with the oracle's on the headline graph (ADVICE r03:
