@@ -1008,7 +1008,9 @@ __global__ void k_live_union(GtsGraphView G, const uint32_t *estart,
      the other way round -- a live edge sets its own flag and its twin's, no
      look-up by the others: 2.31 -> 3.1 ms; a random byte store costs a sector
      read and a write-back, and the live edges' stores cost more than the dead
-     edges' reads.) */
+     edges' reads.  Also tried: of two live twins only the one that starts at the
+     smaller contig joins the pair, the other looks at its twin's state instead of
+     searching the forest twice: 2.29 -> 2.39 ms.) */
   incl[p] = lv ? 1 : !gts_edge_is_marked(G.state[G.twin[p]]) ? 1 : 0;
   if (!lv) return;
   /* (which vertices have a live edge at either end is read off the forest
