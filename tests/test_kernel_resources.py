@@ -53,3 +53,18 @@ def test_write_back_loops_are_not_unrolled():
     assert m, "run(): the write-back loop lost its '#pragma unroll 1'"
     # run_fast(): both write-back loops
     assert len(re.findall(r"#pragma unroll 1\s*\n\s*for \(uint32_t (s|k) = lane;", src)) >= 3
+
+
+def test_build_and_filter_kernels_keep_their_occupancy(res):
+    """what round 4's measurements rest on: the streaming kernels of the build stage hold no
+    scratch, the radix pass stays at four wavefronts a SIMD (two 512-thread workgroups a CU:
+    forcing more made it spill, 1.9 -> 11.6 ms), and the pair kernels of the filter stage
+    3072 edges a workgroup so that three of them share a CU's LDS (3.24 -> 2.44 ms)"""
+    for name, r in kernels(res, r"k_pair_segments_bucket|k_gather_csrILi4|k_twinsILi4|k_emit_edges|k_radix_scatter").items():
+        assert r["vspill"] == 0 and r["scratch"] == 0, (name, r)
+    for name, r in kernels(res, r"k_radix_scatter").items():
+        assert r["vgpr"] <= 128, (name, r)
+    src = open(os.path.join(ROOT, "gt-scaffold_amd", "csrc", "gts_engine.hip")).read()
+    m = re.search(r"#define GTS_FP_CAP (\d+)", src)
+    assert m and 17 * int(m.group(1)) * 3 <= 160 * 1024, "three workgroups of k_filter_pairs no longer fit a CU's LDS"
+
